@@ -1,0 +1,311 @@
+"""Demo-variant task layouts + score_on_end_of_traj restatements.
+
+TEST INFRASTRUCTURE.  One class per reference task file; only the Demo
+(all rand_* False) branches are restated.  Scores follow the reference's
+float64 numpy/Python operation order so they can be compared bit-for-bit with
+the product's host scoring.
+"""
+import itertools as it
+import math
+
+import numpy as np
+
+from .entities_ref import GoalRegion, Robot, Shape
+
+ROBOT_RAD = 0.2          # base_env.py:62
+ROBOT_MASS = 1.0         # base_env.py:63
+SHAPE_RAD = ROBOT_RAD * 0.6   # base_env.py:64
+
+
+def _robot(pos, angle):
+    return Robot(radius=ROBOT_RAD, init_pos=tuple(pos), init_angle=angle, mass=ROBOT_MASS)
+
+
+def _shape(shape_type, colour, pos, angle):
+    return Shape(shape_type=shape_type, colour_name=colour, shape_size=SHAPE_RAD,
+                 init_pos=tuple(pos), init_angle=angle)
+
+
+class TaskRef:
+    name = None
+    ep_len = None
+
+    def __init__(self, world):
+        self.world = world
+        self.on_reset()
+
+    def block_pos(self, ent):
+        return self.world_pose(ent.shape_body)[:2]
+
+    def world_pose(self, body):
+        import ctypes as C
+        w = self.world
+        n = w.L.ref_nbodies(w.h)
+        buf = (C.c_double * (9 * n))()
+        w.L.ref_get_bodies(w.h, buf)
+        return (buf[9 * body], buf[9 * body + 1], buf[9 * body + 2])
+
+
+class MoveToCornerRef(TaskRef):
+    """benchmarks/move_to_corner.py:31-75."""
+    name, ep_len = 'MoveToCorner', 80
+
+    def on_reset(self):
+        w = self.world
+        self.robot = w.add(_robot((0.4, -0.0), 0.55 * math.pi))
+        self.shape = w.add(_shape('square', 'red', (0.1, -0.65), 0.13 * math.pi))
+
+    def score_on_end_of_traj(self):
+        robot_pos = np.asarray(self.block_pos(self.shape))
+        dist = np.linalg.norm(np.asarray([-1.0, 1.0]) - robot_pos)
+        succeed_dist = np.sqrt(2) / 2
+        furthest_dist = np.sqrt(2)
+        drange = (furthest_dist - succeed_dist)
+        score = min(1.0, max(0.0, furthest_dist - dist) / drange)
+        return score
+
+
+class MoveToRegionRef(TaskRef):
+    """benchmarks/move_to_region.py:9-11,30-94."""
+    name, ep_len = 'MoveToRegion', 40
+
+    def on_reset(self):
+        w = self.world
+        self.goal = w.add(GoalRegion(-0.62, -0.17, 0.76, 0.75, 'blue'))
+        self.robot = w.add(_robot((0.058, 0.53), -2.13))
+
+    def score_on_end_of_traj(self):
+        # goal_shape.point_query(robot_pos) -> cpPolyShapePointQuery: dist <= 0
+        # iff the point is not strictly outside any edge plane (or lies on the
+        # boundary).  Box is axis-aligned, radius 0.
+        x, y, _ = self.world_pose(self.robot.robot_body)
+        l, b, r, t = self.goal.bb
+        outside = (x - r > 0.0) or (y - t > 0.0) or (l - x > 0.0) or (b - y > 0.0)
+        return 0.0 if outside else 1.0
+
+
+class MatchRegionsRef(TaskRef):
+    """benchmarks/match_regions.py:44-213."""
+    name, ep_len = 'MatchRegions', 120
+
+    def on_reset(self):
+        w = self.world
+        robot = _robot((-0.5, 0.1), -math.pi * 1.2)
+        self.sensor = w.add(GoalRegion(0.1, 0.7, 0.7, 0.6, 'green'))
+        target_types = ['star', 'square']
+        target_poses = [(0.8, -0.7, 2.37), (-0.68, 0.72, 1.28)]
+        distractor_colours = ['red', 'blue', 'yellow']          # SHAPE_COLOURS minus green
+        distractor_types = [[], ['pentagon'], ['circle', 'pentagon']]
+        distractor_poses = [[], [(-0.05, -0.2, -1.09)], [(-0.75, -0.55, 2.78), (0.3, -0.82, -1.15)]]
+        self.target_shapes = [_shape(t, 'green', (x, y), a) for t, (x, y, a) in zip(target_types, target_poses)]
+        self.distractor_shapes = []
+        for col, types, poses in zip(distractor_colours, distractor_types, distractor_poses):
+            for t, (x, y, a) in zip(types, poses):
+                self.distractor_shapes.append(_shape(t, col, (x, y), a))
+        for e in self.target_shapes + self.distractor_shapes:
+            w.add(e)
+        self.robot = w.add(robot)
+
+    def score_on_end_of_traj(self):
+        ents = self.target_shapes + self.distractor_shapes
+        overlap = self.sensor.get_overlapping_ents(ents)
+        n_t = len([e for e in overlap if e in self.target_shapes])
+        n_d = len([e for e in overlap if e in self.distractor_shapes])
+        target_frac_done = n_t / len(self.target_shapes)
+        if len(overlap) == 0:
+            contamination_rate = 0
+        else:
+            contamination_rate = n_d / len(overlap)
+        return target_frac_done * (1 - contamination_rate)
+
+
+def longest_line(points, inlier_dist, max_separation):
+    """benchmarks/make_line.py:31-71."""
+    points = np.asarray(points)
+    npts = len(points)
+    best = min(1, npts)
+    for i in range(npts - 1):
+        for j in range(i + 1, npts):
+            pi = points[i]
+            offs = points - pi[None]
+            pj_off = offs[j]
+            pj_unit = pj_off / np.linalg.norm(pj_off)
+            proj_lens = np.squeeze(offs @ pj_unit[:, None], axis=1)
+            dists = np.linalg.norm(offs - proj_lens[:, None] * pj_unit, axis=1)
+            inlier_inds, = np.nonzero(dists <= inlier_dist)
+            if len(inlier_inds) <= best:
+                continue
+            inlier_proj_lens = proj_lens[inlier_inds]
+            inlier_proj_lens.sort()
+            seps = np.abs(np.diff(inlier_proj_lens))
+            all_runs = it.groupby(seps <= max_separation)
+            one_run_lens = [len(list(r)) for v, r in all_runs if v]
+            max_run = max(one_run_lens, default=0) + 1
+            if max_run > best:
+                best = max_run
+    return best
+
+
+class MakeLineRef(TaskRef):
+    """benchmarks/make_line.py:10-28,91-152."""
+    name, ep_len = 'MakeLine', 180
+
+    def on_reset(self):
+        w = self.world
+        robot = _robot((0.702, -0.255), 0.347)
+        colours = ['blue', 'yellow', 'red', 'green']
+        shapes = ['star', 'circle', 'star', 'pentagon']
+        poses = [((0.790, -0.820), -0.721), ((-0.177, 0.383), -1.733),
+                 ((-0.051, -0.128), 2.696), ((-0.292, -0.745), -0.159)]
+        self.blocks = [w.add(_shape(s, c, p, a)) for s, c, (p, a) in zip(shapes, colours, poses)]
+        self.robot = w.add(robot)
+
+    def score_on_end_of_traj(self):
+        points = np.asarray([self.block_pos(b) for b in self.blocks], dtype='float64')
+        line_len = longest_line(points, SHAPE_RAD * 1.5, SHAPE_RAD * 3.5)
+        max_line_len = len(points)
+        min_line_len = max(max_line_len - 2, 2)
+        return max(line_len - min_line_len, 0) / (max_line_len - min_line_len)
+
+
+class FindDupeRef(TaskRef):
+    """benchmarks/find_dupe.py:7-38,72-216."""
+    name, ep_len = 'FindDupe', 100
+
+    def on_reset(self):
+        w = self.world
+        robot = _robot((-0.57, 0.25), 3.83)
+        out_shapes = ['pentagon', 'circle', 'circle', 'square', 'star', 'pentagon']
+        out_colours = ['green', 'red', 'red', 'yellow', 'blue', 'yellow']
+        out_poses = [((-0.066751, 0.7552), -2.9266), ((-0.05195, 0.31468), 1.5418),
+                     ((0.57528, -0.46865), -2.2141), ((0.40594, -0.74977), 0.24582),
+                     ((0.45254, 0.3681), -1.0834), ((0.76849, -0.10652), 0.10028)]
+        self.sensor = w.add(GoalRegion(-0.72, -0.22, 0.67, 0.72, 'yellow'))
+        self.outside_blocks, self.target_set = [], []
+        for s, c, (p, a) in zip(out_shapes, out_colours, out_poses):
+            blk = w.add(_shape(s, c, p, a))
+            self.outside_blocks.append(blk)
+            if c == 'yellow' and s == 'pentagon':
+                self.target_set.append(blk)
+        self.query_block = w.add(_shape('pentagon', 'yellow', (-0.33, -0.49), -0.51))
+        self.target_set.append(self.query_block)
+        self.distractor_set = [b for b in self.outside_blocks if b not in self.target_set]
+        self.robot = w.add(robot)
+
+    def score_on_end_of_traj(self):
+        overlap = self.sensor.get_overlapping_ents([self.query_block, *self.outside_blocks])
+        n_t = len([e for e in overlap if e in self.target_set])
+        n_d = len([e for e in overlap if e in self.distractor_set])
+        have_two_shapes = float(n_t >= 2)
+        if len(overlap) == 0:
+            contamination_rate = 0
+        else:
+            contamination_rate = n_d / len(overlap)
+        return have_two_shapes * (1 - contamination_rate)
+
+
+class FixColourRef(TaskRef):
+    """benchmarks/fix_colour.py:15-40,69-202."""
+    name, ep_len = 'FixColour', 60
+
+    def on_reset(self):
+        w = self.world
+        robot = _robot((0.368, 0.586), 0.718)
+        block_colours = ['green', 'green', 'blue']
+        block_shapes = ['pentagon', 'square', 'pentagon']
+        block_poses = [((0.289, 0.030), 0.307), ((0.133, -0.561), 1.699), ((-0.336, 0.000), -1.529)]
+        region_xyhws = [(-0.032, 0.348, 0.427, 0.468), (0.019, -0.391, 0.460, 0.458),
+                        (-0.681, 0.196, 0.498, 0.418)]
+        region_colours = ['green', 'green', 'red']
+        self.sensors = [w.add(GoalRegion(*xyhw, col)) for col, xyhw in zip(region_colours, region_xyhws)]
+        self.blocks, self.target_blocks = [], []
+        for s, c, tc, (p, a) in zip(block_shapes, block_colours, region_colours, block_poses):
+            blk = _shape(s, c, p, a)
+            self.blocks.append(blk)
+            self.target_blocks.append([] if c != tc else [blk])
+        for b in self.blocks:
+            w.add(b)
+        self.robot = w.add(robot)
+
+    def score_on_end_of_traj(self):
+        for sensor, tgt in zip(self.sensors, self.target_blocks):
+            overlap = sensor.get_overlapping_ents(self.blocks)
+            # list(set) == [..]: equal only for 0 or 1 elements
+            if len(overlap) != len(tgt) or any(a is not b for a, b in zip(overlap, tgt)):
+                return 0.0
+        return 1.0
+
+
+class _ClusterRef(TaskRef):
+    """benchmarks/cluster.py:67-216."""
+    ep_len = 240
+    by = None
+
+    def on_reset(self):
+        w = self.world
+        robot = _robot(*self.ROBOT_POSE)
+        self.shape_ents = [w.add(_shape(s, c, p, a))
+                           for (p, a), c, s in zip(self.POSES, self.COLOURS, self.SHAPES)]
+        c_values_list = np.asarray(self.COLOURS if self.by == 'colour' else self.SHAPES, dtype='object')
+        self.characteristic_values = np.unique(c_values_list)
+        self.blocks_by_characteristic = {}
+        for shape, c_value in zip(self.shape_ents, c_values_list):
+            self.blocks_by_characteristic.setdefault(c_value, []).append(shape)
+        self.robot = w.add(robot)
+
+    def score_on_end_of_traj(self):
+        nvals = len(self.characteristic_values)
+        centroids = np.zeros((nvals, 2))
+        for c_idx, c_value in enumerate(self.characteristic_values):
+            c_blocks = self.blocks_by_characteristic.get(c_value)
+            if not c_blocks:
+                centroid = (0, 0)
+            else:
+                positions = np.asarray([self.block_pos(b) for b in c_blocks])
+                centroid = np.mean(positions, axis=0)
+            centroids[c_idx] = centroid
+        min_margin = 2.0
+        n_blocks = 0
+        n_correct = 0
+        for c_idx, c_value in enumerate(self.characteristic_values):
+            for block in self.blocks_by_characteristic.get(c_value, []):
+                n_blocks += 1
+                block_pos = np.array([list(self.block_pos(block))])
+                centroid_sses = np.sum((block_pos - centroids)**2, axis=1)
+                indices = np.arange(nvals)
+                true_sse, = centroid_sses[indices == c_idx]
+                bad_sses = centroid_sses[indices != c_idx]
+                nearest_bad_centroid = np.min(bad_sses)
+                true_centroid_sse = centroid_sses[c_idx]
+                margin = min_margin * true_centroid_sse     # squared distance: reference quirk
+                n_correct += int(np.sqrt(true_sse) < np.sqrt(nearest_bad_centroid) - margin)
+        frac_correct = float(n_correct) / max(n_blocks, 1)
+        thresh = 0.75
+        return max(frac_correct - thresh, 0) / (1 - thresh)
+
+
+class ClusterColourRef(_ClusterRef):
+    """benchmarks/cluster.py:219-256."""
+    name, by = 'ClusterColour', 'colour'
+    ROBOT_POSE = ((0.71692, -0.34374), 0.83693)
+    COLOURS = ['blue', 'blue', 'blue', 'green', 'green', 'red', 'yellow', 'yellow']
+    SHAPES = ['circle', 'star', 'square', 'pentagon', 'pentagon', 'square', 'star', 'pentagon']
+    POSES = [((-0.5147, 0.14149), -0.38871), ((-0.1347, -0.71414), 1.0533),
+             ((-0.74247, -0.097592), 1.1571), ((-0.077363, -0.42964), -0.64379),
+             ((0.51978, 0.1853), -1.1762), ((-0.5278, -0.21642), 2.9356),
+             ((-0.54039, 0.48292), 0.072818), ((-0.16761, 0.64303), -2.3255)]
+
+
+class ClusterShapeRef(_ClusterRef):
+    """benchmarks/cluster.py:259-297."""
+    name, by = 'ClusterShape', 'type'
+    ROBOT_POSE = ((0.286, -0.202), -1.878)
+    COLOURS = ['yellow', 'blue', 'red', 'red', 'green', 'yellow', 'blue', 'green']
+    SHAPES = ['square', 'pentagon', 'pentagon', 'pentagon', 'circle', 'star', 'star', 'circle']
+    POSES = [((-0.414, 0.297), -1.731), ((0.068, 0.705), 2.184), ((0.821, 0.220), 0.650),
+             ((-0.461, -0.749), -2.673), ((0.867, -0.149), -2.215), ((-0.785, -0.140), -0.405),
+             ((-0.305, -0.226), 1.341), ((0.758, -0.708), -2.140)]
+
+
+TASKS = {c.name: c for c in (MoveToCornerRef, MoveToRegionRef, MatchRegionsRef, MakeLineRef,
+                             FindDupeRef, FixColourRef, ClusterColourRef, ClusterShapeRef)}

@@ -1,0 +1,94 @@
+"""Pins for the oracle rasteriser + LoRes4E preprocessor restatement."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.env_ref import LoRes4ERef, RefEnv, area_downsample
+from oracle.style_ref import COLOURS_RGB, darken_rgb, lighten_rgb, to_u8
+
+IMG_DIR = '/root/reference/images'
+
+
+def test_palette_matches_survey_appendix_d():
+    # SURVEY.md Appendix D (u8 palette: base / darkened / lightened x2)
+    expect = {
+        'blue': ((135, 185, 211), (110, 170, 202), (194, 219, 233)),
+        'yellow': ((254, 213, 123), (254, 201, 86), (254, 234, 188)),
+        'red': ((245, 129, 165), (243, 94, 141), (250, 190, 209)),
+        'green': ((195, 208, 130), (183, 198, 105), (224, 231, 191)),
+        'grey': ((162, 163, 175), (144, 145, 159), (208, 208, 214)),
+    }
+    for name, (base, dark, light2) in expect.items():
+        c = COLOURS_RGB[name]
+        assert to_u8(c) == base
+        assert to_u8(darken_rgb(c)) == dark
+        assert to_u8(lighten_rgb(c, 2)) == light2
+    assert to_u8(lighten_rgb(COLOURS_RGB['grey'], 4)) == (231, 231, 234)
+
+
+def test_area_downsample_round_half_even():
+    img = np.zeros((4, 4, 1), dtype=np.uint8)
+    img[0, 0, 0] = 8          # mean 0.5 -> 0 (ties to even)
+    assert area_downsample(img, 4)[0, 0, 0] == 0
+    img[0, 1, 0] = 16         # mean 1.5 -> 2
+    assert area_downsample(img, 4)[0, 0, 0] == 2
+    img[0, 2, 0] = 1          # 25/16 = 1.5625 -> 2
+    assert area_downsample(img, 4)[0, 0, 0] == 2
+    rng = np.random.RandomState(0)
+    big = rng.randint(0, 256, size=(384, 384, 12)).astype(np.uint8)
+    out = area_downsample(big, 4)
+    ref = np.rint(big.reshape(96, 4, 96, 4, 12).astype(np.float64).mean(axis=(1, 3)))
+    assert np.array_equal(out, ref.astype(np.uint8))
+
+
+def test_ego_frame_geometry():
+    """Robot centre lands at (0.5 W, 0.15 H) from the bottom-left and faces up
+    (base_env.py:294-301)."""
+    e = RefEnv('MoveToCorner')
+    e.reset()
+    ego = e.render('ego')
+    assert ego.shape == (384, 384, 3)
+    # pixel just below the robot centre: inside the r=0.19 grey disc (the eyes sit above)
+    row = 383 - int(0.15 * 384) + 8
+    assert tuple(ego[row, 192]) == (162, 163, 175)
+    # 0.195 units to the left/right of centre: the dark ring (0.19 < r < 0.2)
+    off = int(round(0.195 * 384 / 2.04))
+    assert tuple(ego[383 - int(0.15 * 384), 192 - off]) == (144, 145, 159)
+    # far corner outside the arena: background
+    e2 = RefEnv('MoveToRegion')
+    e2.reset()
+    assert tuple(e2.render('allo')[1, 1]) == (231, 231, 234)
+
+
+def test_lores4e_stack_semantics():
+    """FlattenFrameStack: reset fills 4 copies; step appends newest last
+    (benchmarks/__init__.py:124-136)."""
+    env = LoRes4ERef(RefEnv('MoveToCorner'))
+    obs0 = env.reset()
+    assert obs0.shape == (96, 96, 12) and obs0.dtype == np.uint8
+    for k in range(1, 4):
+        assert np.array_equal(obs0[..., :3], obs0[..., 3 * k:3 * k + 3])
+    obs1, _, _, _ = env.step(4)
+    obs2, _, _, _ = env.step(4)
+    assert np.array_equal(obs1[..., :9], obs0[..., 3:])
+    assert np.array_equal(obs2[..., :9], obs1[..., 3:])
+    assert not np.array_equal(obs2[..., 9:], obs2[..., 6:9])
+    # resize-after-stack == stack-after-resize (per-channel box filter)
+    assert np.array_equal(obs2[..., 9:], env.env.render_lores('ego'))
+
+
+@pytest.mark.skipif(not os.path.isdir(IMG_DIR), reason='reference images only exist in the build container')
+@pytest.mark.parametrize('task', ['MoveToCorner', 'MoveToRegion', 'MatchRegions', 'MakeLine',
+                                  'FindDupe', 'FixColour', 'ClusterColour', 'ClusterShape'])
+def test_allo_reset_frame_vs_reference_png(task):
+    """Weak pin: images/static-<task>-demo-v0.png are 192x192
+    allocentric renders of each Demo initial state."""
+    from PIL import Image
+    e = RefEnv(task)
+    e.reset()
+    half = area_downsample(e.render('allo'), 2).astype(int)
+    ref = np.asarray(Image.open(os.path.join(IMG_DIR, f'static-{task.lower()}-demo-v0.png')).convert('RGB')).astype(int)
+    d = np.abs(half - ref).max(axis=2)
+    assert d.mean() < 1.0                  # same layout, palette and draw order
+    assert (d > 24).mean() < 0.02          # only edge pixels differ (AA / resampling differences)
