@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's headline metric on MI355X:
+
+    env-steps/sec (incl. 96x96 LoRes4E render) at N_envs=4096 on MoveToCorner-Demo-LoRes4E-v0
+
+A "step" is one pass of the hot path over one batch: BaseEnv.step() for all 4096 envs of the rank
+(set_action + 10 physics substeps x 10 solver iterations, episode bookkeeping with auto-reset and
+host scoring at episode ends, ego rasterisation + INTER_AREA + FlattenFrameStack into the
+[N,96,96,12] u8 observation tensor) under random actions that are already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0 (contract in the task statement) + "roofline" for the dominant kernel
+(HIP-event timed on the launch stream, inside the timed region) + "cpu_baseline" (the fp64 oracle
+port on the host cores, rank 0 at N=1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+TASK = 'MoveToCorner-Demo-LoRes4E-v0'
+N_ENVS = 4096
+
+
+def _cpu_worker(args):
+    seed, seconds = args
+    from oracle.env_ref import LoRes4ERef, RefEnv
+    env = LoRes4ERef(RefEnv('MoveToCorner'))
+    rng = np.random.RandomState(seed)
+    env.reset()
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        _, _, done, _ = env.step(rng.randint(18))
+        n += 1
+        if done:
+            env.reset()
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(seconds=12.0):
+    """The oracle (fp64 restatement of the pymunk + GL + cv2 path; NOT pymunk itself) on the host cores: one
+    env per process, random actions, physics + 384x384 ego render + 4-frame stack + INTER_AREA, like
+    misc/benchmark_env_perf.py:12-18 drives the reference."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(1000 + k, seconds) for k in range(cores)])
+    steps = sum(r[0] for r in res)
+    wall = max(r[1] for r in res)
+    return {'value': steps / wall, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{steps} env-steps of MoveToCorner-Demo-LoRes4E (oracle/ fp64 C port incl. 384x384 ego render, '
+                      f'4-frame stack, 4x4 box filter), {cores} processes x {seconds:.0f} s, random actions'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=400)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--task', default=TASK)
+    ap.add_argument('--envs', type=int, default=N_ENVS)
+    ap.add_argument('--lanes', type=int, default=0)
+    ap.add_argument('--dtype', default='f32')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world)      # "nccl" == RCCL on ROCm
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    device = f'cuda:{local_rank}'
+
+    import magical_amd
+    env = magical_amd.make(args.task, n_envs=args.envs, device=device, lanes_per_env=args.lanes, dtype=args.dtype)
+    n, K, W = args.envs, args.steps, args.warmup
+    # synthetic input: A = RandomState(seed).randint(0, 18, (T, N)) uploaded once; each rank its own slice
+    tape = torch.as_tensor(np.random.RandomState(rank).randint(0, 18, size=(K + W, n)).astype(np.int32), device=device)
+    obs = env.reset()
+    for s in range(W):
+        obs, rew, done, info = env.step(tape[s])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    env.set_timing(True)
+    score_sum = torch.zeros(1, dtype=torch.float64, device=device)
+    n_eps = 0
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(W, W + K):
+        obs, rew, done, info = env.step(tape[s])
+        if done.any():
+            n_eps += int(done.sum())
+            score_sum += float(info['eval_score'][done].sum())
+    if world > 1:
+        # end-of-rollout gather over xGMI (RCCL): per-rank score sums; observations never leave their GPU
+        gathered = torch.zeros(world, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(gathered, score_sum)
+        score_sum = gathered.sum(dim=0, keepdim=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_ms = env.read_timing('step')
+    rast_ms = env.read_timing('render')
+    env.set_timing(False)
+
+    if rank == 0:
+        value = n * world * K / elapsed
+        # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): persistent state read once + written once;
+        # stacked observation: read the 9 surviving channels, write all 12, per pixel
+        rows_p, rows_f = env.state_p.shape[0], env.state_f.shape[0]
+        slots = env._info('cache_slots')
+        mean_cache = float(env.state_i[1].float().mean().item())
+        state_bytes = rows_p * env.state_p.element_size() + (rows_f - 4 * slots) * env.state_f.element_size() + 12 + 20 * mean_cache
+        step_bytes = n * (2 * state_bytes + 4 + 1)
+        rast_bytes = n * (96 * 96 * (9 + 12) + rows_p * env.state_p.element_size())
+        kernels = {'k_step': (float(step_ms.mean()), step_bytes), 'k_raster': (float(rast_ms.mean()), rast_bytes)}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        ach = kernels[dom][1] / (kernels[dom][0] * 1e-3) / 1e9
+        out = {
+            'metric': 'env-steps/sec (incl. 96x96 LoRes4E render) at N_envs=4096', 'value': value, 'unit': 'env-steps/s',
+            'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.dtype == 'f32' else args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'{args.task}, {n} envs per GPU, random actions, auto-reset every {env.max_episode_steps} steps, '
+                                   'obs u8[N,96,96,12] (4 ego frames, oldest first)',
+                       'n_envs_per_gpu': n, 'lanes_per_env': env.lanes_per_env, 'episodes_finished': n_eps * world,
+                       'mean_eval_score': float(score_sum.item()) / max(n_eps * world, 1),
+                       'arith': 'fp32 velocities/impulses/contacts + fp64 poses; fp64 rasteriser' if args.dtype == 'f32' else args.dtype},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                         'avg_launch_ms': kernels[dom][0], 'algorithmic_bytes_per_launch': kernels[dom][1],
+                         'other_kernels': {k: {'avg_launch_ms': v[0], 'algorithmic_bytes_per_launch': v[1],
+                                               'achieved_GBs': v[1] / (v[0] * 1e-3) / 1e9} for k, v in kernels.items() if k != dom}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

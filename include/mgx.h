@@ -1,0 +1,131 @@
+/*
+ * mgx.h -- C ABI of libmagical_hip.so: the MI355X-native batched replacement for
+ * MAGICAL's pymunk/pyglet-backed BaseEnv.step() hot path.
+ *
+ * The reference (qxcv/magical, pure Python) has no FFI of its own; its hot path
+ * sits on the pymunk object API (downward) and the Gym env protocol (upward),
+ * SURVEY.md §8b.  Each entry point below names the reference interface it
+ * replaces.  Conventions:
+ *   - plain pointers and sizes only; device buffers are OWNED BY THE CALLER
+ *     (PyTorch tensors in the shipped host) and only borrowed for the call;
+ *   - every function returns 0 on success or a negative mgx_status;
+ *     mgx_last_error() returns a thread-local message for the last failure;
+ *   - all device work is enqueued on the caller-supplied hipStream_t (passed
+ *     as void*); nothing synchronises the host unless the name says _sync;
+ *   - one mgx_engine per GPU per world template; one host thread per engine.
+ */
+#ifndef MGX_H_
+#define MGX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgx_world mgx_world;    /* host-side world description (entity list -> template) */
+typedef struct mgx_engine mgx_engine;  /* per-GPU batch of N envs stepping one template */
+
+enum mgx_status {
+    MGX_OK = 0,
+    MGX_ERR_ARG = -1,        /* bad argument / out of range */
+    MGX_ERR_CAPACITY = -2,   /* world too large for the compiled capacities */
+    MGX_ERR_STATE = -3,      /* call order violated (e.g. add after finalize) */
+    MGX_ERR_HIP = -4,        /* HIP runtime error (message has hipGetErrorString) */
+    MGX_ERR_NO_DEVICE = -5,  /* no gfx950 device visible */
+};
+
+/* entities.py:545-554 ShapeType order / :557-562 ShapeColour order */
+enum mgx_shape_type { MGX_TRIANGLE = 0, MGX_SQUARE, MGX_PENTAGON, MGX_HEXAGON, MGX_OCTAGON, MGX_CIRCLE, MGX_STAR };
+enum mgx_colour { MGX_RED = 0, MGX_GREEN, MGX_BLUE, MGX_YELLOW };
+enum mgx_dtype { MGX_F32 = 0, MGX_F64 = 1 };
+enum mgx_view { MGX_VIEW_EGO = 0, MGX_VIEW_ALLO = 1 };
+/* output layouts of mgx_engine_render */
+enum mgx_obs_layout {
+    MGX_OBS_FRAME = 0,   /* u8[N][96][96][3]: just the new frame (caller owns any ring) */
+    MGX_OBS_STACK4 = 1,  /* u8[N][96][96][12]: FlattenFrameStack semantics, oldest first; shifted in place */
+};
+
+const char *mgx_last_error(void);
+int mgx_version(void);
+
+/* ---- world description: replaces BaseEnv.reset()'s entity construction -------------------
+ * base_env.py:177-234 (new pm.Space, collision_slop=0.01, iterations=phys_iter, arena added
+ * first) + entities.py Entity.setup() for each entity, in add_entities() order. */
+int mgx_world_create(mgx_world **out);
+void mgx_world_destroy(mgx_world *w);
+/* base_env.py:49-57 PhysicsVariables: robot_pos, robot_rot, robot_finger, shape_trans, shape_rot */
+int mgx_world_set_phys_vars(mgx_world *w, const double vars[5]);
+/* entities.py:217-490 Robot(radius=0.2, init_pos, init_angle, mass=1.0) */
+int mgx_world_add_robot(mgx_world *w, double x, double y, double angle);
+/* entities.py:584-761 Shape(shape_type, colour, shape_size=0.12, init_pos, init_angle, mass=0.5); returns entity id */
+int mgx_world_add_shape(mgx_world *w, int shape_type, int colour, double x, double y, double angle);
+/* entities.py:769-886 GoalRegion(x, y, h, w, colour); returns entity id */
+int mgx_world_add_goal(mgx_world *w, double x, double y, double h, double w_, int colour);
+/* freeze the entity list and build bodies / shapes / joints / collision pairs / draw list */
+int mgx_world_finalize(mgx_world *w, int max_episode_steps);
+
+/* introspection (used by the host for scoring and by the parity tests) */
+enum mgx_info_key {
+    MGX_INFO_N_BODIES = 0, MGX_INFO_N_SHAPES, MGX_INFO_N_JOINTS, MGX_INFO_N_PAIRS, MGX_INFO_N_PRIMS,
+    MGX_INFO_STATE_ROWS_P, MGX_INFO_STATE_ROWS_F, MGX_INFO_STATE_ROWS_I, MGX_INFO_ROBOT_BODY, MGX_INFO_N_ENTITIES,
+    MGX_INFO_CACHE_SLOTS, MGX_INFO_MAX_CONTACTS, MGX_INFO_MAX_EPISODE_STEPS, MGX_INFO_N_JACC,
+};
+int mgx_world_info(const mgx_world *w, int key, int *out);
+/* body index of entity `ent` (shape body; -1 for goals) and its type/colour */
+int mgx_world_entity(const mgx_world *w, int ent, int *kind, int *body, int *shape_type, int *colour);
+/* out[n_bodies][2] = (1/m, 1/I); out_init[n_bodies][3] = initial (x,y,angle) */
+int mgx_world_body_table(const mgx_world *w, double *mass_inv, double *init_pose);
+/* k-th persistent body component (k < rows_p + motion body rows): component comp (0..8 = x y a vx vy w vbx vby wb)
+ * of body `body` lives in row `row` of the pose blob (comp < 3) or of the motion blob (comp >= 3) */
+int mgx_world_state_entry(const mgx_world *w, int k, int *body, int *comp, int *row);
+int mgx_world_n_state_entries(const mgx_world *w);
+/* goal region `ent`: sensor box (l, b, r, t) */
+int mgx_world_goal_bb(const mgx_world *w, int ent, double bb[4]);
+/* shapes of entity `ent`: count; per shape kind (0 circle, 2 poly), radius, nverts and local verts xy[nverts*2] */
+int mgx_world_entity_shapes(const mgx_world *w, int ent, int max_shapes, int *kinds, double *radii, int *nverts, double *xy, int xy_stride);
+
+/* ---- engine: replaces BaseEnv.step()/render() for N envs ---------------------------------
+ * Per-env persistent state lives in three caller-owned DEVICE blobs, all [rows][N] with the env
+ * index fastest (coalesced lane<->env access):
+ *   state_p : pose blob   (x, y, angle rows)        element = pose type   (f64 for MGX_F32 and MGX_F64)
+ *   state_f : motion blob (velocities, joint and contact impulse accumulators) element = f32 / f64
+ *   state_i : int32 blob  (episode step counter, contact-cache headers)
+ * dtype: MGX_F32 = fp32 velocities/impulses/contacts with fp64 poses (the shipped engine: the
+ * reference's zero-length pin joints difference nearly equal world positions), MGX_F64 = all fp64
+ * (validation), MGX_F32_PURE = all fp32 (ablation). */
+enum mgx_engine_dtype { MGX_F32_PURE = 2 };
+int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int lanes_per_env, mgx_engine **out);
+void mgx_engine_destroy(mgx_engine *e);
+/* rows of the three blobs, element sizes in bytes of state_p / state_f */
+int mgx_engine_state_shape(const mgx_engine *e, int *rows_p, int *rows_f, int *rows_i, int *size_p, int *size_f);
+int mgx_engine_lanes_per_env(const mgx_engine *e);
+int mgx_engine_lds_bytes(const mgx_engine *e, int which);   /* 0 = step kernel, 1 = raster kernel */
+/* BaseEnv.reset() (base_env.py:177-234): template state -> envs where mask[i] != 0 (mask NULL = all).
+ * mask is a DEVICE pointer to u8[N]. */
+int mgx_engine_reset(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const uint8_t *mask, void *stream);
+/* BaseEnv.step() physics (base_env.py:255-274): set_action + 10 x {Robot.update; space.step(dt)} +
+ * episode step counter.  actions: DEVICE i32[N] in [0,18).  done: DEVICE u8[N] (may be NULL). */
+int mgx_engine_step(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const int32_t *actions,
+                    uint8_t *done, void *stream);
+/* n_substeps physics substeps under `actions` without touching the episode counter (parity tests) */
+int mgx_engine_substeps(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const int32_t *actions,
+                        int n_substeps, void *stream);
+/* BaseEnv.render('rgb_array') ego/allo view + ResizeObservation(96) + FlattenFrameStack
+ * (base_env.py:309-338, benchmarks/__init__.py:80-136,219-256).  out: DEVICE u8, layout per `layout`;
+ * env_stride in bytes (multiple of 4).  fill_mask (DEVICE u8[N] or NULL): envs whose stack is (re)filled
+ * with 4 copies of the new frame (FlattenFrameStack.reset). */
+int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t env_stride, int view, int layout,
+                      const uint8_t *fill_mask, void *stream);
+/* native-resolution (384x384x3, no box filter) render of ONE env, for tests against the oracle/images */
+int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_t *out, int view, void *stream);
+/* HIP-event timing: when enabled every step (which=0) / render (which=1) launch is bracketed by events on
+ * the launch stream; timing_read synchronises those events and returns up to `max` most recent launch
+ * durations in ms (oldest first) and clears the log. */
+int mgx_engine_set_timing(mgx_engine *e, int enable);
+int mgx_engine_timing_read(mgx_engine *e, int which, float *ms, int max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H_ */

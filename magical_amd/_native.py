@@ -1,0 +1,116 @@
+"""ctypes binding of libmagical_hip.so (the C ABI in include/mgx.h).
+
+The product path has NO fallback: if the HIP library is missing or no GPU is
+visible, loading / engine creation raises.  Build with `python __graft_entry__.py`
+(or `magical_amd._native.build()`), which runs hipcc for gfx950.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, 'csrc')
+LIB_PATH = os.path.join(_PKG, 'libmagical_hip.so')
+_SOURCES = ['mgx_api.hip', 'mgx_world.cpp']
+_DEPS = _SOURCES + ['mgx_step.hip', 'mgx_raster.hip', 'mgx_sim.h', 'mgx_raster.h', 'mgx_tmpl.h', 'mgx_world.h']
+
+# enums (include/mgx.h)
+MGX_F32, MGX_F64, MGX_F32_PURE = 0, 1, 2
+VIEW_EGO, VIEW_ALLO = 0, 1
+OBS_FRAME, OBS_STACK4 = 0, 1
+INFO = {k: i for i, k in enumerate([
+    'n_bodies', 'n_shapes', 'n_joints', 'n_pairs', 'n_prims', 'state_rows_p', 'state_rows_f', 'state_rows_i',
+    'robot_body', 'n_entities', 'cache_slots', 'max_contacts', 'max_episode_steps', 'n_jacc'])}
+
+
+class MgxError(RuntimeError):
+    pass
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(_CSRC, f)) > t for f in _DEPS)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-Wno-unused-parameter', '-o', LIB_PATH] + [os.path.join(_CSRC, f) for f in _SOURCES]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd, cwd=_CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MgxError(f'{LIB_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py`); '
+                       'magical_amd has no CPU fallback')
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.mgx_last_error.restype = C.c_char_p
+    sig = {
+        'mgx_version': [],
+        'mgx_world_create': [C.POINTER(vp)],
+        'mgx_world_set_phys_vars': [vp, dp],
+        'mgx_world_add_robot': [vp, dbl, dbl, dbl],
+        'mgx_world_add_shape': [vp, i32, i32, dbl, dbl, dbl],
+        'mgx_world_add_goal': [vp, dbl, dbl, dbl, dbl, i32],
+        'mgx_world_finalize': [vp, i32],
+        'mgx_world_info': [vp, i32, ip],
+        'mgx_world_entity': [vp, i32, ip, ip, ip, ip],
+        'mgx_world_body_table': [vp, dp, dp],
+        'mgx_world_n_state_entries': [vp],
+        'mgx_world_state_entry': [vp, i32, ip, ip, ip],
+        'mgx_world_goal_bb': [vp, i32, dp],
+        'mgx_world_entity_shapes': [vp, i32, i32, ip, dp, ip, dp, i32],
+        'mgx_engine_create': [vp, i32, i32, i32, i32, C.POINTER(vp)],
+        'mgx_engine_state_shape': [vp, ip, ip, ip, ip, ip],
+        'mgx_engine_lanes_per_env': [vp],
+        'mgx_engine_lds_bytes': [vp, i32],
+        'mgx_engine_reset': [vp, vp, vp, vp, vp, vp],
+        'mgx_engine_step': [vp, vp, vp, vp, vp, vp, vp],
+        'mgx_engine_substeps': [vp, vp, vp, vp, vp, i32, vp],
+        'mgx_engine_render': [vp, vp, vp, i64, i32, i32, vp, vp],
+        'mgx_engine_render_native': [vp, vp, i32, vp, i32, vp],
+        'mgx_engine_set_timing': [vp, i32],
+        'mgx_engine_timing_read': [vp, i32, C.POINTER(C.c_float), i32],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    L.mgx_world_destroy.argtypes = [vp]
+    L.mgx_world_destroy.restype = None
+    L.mgx_engine_destroy.argtypes = [vp]
+    L.mgx_engine_destroy.restype = None
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        raise MgxError(f'mgx error {rc}: {lib().mgx_last_error().decode()}')
+    return rc
+
+
+EXPORTED_SYMBOLS = [
+    'mgx_last_error', 'mgx_version', 'mgx_world_create', 'mgx_world_destroy', 'mgx_world_set_phys_vars',
+    'mgx_world_add_robot', 'mgx_world_add_shape', 'mgx_world_add_goal', 'mgx_world_finalize', 'mgx_world_info',
+    'mgx_world_entity', 'mgx_world_body_table', 'mgx_world_n_state_entries', 'mgx_world_state_entry',
+    'mgx_world_goal_bb', 'mgx_world_entity_shapes', 'mgx_engine_create', 'mgx_engine_destroy',
+    'mgx_engine_state_shape', 'mgx_engine_lanes_per_env', 'mgx_engine_lds_bytes', 'mgx_engine_reset',
+    'mgx_engine_step', 'mgx_engine_substeps', 'mgx_engine_render', 'mgx_engine_render_native',
+    'mgx_engine_set_timing', 'mgx_engine_timing_read',
+]

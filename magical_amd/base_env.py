@@ -1,0 +1,319 @@
+"""Batched mirror of magical/base_env.py: one object steps N independent envs on one MI355X.
+
+`BaseEnv` keeps the reference's constructor keywords, constants, `reset()/step()/render()/
+seed()/close()` protocol, `action_to_flags/flags_to_action`, the `on_reset()` /
+`score_on_end_of_traj()` task hooks and `add_entities()`; what used to be one pymunk Space +
+one pyglet Viewer per env is one native engine handle (include/mgx.h) per GPU.
+
+step() returns (obs, reward, done, info) like the reference (base_env.py:255-292), batched:
+  obs    : torch tensor on the engine's device (layout depends on the preprocessor, see
+           magical_amd/benchmarks/__init__.py)
+  reward : torch.float32[N], always 0 (base_env.py:266-267)
+  done   : numpy bool[N]
+  info   : {'eval_score': numpy float64[N]}  (0.0 until done, base_env.py:285-288)
+With auto_reset=True (default, SB3 VecEnv semantics) finished envs are reset inside step()
+and their returned obs is the first observation of the next episode.
+"""
+import abc
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+from . import entities as en
+
+
+class PhysicsVariables:
+    """base_env.py:49-57 (defaults + the uniform ranges used by rand_dynamics)."""
+    robot_pos_joint_max_force = (3, (2.2, 3.5))
+    robot_rot_joint_max_force = (1, (0.7, 1.5))
+    robot_finger_max_force = (4, (2.5, 4.5))
+    shape_trans_joint_max_force = (1.5, (1.0, 1.8))
+    shape_rot_joint_max_force = (0.1, (0.07, 0.15))
+    NAMES = ('robot_pos_joint_max_force', 'robot_rot_joint_max_force', 'robot_finger_max_force',
+             'shape_trans_joint_max_force', 'shape_rot_joint_max_force')
+
+    @classmethod
+    def defaults(cls):
+        return [float(getattr(cls, n)[0]) for n in cls.NAMES]
+
+    @classmethod
+    def sample(cls, rng):
+        return [float(rng.uniform(*getattr(cls, n)[1])) for n in cls.NAMES]
+
+
+class BaseEnv(abc.ABC):
+    # constants for all envs (base_env.py:61-76)
+    ROBOT_RAD = 0.2
+    ROBOT_MASS = 1.0
+    SHAPE_RAD = ROBOT_RAD * 0.6
+    ARENA_BOUNDS_LRBT = [-1, 1, -1, 1]
+    ARENA_SIZE_MAX = max(ARENA_BOUNDS_LRBT)
+
+    def __init__(self, *, n_envs=1, device='cuda:0', res_hw=(384, 384), fps=8, phys_steps=10, phys_iter=10,
+                 max_episode_steps=None, rand_dynamics=False, ego_view=True, allo_view=True,
+                 dtype='f32', lanes_per_env=0, auto_reset=True):
+        import torch
+        if fps != 8 or phys_steps != 10 or phys_iter != 10:
+            raise NotImplementedError('the engine is built for the registered rates: fps=8, 10 substeps, 10 iterations '
+                                      '(benchmarks/__init__.py:401-404)')
+        if rand_dynamics:
+            raise NotImplementedError('rand_dynamics (Test* variants) is not built yet; Demo variants only')
+        assert ego_view or allo_view, 'must use egocentric view or allocentric view (or both)'
+        self.n_envs, self.fps, self.phys_steps, self.phys_iter = int(n_envs), fps, phys_steps, phys_iter
+        self.res_hw, self.max_episode_steps = tuple(res_hw), max_episode_steps
+        self.ego_view, self.allo_view, self.rand_dynamics = ego_view, allo_view, rand_dynamics
+        self.auto_reset = auto_reset
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise nat.MgxError('magical_amd runs on an MI355X (torch device "cuda:N"); there is no CPU fallback')
+        self.dtype_name = dtype
+        self._dtype = {'f32': nat.MGX_F32, 'f64': nat.MGX_F64, 'f32_pure': nat.MGX_F32_PURE}[dtype]
+        self._lanes = lanes_per_env
+        self.action_space_n = len(en.ACTION_NUMS_FLAGS_NAMES)
+        self._lib = nat.lib()
+        self._world = None
+        self._engine = None
+        self._entities = None
+        self._robot = None
+        self.seed()
+        self._build()
+
+    # ------------------------------------------------------------------ reference protocol
+    def action_to_flags(self, int_action):
+        return en.ACTION_ID_TO_FLAGS[int(int_action)]
+
+    def flags_to_action(self, flags):
+        return en.FLAGS_TO_ACTION_ID[tuple(flags)]
+
+    def seed(self, seed=None):
+        if seed is None:
+            seed = np.random.randint(0, (1 << 31) - 1)
+        self.rng = np.random.RandomState(seed=seed)
+        return [seed]
+
+    def _make_robot(self, init_pos, init_angle):
+        return en.Robot(radius=self.ROBOT_RAD, init_pos=init_pos, init_angle=init_angle, mass=self.ROBOT_MASS)
+
+    def _make_shape(self, **kwargs):
+        return en.Shape(shape_size=self.SHAPE_RAD, **kwargs)
+
+    @abc.abstractmethod
+    def on_reset(self):
+        """Create the task's entities and pass them to add_entities() in draw/joint order."""
+
+    @abc.abstractmethod
+    def score_on_end_of_traj(self, poses):
+        """poses: float64[M, n_bodies, 3] of the M finished envs -> float64[M] in [0, 1]."""
+
+    def add_entities(self, entities):
+        L, w = self._lib, self._world
+        for ent in entities:
+            if isinstance(ent, en.Robot):
+                self._robot = ent
+                ent.ent_id = nat.check(L.mgx_world_add_robot(w, ent.init_pos[0], ent.init_pos[1], ent.init_angle))
+            elif isinstance(ent, en.Shape):
+                ent.ent_id = nat.check(L.mgx_world_add_shape(w, en.SHAPE_TYPE_ID[ent.shape_type], en.COLOUR_ID[ent.colour_name],
+                                                             ent.init_pos[0], ent.init_pos[1], ent.init_angle))
+            elif isinstance(ent, en.GoalRegion):
+                ent.ent_id = nat.check(L.mgx_world_add_goal(w, ent.x, ent.y, ent.h, ent.w, en.COLOUR_ID[ent.colour_name]))
+            else:
+                raise TypeError(f"don't know how to handle entity {ent!r}")
+            self._entities.append(ent)
+
+    # ------------------------------------------------------------------ engine construction
+    def _build(self):
+        import torch
+        L = self._lib
+        w = C.c_void_p()
+        nat.check(L.mgx_world_create(C.byref(w)))
+        self._world = w
+        self._entities = []
+        pv = (C.c_double * 5)(*PhysicsVariables.defaults())
+        nat.check(L.mgx_world_set_phys_vars(w, pv))
+        self.on_reset()      # arena is added by the library itself, first (base_env.py:213)
+        assert isinstance(self._robot, en.Robot)
+        nat.check(L.mgx_world_finalize(w, int(self.max_episode_steps or (1 << 30))))
+        out = C.c_int()
+        self.n_bodies = self._info('n_bodies')
+        for ent in self._entities:
+            kind, body = C.c_int(), C.c_int()
+            nat.check(L.mgx_world_entity(w, ent.ent_id, C.byref(kind), C.byref(body), None, None))
+            ent.body = body.value if body.value >= 0 else None
+            if isinstance(ent, en.GoalRegion):
+                bb = (C.c_double * 4)()
+                nat.check(L.mgx_world_goal_bb(w, ent.ent_id, bb))
+                ent.bb = tuple(bb)       # l b r t
+        eng = C.c_void_p()
+        nat.check(L.mgx_engine_create(w, self.n_envs, self.device.index or 0, self._dtype, self._lanes, C.byref(eng)))
+        self._engine = eng
+        rp, rf, ri, szp, szf = (C.c_int() for _ in range(5))
+        nat.check(L.mgx_engine_state_shape(eng, C.byref(rp), C.byref(rf), C.byref(ri), C.byref(szp), C.byref(szf)))
+        tp = torch.float64 if szp.value == 8 else torch.float32
+        tf = torch.float64 if szf.value == 8 else torch.float32
+        self.state_p = torch.zeros((rp.value, self.n_envs), dtype=tp, device=self.device)
+        self.state_f = torch.zeros((rf.value, self.n_envs), dtype=tf, device=self.device)
+        self.state_i = torch.zeros((ri.value, self.n_envs), dtype=torch.int32, device=self.device)
+        self._done_dev = torch.zeros(self.n_envs, dtype=torch.uint8, device=self.device)
+        self._reward = torch.zeros(self.n_envs, dtype=torch.float32, device=self.device)
+        self._steps = np.zeros(self.n_envs, dtype=np.int64)
+        # pose-blob row of (x, y, angle) per body, -1 where the body is not persistent
+        n = nat.check(L.mgx_world_n_state_entries(w))
+        self._pose_rows = -np.ones((self.n_bodies, 3), dtype=np.int64)
+        self._motion_rows = -np.ones((self.n_bodies, 9), dtype=np.int64)
+        for k in range(n):
+            b, c, r = C.c_int(), C.c_int(), C.c_int()
+            nat.check(L.mgx_world_state_entry(w, k, C.byref(b), C.byref(c), C.byref(r)))
+            if c.value < 3:
+                self._pose_rows[b.value, c.value] = r.value
+            else:
+                self._motion_rows[b.value, c.value] = r.value
+        self.lanes_per_env = L.mgx_engine_lanes_per_env(eng)
+        del out
+
+    def _info(self, key):
+        out = C.c_int()
+        nat.check(self._lib.mgx_world_info(self._world, nat.INFO[key], C.byref(out)))
+        return out.value
+
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ reset / step
+    def reset(self):
+        """base_env.py:177-234 for every env.  Returns the first observation."""
+        nat.check(self._lib.mgx_engine_reset(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
+                                             self.state_i.data_ptr(), None, self._stream()))
+        self._steps[:] = 0
+        return self._observe(fill_all=True)
+
+    def step(self, actions):
+        import torch
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions), device=self.device)
+        actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        assert actions.shape == (self.n_envs,)
+        nat.check(self._lib.mgx_engine_step(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
+                                            self.state_i.data_ptr(), actions.data_ptr(), self._done_dev.data_ptr(),
+                                            self._stream()))
+        self._steps += 1
+        done = np.zeros(self.n_envs, dtype=bool)
+        eval_score = np.zeros(self.n_envs, dtype=np.float64)
+        if self.max_episode_steps is not None:
+            done = self._steps >= self.max_episode_steps
+        fill = None
+        if done.any():
+            idx = np.nonzero(done)[0]
+            eval_score[idx] = self.score_on_end_of_traj(self.get_poses(idx))
+            assert np.all((eval_score >= 0) & (eval_score <= 1)), 'eval score out of range'
+            if self.auto_reset:
+                # the device-side done flags written by the step kernel double as reset + frame-fill masks
+                nat.check(self._lib.mgx_engine_reset(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
+                                                     self.state_i.data_ptr(), self._done_dev.data_ptr(), self._stream()))
+                self._steps[idx] = 0
+                fill = self._done_dev
+        obs = self._observe(fill_mask=fill)
+        return obs, self._reward, done, {'eval_score': eval_score}
+
+    def close(self):
+        if self._engine is not None:
+            self._lib.mgx_engine_destroy(self._engine)
+            self._engine = None
+        if self._world is not None:
+            self._lib.mgx_world_destroy(self._world)
+            self._world = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ observations
+    def _observe(self, fill_all=False, fill_mask=None):
+        """Default (no preprocessor): state-only observation f32[N, n_bodies, 3] = (x, y, angle)."""
+        return self.get_poses_tensor()
+
+    def get_poses_tensor(self):
+        import torch
+        rows = torch.as_tensor(np.where(self._pose_rows >= 0, self._pose_rows, 0).reshape(-1), device=self.device)
+        valid = torch.as_tensor((self._pose_rows >= 0).reshape(-1), device=self.device)
+        p = self.state_p.index_select(0, rows) * valid[:, None].to(self.state_p.dtype)
+        return p.reshape(self.n_bodies, 3, self.n_envs).permute(2, 0, 1).to(torch.float32)
+
+    def get_poses(self, env_idx=None):
+        """float64[M, n_bodies, 3] poses of the selected envs on the host (synchronises)."""
+        import torch
+        sp = self.state_p if env_idx is None else self.state_p[:, torch.as_tensor(env_idx, device=self.device)]
+        sp = sp.to(torch.float64).cpu().numpy()
+        out = np.zeros((sp.shape[1], self.n_bodies, 3), dtype=np.float64)
+        for b in range(self.n_bodies):
+            for c in range(3):
+                r = self._pose_rows[b, c]
+                if r >= 0:
+                    out[:, b, c] = sp[r]
+        return out
+
+    def get_bodies(self):
+        """float64[N, n_bodies, 9] (x y a vx vy w vbx vby wb); non-persistent components are 0."""
+        sp = self.state_p.to('cpu').numpy().astype(np.float64)
+        sf = self.state_f.to('cpu').numpy().astype(np.float64)
+        out = np.zeros((self.n_envs, self.n_bodies, 9), dtype=np.float64)
+        for b in range(self.n_bodies):
+            for c in range(9):
+                r = self._pose_rows[b, c] if c < 3 else self._motion_rows[b, c]
+                if r >= 0:
+                    out[:, b, c] = (sp if c < 3 else sf)[r]
+        return out
+
+    def set_bodies(self, bodies):
+        """Inverse of get_bodies (parity tests / checkpoint restore)."""
+        import torch
+        sp = self.state_p.to('cpu').numpy().copy()
+        sf = self.state_f.to('cpu').numpy().copy()
+        for b in range(self.n_bodies):
+            for c in range(9):
+                r = self._pose_rows[b, c] if c < 3 else self._motion_rows[b, c]
+                if r >= 0:
+                    (sp if c < 3 else sf)[r] = bodies[:, b, c]
+        self.state_p.copy_(torch.as_tensor(sp))
+        self.state_f.copy_(torch.as_tensor(sf))
+
+    def substeps(self, actions, n):
+        """n physics substeps under `actions` without advancing the episode counter (parity tests)."""
+        import torch
+        actions = torch.as_tensor(np.asarray(actions), device=self.device).to(torch.int32).contiguous()
+        nat.check(self._lib.mgx_engine_substeps(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
+                                                self.state_i.data_ptr(), actions.data_ptr(), int(n), self._stream()))
+
+    def render_frames(self, out, view='ego', layout='frame', fill_mask=None):
+        """Rasterise every env into `out` (torch.uint8 on the engine device): [N,96,96,3] or [N,96,96,12]."""
+        lay = nat.OBS_FRAME if layout == 'frame' else nat.OBS_STACK4
+        assert out.is_contiguous() and out.device == self.device and out.shape[0] == self.n_envs
+        nat.check(self._lib.mgx_engine_render(self._engine, self.state_p.data_ptr(), out.data_ptr(), out.stride(0),
+                                              nat.VIEW_EGO if view == 'ego' else nat.VIEW_ALLO, lay,
+                                              None if fill_mask is None else fill_mask.data_ptr(), self._stream()))
+        return out
+
+    def render(self, mode='rgb_array', env=0):
+        """base_env.py:309-338 for ONE env at the native 384x384: {'allo': u8[384,384,3], 'ego': ...} (numpy)."""
+        import torch
+        assert mode == 'rgb_array'
+        views = {}
+        buf = torch.empty((384, 384, 3), dtype=torch.uint8, device=self.device)
+        for name, flag, vid in (('allo', self.allo_view, nat.VIEW_ALLO), ('ego', self.ego_view, nat.VIEW_EGO)):
+            if flag:
+                nat.check(self._lib.mgx_engine_render_native(self._engine, self.state_p.data_ptr(), int(env),
+                                                             buf.data_ptr(), vid, self._stream()))
+                views[name] = buf.cpu().numpy().copy()
+        return views
+
+    # ------------------------------------------------------------------ kernel timing (bench.py)
+    def set_timing(self, on):
+        nat.check(self._lib.mgx_engine_set_timing(self._engine, int(bool(on))))
+
+    def read_timing(self, which, max_n=4096):
+        buf = (C.c_float * max_n)()
+        n = nat.check(self._lib.mgx_engine_timing_read(self._engine, 0 if which == 'step' else 1, buf, max_n))
+        return np.array(buf[:n], dtype=np.float64)

@@ -1,0 +1,84 @@
+"""Host-side float64 helpers shared by the tasks' score_on_end_of_traj() implementations.
+
+Scores are functions of the final body poses only; they run once per episode on the poses
+downloaded from the device (float64).  Everything is batched over the M finished envs, with
+operation orders chosen so the result is bit-identical to the reference's per-env numpy code.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from .. import _native as nat
+from .. import entities as en
+
+
+def row_norm(d):
+    """np.linalg.norm(v) for each row v of d[M, 2].  The reference calls the 1-D form, which numpy
+    evaluates as sqrt(v.dot(v)) through BLAS ddot (FMA on most builds); elementwise x*x + y*y can
+    differ in the last bit, so go through the same primitive row by row."""
+    out = np.empty(len(d), dtype=np.float64)
+    dot, sqrt = np.dot, math.sqrt
+    for k, r in enumerate(d):
+        out[k] = sqrt(dot(r, r))
+    return out
+
+
+def entity_shapes(env, ent):
+    """[(kind, radius, local_verts[n,2])] of a block entity, from the native world."""
+    L, w = env._lib, env._world
+    max_shapes, stride = 8, 16
+    kinds = (C.c_int * max_shapes)()
+    radii = (C.c_double * max_shapes)()
+    nverts = (C.c_int * max_shapes)()
+    xy = (C.c_double * (max_shapes * stride))()
+    n = nat.check(L.mgx_world_entity_shapes(w, ent.ent_id, max_shapes, kinds, radii, nverts, xy, stride))
+    out = []
+    for s in range(n):
+        v = np.array(xy[s * stride:s * stride + 2 * nverts[s]], dtype=np.float64).reshape(-1, 2)
+        out.append((kinds[s], radii[s], v))
+    return out
+
+
+def _shape_hits_box(kind, radius, verts, pose, bb):
+    """Does the shape (at poses[M,3]) overlap the axis-aligned sensor box?  Mirrors
+    space.shape_query(goal_shape) -> cpShapesCollide(...).count > 0 (entities.py:837-838):
+    overlap iff the minimum separation between the cores is <= the shape's radius."""
+    l, b, r, t = bb
+    x, y, a = pose[:, 0], pose[:, 1], pose[:, 2]
+    if kind == 0:   # circle
+        dx = np.maximum(np.maximum(l - x, 0.0), x - r)
+        dy = np.maximum(np.maximum(b - y, 0.0), y - t)
+        return dx * dx + dy * dy <= radius * radius
+    c, s = np.cos(a), np.sin(a)
+    wx = x[:, None] + (c[:, None] * verts[None, :, 0] - s[:, None] * verts[None, :, 1])
+    wy = y[:, None] + (c[:, None] * verts[None, :, 1] + s[:, None] * verts[None, :, 0])
+    sep = np.maximum.reduce([l - wx.max(axis=1), wx.min(axis=1) - r, b - wy.max(axis=1), wy.min(axis=1) - t])
+    corners = np.array([(l, b), (r, b), (r, t), (l, t)], dtype=np.float64)
+    n = verts.shape[0]
+    for i in range(n):
+        j = (i + 1) % n
+        ex, ey = wx[:, j] - wx[:, i], wy[:, j] - wy[:, i]
+        ln = np.sqrt(ex * ex + ey * ey)
+        nx, ny = ey / ln, -ex / ln           # outward normal of a CCW polygon
+        d = np.min(nx[:, None] * (corners[None, :, 0] - wx[:, i, None]) + ny[:, None] * (corners[None, :, 1] - wy[:, i, None]), axis=1)
+        sep = np.maximum(sep, d)
+    return sep <= radius
+
+
+def overlapping_ents(env, goal, ents, poses):
+    """GoalRegion.get_overlapping_ents(com_overlap=True) (entities.py:821-881), batched:
+    bool[M, len(ents)] -- an entity counts iff EVERY one of its shapes overlaps the sensor AND its
+    body position lies inside the sensor's bounding box."""
+    l, b, r, t = goal.bb
+    out = np.zeros((poses.shape[0], len(ents)), dtype=bool)
+    for k, ent in enumerate(ents):
+        pose = poses[:, ent.body, :]
+        inside = (l <= pose[:, 0]) & (r >= pose[:, 0]) & (b <= pose[:, 1]) & (t >= pose[:, 1])
+        ok = inside.copy()
+        if not hasattr(ent, '_shapes_cache'):
+            ent._shapes_cache = entity_shapes(env, ent)
+        for kind, radius, verts in ent._shapes_cache:
+            ok &= _shape_hits_box(kind, radius, verts, pose, goal.bb)
+        out[:, k] = ok
+    return out

@@ -1,0 +1,85 @@
+"""ClusterColour / ClusterShape (mirror of magical/benchmarks/cluster.py, Demo branch)."""
+import abc
+import enum
+
+import numpy as np
+
+from .. import entities as en
+from ..base_env import BaseEnv
+
+
+class BaseClusterEnv(BaseEnv, abc.ABC):
+    class ClusterBy(str, enum.Enum):
+        COLOUR = 'colour'
+        TYPE = 'type'
+
+    def __init__(self, rand_shape_colour=False, rand_shape_type=False, rand_layout_minor=False, rand_layout_full=False,
+                 rand_shape_count=False, cluster_by=ClusterBy.COLOUR, **kwargs):
+        if rand_shape_colour or rand_shape_type or rand_layout_minor or rand_layout_full or rand_shape_count:
+            raise NotImplementedError('only the Demo variant is built (Test* variants: SURVEY.md §8f)')
+        self.cluster_by = cluster_by
+        super().__init__(**kwargs)
+
+    def on_reset(self):   # cluster.py:67-164
+        robot = self._make_robot(*self.DEFAULT_ROBOT_POSE)
+        colours, shape_types, poses = self.DEFAULT_BLOCK_COLOURS, self.DEFAULT_BLOCK_SHAPES, self.DEFAULT_BLOCK_POSES
+        shape_ents = [self._make_shape(shape_type=st, colour_name=c, init_pos=(x, y), init_angle=a)
+                      for ((x, y), a), c, st in zip(poses, colours, shape_types)]
+        self.add_entities(shape_ents)
+        values = colours if self.cluster_by == self.ClusterBy.COLOUR else shape_types
+        c_values_list = np.asarray([v.value for v in values], dtype='object')
+        self.__characteristic_values = np.unique(c_values_list)          # sorted, like the reference
+        self.__shape_ents = shape_ents
+        self.__members = [[k for k, v in enumerate(c_values_list) if v == c_value]
+                          for c_value in self.__characteristic_values]
+        self.add_entities([robot])
+
+    def score_on_end_of_traj(self, poses):   # cluster.py:166-216
+        pos = poses[:, [e.body for e in self.__shape_ents], :2]            # [M, n_blocks, 2]
+        nvals = len(self.__characteristic_values)
+        centroids = np.zeros((pos.shape[0], nvals, 2))
+        for c_idx, members in enumerate(self.__members):
+            centroids[:, c_idx] = np.mean(pos[:, members, :], axis=1)
+        min_margin = 2.0
+        n_blocks = 0
+        n_correct = np.zeros(pos.shape[0], dtype=np.int64)
+        indices = np.arange(nvals)
+        for c_idx, members in enumerate(self.__members):
+            for k in members:
+                n_blocks += 1
+                centroid_sses = np.sum((pos[:, k, None, :] - centroids)**2, axis=2)     # [M, nvals]
+                true_sse = centroid_sses[:, c_idx]
+                nearest_bad_centroid = np.min(centroid_sses[:, indices != c_idx], axis=1)
+                margin = min_margin * true_sse        # squared distance as margin: reference quirk (cluster.py:203-206)
+                n_correct += (np.sqrt(true_sse) < np.sqrt(nearest_bad_centroid) - margin).astype(np.int64)
+        frac_correct = n_correct.astype(np.float64) / max(n_blocks, 1)
+        thresh = 0.75
+        return np.maximum(frac_correct - thresh, 0) / (1 - thresh)
+
+
+class ClusterColourEnv(BaseClusterEnv):   # cluster.py:219-256
+    DEFAULT_ROBOT_POSE = ((0.71692, -0.34374), 0.83693)
+    DEFAULT_BLOCK_COLOURS = [en.ShapeColour.BLUE, en.ShapeColour.BLUE, en.ShapeColour.BLUE, en.ShapeColour.GREEN,
+                             en.ShapeColour.GREEN, en.ShapeColour.RED, en.ShapeColour.YELLOW, en.ShapeColour.YELLOW]
+    DEFAULT_BLOCK_SHAPES = [en.ShapeType.CIRCLE, en.ShapeType.STAR, en.ShapeType.SQUARE, en.ShapeType.PENTAGON,
+                            en.ShapeType.PENTAGON, en.ShapeType.SQUARE, en.ShapeType.STAR, en.ShapeType.PENTAGON]
+    DEFAULT_BLOCK_POSES = [((-0.5147, 0.14149), -0.38871), ((-0.1347, -0.71414), 1.0533), ((-0.74247, -0.097592), 1.1571),
+                           ((-0.077363, -0.42964), -0.64379), ((0.51978, 0.1853), -1.1762), ((-0.5278, -0.21642), 2.9356),
+                           ((-0.54039, 0.48292), 0.072818), ((-0.16761, 0.64303), -2.3255)]
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, cluster_by=BaseClusterEnv.ClusterBy.COLOUR, **kwargs)
+
+
+class ClusterShapeEnv(BaseClusterEnv):   # cluster.py:259-297
+    DEFAULT_ROBOT_POSE = ((0.286, -0.202), -1.878)
+    DEFAULT_BLOCK_COLOURS = [en.ShapeColour.YELLOW, en.ShapeColour.BLUE, en.ShapeColour.RED, en.ShapeColour.RED,
+                             en.ShapeColour.GREEN, en.ShapeColour.YELLOW, en.ShapeColour.BLUE, en.ShapeColour.GREEN]
+    DEFAULT_BLOCK_SHAPES = [en.ShapeType.SQUARE, en.ShapeType.PENTAGON, en.ShapeType.PENTAGON, en.ShapeType.PENTAGON,
+                            en.ShapeType.CIRCLE, en.ShapeType.STAR, en.ShapeType.STAR, en.ShapeType.CIRCLE]
+    DEFAULT_BLOCK_POSES = [((-0.414, 0.297), -1.731), ((0.068, 0.705), 2.184), ((0.821, 0.220), 0.650),
+                           ((-0.461, -0.749), -2.673), ((0.867, -0.149), -2.215), ((-0.785, -0.140), -0.405),
+                           ((-0.305, -0.226), 1.341), ((0.758, -0.708), -2.140)]
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, cluster_by=BaseClusterEnv.ClusterBy.TYPE, **kwargs)

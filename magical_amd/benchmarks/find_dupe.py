@@ -1,0 +1,55 @@
+"""FindDupe (mirror of magical/benchmarks/find_dupe.py, Demo branch)."""
+import numpy as np
+
+from .. import entities as en
+from ..base_env import BaseEnv
+from ._scoring import overlapping_ents
+
+DEFAULT_QUERY_COLOUR = en.ShapeColour.YELLOW
+DEFAULT_QUERY_SHAPE = en.ShapeType.PENTAGON
+DEFAULT_OUT_BLOCK_SHAPES = [en.ShapeType.PENTAGON, en.ShapeType.CIRCLE, en.ShapeType.CIRCLE, en.ShapeType.SQUARE,
+                            en.ShapeType.STAR, DEFAULT_QUERY_SHAPE]
+DEFAULT_OUT_BLOCK_COLOURS = [en.ShapeColour.GREEN, en.ShapeColour.RED, en.ShapeColour.RED, en.ShapeColour.YELLOW,
+                             en.ShapeColour.BLUE, DEFAULT_QUERY_COLOUR]
+DEFAULT_OUT_BLOCK_POSES = [((-0.066751, 0.7552), -2.9266), ((-0.05195, 0.31468), 1.5418), ((0.57528, -0.46865), -2.2141),
+                           ((0.40594, -0.74977), 0.24582), ((0.45254, 0.3681), -1.0834), ((0.76849, -0.10652), 0.10028)]
+DEFAULT_ROBOT_POSE = ((-0.57, 0.25), 3.83)
+DEFAULT_TARGET_REGION_XYHW = (-0.72, -0.22, 0.67, 0.72)
+DEFAULT_QUERY_BLOCK_POSE = ((-0.33, -0.49), -0.51)
+
+
+class FindDupeEnv(BaseEnv):
+    def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
+                 rand_layout_full=False, **kwargs):
+        if rand_colours or rand_shapes or rand_count or rand_layout_minor or rand_layout_full:
+            raise NotImplementedError('only the Demo variant is built (Test* variants: SURVEY.md §8f)')
+        super().__init__(**kwargs)
+
+    def on_reset(self):   # find_dupe.py:72-155
+        robot = self._make_robot(*DEFAULT_ROBOT_POSE)
+        sensor = en.GoalRegion(*DEFAULT_TARGET_REGION_XYHW, DEFAULT_QUERY_COLOUR)
+        self.add_entities([sensor])
+        self.__sensor_ref = sensor
+        outside_blocks, targets = [], []
+        for bshape, bcol, (bpos, bangle) in zip(DEFAULT_OUT_BLOCK_SHAPES, DEFAULT_OUT_BLOCK_COLOURS, DEFAULT_OUT_BLOCK_POSES):
+            blk = self._make_shape(shape_type=bshape, colour_name=bcol, init_pos=bpos, init_angle=bangle)
+            outside_blocks.append(blk)
+            if bcol == DEFAULT_QUERY_COLOUR and bshape == DEFAULT_QUERY_SHAPE:
+                targets.append(blk)
+        self.add_entities(outside_blocks)
+        query_block = self._make_shape(shape_type=DEFAULT_QUERY_SHAPE, colour_name=DEFAULT_QUERY_COLOUR,
+                                       init_pos=DEFAULT_QUERY_BLOCK_POSE[0], init_angle=DEFAULT_QUERY_BLOCK_POSE[1])
+        targets.append(query_block)
+        self.add_entities([query_block])
+        self.add_entities([robot])
+        self.__all_blocks = [query_block, *outside_blocks]
+        self.__is_target = np.array([b in targets for b in self.__all_blocks])
+
+    def score_on_end_of_traj(self, poses):   # find_dupe.py:203-216
+        ov = overlapping_ents(self, self.__sensor_ref, self.__all_blocks, poses)
+        n_overlap_targets = ov[:, self.__is_target].sum(axis=1)
+        n_overlap_distractors = ov[:, ~self.__is_target].sum(axis=1)
+        n_overlap = ov.sum(axis=1)
+        have_two_shapes = (n_overlap_targets >= 2).astype(np.float64)
+        contamination_rate = np.where(n_overlap == 0, 0.0, n_overlap_distractors / np.maximum(n_overlap, 1))
+        return have_two_shapes * (1 - contamination_rate)

@@ -1,0 +1,68 @@
+"""MakeLine (mirror of magical/benchmarks/make_line.py, Demo branch)."""
+import numpy as np
+
+from .. import entities as en
+from ..base_env import BaseEnv
+from ._scoring import row_norm
+
+INLIER_RAD_MULT = 1.5
+MAX_SEP_RADS = 3.5
+DEFAULT_ROBOT_POSE = ((0.702, -0.255), 0.347)
+DEFAULT_BLOCK_COLOURS = [en.ShapeColour.BLUE, en.ShapeColour.YELLOW, en.ShapeColour.RED, en.ShapeColour.GREEN]
+DEFAULT_BLOCK_SHAPES = [en.ShapeType.STAR, en.ShapeType.CIRCLE, en.ShapeType.STAR, en.ShapeType.PENTAGON]
+DEFAULT_BLOCK_POSES = [((0.790, -0.820), -0.721), ((-0.177, 0.383), -1.733),
+                       ((-0.051, -0.128), 2.696), ((-0.292, -0.745), -0.159)]
+
+
+def longest_line(points, inlier_dist, max_separation):
+    """make_line.py:31-71 for one env: exhaustive pair lines, inliers within inlier_dist, longest run of
+    inliers whose neighbours along the line are at most max_separation apart."""
+    npts = len(points)
+    best = min(1, npts)
+    for i in range(npts - 1):
+        for j in range(i + 1, npts):
+            offs = points - points[i][None]
+            pj_off = offs[j]
+            pj_unit = pj_off / np.linalg.norm(pj_off)
+            proj_lens = np.squeeze(offs @ pj_unit[:, None], axis=1)
+            dists = np.linalg.norm(offs - proj_lens[:, None] * pj_unit, axis=1)
+            inliers = np.nonzero(dists <= inlier_dist)[0]
+            if len(inliers) <= best:
+                continue
+            lens = np.sort(proj_lens[inliers])
+            close = np.abs(np.diff(lens)) <= max_separation
+            run = longest = 0
+            for flag in close:
+                run = run + 1 if flag else 0
+                longest = max(longest, run)
+            if longest + 1 > best:
+                best = longest + 1
+    return best
+
+
+class MakeLineEnv(BaseEnv):
+    def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
+                 rand_layout_full=False, **kwargs):
+        if rand_colours or rand_shapes or rand_count or rand_layout_minor or rand_layout_full:
+            raise NotImplementedError('only the Demo variant is built (Test* variants: SURVEY.md §8f)')
+        super().__init__(**kwargs)
+        self.inlier_dist = self.SHAPE_RAD * INLIER_RAD_MULT
+        self.max_sep = self.SHAPE_RAD * MAX_SEP_RADS
+
+    def on_reset(self):   # make_line.py:91-122
+        robot = self._make_robot(*DEFAULT_ROBOT_POSE)
+        self._blocks = [self._make_shape(shape_type=s, colour_name=c, init_pos=p, init_angle=a)
+                        for s, c, (p, a) in zip(DEFAULT_BLOCK_SHAPES, DEFAULT_BLOCK_COLOURS, DEFAULT_BLOCK_POSES)]
+        self.add_entities(self._blocks)
+        self.add_entities([robot])
+
+    def score_on_end_of_traj(self, poses):   # make_line.py:142-152
+        bodies = [b.body for b in self._blocks]
+        out = np.empty(poses.shape[0], dtype=np.float64)
+        max_line_len = len(bodies)
+        min_line_len = max(max_line_len - 2, 2)
+        for m in range(poses.shape[0]):
+            points = np.ascontiguousarray(poses[m, bodies, :2], dtype='float64')
+            line_len = longest_line(points, self.inlier_dist, self.max_sep)
+            out[m] = max(line_len - min_line_len, 0) / (max_line_len - min_line_len)
+        return out

@@ -1,0 +1,31 @@
+"""MoveToCorner (mirror of magical/benchmarks/move_to_corner.py, Demo branch)."""
+import math
+
+import numpy as np
+
+from .. import entities as en
+from ..base_env import BaseEnv
+from ._scoring import row_norm
+
+
+class MoveToCornerEnv(BaseEnv):
+    def __init__(self, rand_shape_colour=False, rand_shape_type=False, rand_poses=False, debug_reward=False, **kwargs):
+        if rand_shape_colour or rand_shape_type or rand_poses or debug_reward:
+            raise NotImplementedError('only the Demo variant is built (Test* variants: SURVEY.md §8f)')
+        super().__init__(**kwargs)
+
+    def on_reset(self):   # move_to_corner.py:31-54
+        robot = self._make_robot(np.asarray((0.4, -0.0)), 0.55 * math.pi)
+        self.add_entities([robot])
+        shape = self._make_shape(shape_type=en.ShapeType.SQUARE, colour_name='red',
+                                 init_pos=np.asarray((0.1, -0.65)), init_angle=0.13 * math.pi)
+        self.add_entities([shape])
+        self.__shape_ref = shape
+
+    def score_on_end_of_traj(self, poses):   # move_to_corner.py:66-75
+        shape_pos = poses[:, self.__shape_ref.body, :2]
+        dist = row_norm(np.asarray([-1.0, 1.0]) - shape_pos)   # target is top left
+        succeed_dist = np.sqrt(2) / 2
+        furthest_dist = np.sqrt(2)
+        drange = furthest_dist - succeed_dist
+        return np.minimum(1.0, np.maximum(0.0, furthest_dist - dist) / drange)

@@ -1,0 +1,88 @@
+// mgx_step.hip -- k_step / k_reset: the physics half of BaseEnv.step() for N envs in lockstep.
+//
+// Launch geometry (CDNA4): one 64-lane wavefront per workgroup; the wave is split into
+// 64/L groups of L lanes and each group owns one env (L = 4..64, chosen per world by the host).
+// All of an env's state is staged HBM -> LDS once per env-step, the 10 substeps x 10 solver
+// iterations run out of LDS, and the state goes back once: HBM traffic per env-step is exactly
+// the persistent state, read once and written once, in [row][env] SoA order so that the loads of
+// consecutive envs coalesce.  N envs x L lanes / 64 workgroups: 4096 envs at L = 16 are 1024
+// single-wave workgroups = 4 per CU, spread over all 8 XCDs by the dispatcher.
+//
+// No MFMA: there is no dense contraction anywhere on this path.
+#include <hip/hip_runtime.h>
+
+#include "mgx_sim.h"
+
+namespace mgx {
+
+// template blob in global memory: [TmplHeader][int words][R words][P words], P part 8-byte aligned
+struct TmplDev {
+    const uint32_t *words;
+    int n_words;       // total 32-bit words to stage into LDS
+    int off_i, off_r, off_p;   // word offsets of the three arrays
+    int env_stride_words;      // per-env LDS stride in 32-bit words (multiple of 2)
+    int env_off_r, env_off_i;  // word offsets of the R and int regions inside an env's slab (P region first)
+    int lds_tmpl_words;        // words reserved for the template at the start of LDS (multiple of 2)
+};
+
+template <typename R, typename P, int L>
+__global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
+                                             const int32_t *__restrict__ actions, uint8_t *__restrict__ done,
+                                             int n_envs, int n_sub, int count_step, int iterations) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < t.n_words; i += 64) lds[i] = t.words[i];
+    __syncthreads();
+    const TmplHeader *h = reinterpret_cast<const TmplHeader *>(lds);
+    const int32_t *ti = reinterpret_cast<const int32_t *>(lds + t.off_i);
+    const R *tr = reinterpret_cast<const R *>(lds + t.off_r);
+    const P *tp = reinterpret_cast<const P *>(lds + t.off_p);
+
+    constexpr int EPB = 64 / L;
+    const int env_local = tid / L, lane = tid % L, nl = L;
+    long env = (long)blockIdx.x * EPB + env_local;
+    const bool valid = env < n_envs;
+    if (!valid) env = n_envs - 1;   // tail lanes shadow the last env (no stores) so barriers stay uniform
+    uint32_t *slab = lds + t.lds_tmpl_words + env_local * t.env_stride_words;
+    Env<R, P> e(h, ti, tr, tp, reinterpret_cast<R *>(slab + t.env_off_r), reinterpret_cast<P *>(slab),
+                reinterpret_cast<int32_t *>(slab + t.env_off_i));
+    const long stride = n_envs;
+
+#define SYNC(stmt) stmt; __syncthreads();
+    SYNC(ph_init_work(e, lane, nl))
+    SYNC(ph_load_state(e, sp, sf, si, stride, env, lane, nl))
+    ph_refresh_trig(e, lane, nl);
+    if (lane == 0) E_I(misc, M_ACTION) = actions[env];
+    __syncthreads();
+    if (lane == 0) ph_control(e);
+    __syncthreads();
+    for (int sub = 0; sub < n_sub; sub++) {
+        MGX_SUBSTEP_PHASES(SYNC)
+    }
+    if (lane == 0 && count_step) {
+        int steps = E_I(misc, M_STEPS) + 1;
+        E_I(misc, M_STEPS) = steps;
+        if (done && valid) done[env] = steps >= h->max_episode_steps ? 1 : 0;
+    }
+    __syncthreads();
+    if (valid) ph_store_state(e, sp, sf, si, stride, env, lane, nl);
+#undef SYNC
+}
+
+// BaseEnv.reset(): one thread per env writes the template state into the masked envs
+template <typename R, typename P>
+__global__ __launch_bounds__(64) void k_reset(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
+                                              const uint8_t *__restrict__ mask, int n_envs) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    for (int i = threadIdx.x; i < t.n_words; i += 64) lds[i] = t.words[i];
+    __syncthreads();
+    const TmplHeader *h = reinterpret_cast<const TmplHeader *>(lds);
+    const int32_t *ti = reinterpret_cast<const int32_t *>(lds + t.off_i);
+    const P *tp = reinterpret_cast<const P *>(lds + t.off_p);
+    long env = (long)blockIdx.x * 64 + threadIdx.x;
+    if (env >= n_envs) return;
+    if (mask && !mask[env]) return;
+    reset_env_state<R, P>(*h, ti, tp, sp, sf, si, (long)n_envs, env);
+}
+
+}  // namespace mgx

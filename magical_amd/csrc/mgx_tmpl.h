@@ -1,0 +1,162 @@
+// mgx_tmpl.h -- world template + per-env working-set layout shared by the host builder
+// (mgx_world.cpp) and the kernels (mgx_step.hip, mgx_raster.hip).
+//
+// A "template" is everything that is identical for all envs of a batch: body masses, local
+// shape geometry, joints, the filtered collision-pair list and the draw list.  It is
+// serialised as a header of counts plus two flat arrays (int32 words, real words) that each
+// workgroup copies into LDS.  Array offsets are derived from the counts by the same
+// constructor on host and device, so the header stays small.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MGX_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define MGX_HD inline
+#endif
+
+namespace mgx {
+
+enum BodyType { BODY_STATIC = 0, BODY_KINEMATIC = 1, BODY_DYNAMIC = 2 };
+enum ShapeKind { SH_CIRCLE = 0, SH_SEGMENT = 1, SH_POLY = 2 };
+enum JointKind { J_PIVOT = 0, J_GEAR = 1, J_SPRING = 2, J_PIN = 3, J_LIMIT = 4, J_MOTOR = 5 };
+enum PrimKind { PR_POLY = 0, PR_NGON = 1, PR_LINELOOP = 2 };
+enum PrimXform { XF_WORLD = 0, XF_BODY = 1, XF_EYE = 2 };
+
+// compile-time capacities (largest Demo world: Cluster* = 14 moving bodies, 27 shapes, 26 joints)
+constexpr int CAP_BODIES = 16;
+constexpr int CAP_SHAPES = 32;
+constexpr int CAP_VERTS = 112;
+constexpr int CAP_JOINTS = 32;
+constexpr int CAP_PAIRS = 448;
+constexpr int CAP_PRIMS = 64;    // rasteriser keeps per-tile primitive sets in one 64-bit ballot mask
+constexpr int CAP_PVERTS = 320;
+
+constexpr int JOINT_PARAMS = 10;   // ax ay bx by p0 p1 p2 bias_rate max_bias max_impulse
+constexpr int PRIM_IWORDS = 6;     // kind, nverts, voff, xform|body<<8|eye_body<<16, rgb(packed), stipple
+constexpr int PRIM_RWORDS = 6;     // eye_base(2) eye_pre(2) line_halfwidth radius
+
+struct TmplHeader {
+    int32_t n_bodies, n_shapes, n_verts, n_joints, n_pairs, n_prims, n_pverts;
+    int32_t n_state, n_state_p, n_jacc, cache_slots, max_contacts, max_overlaps;   // n_state_p of the n_state rows are pose rows
+    int32_t robot_body, control_body, finger_body[2], motor_joint[2];
+    int32_t max_episode_steps, n_words_i, n_words_r, n_words_p;
+};
+
+// indices into the consts block
+enum ConstIdx {
+    C_DT = 0, C_CONTACT_BIAS_RATE, C_SLOP, C_SPEED_FWD, C_SPEED_BACK, C_TURN, C_FINGER_OPEN, C_FINGER_CLOSED, C_N
+};
+
+// offsets into the template's int / real arrays
+struct TmplOff {
+    // ints
+    int body_type, body_parent, shape_kind, shape_body, shape_voff, shape_nv;
+    int joint_kind, joint_a, joint_b, joint_acc, pair, state_map, prim_i, body_prow, n_i;
+    // reals
+    int body_minv, body_iinv, body_init, body_anchor, shape_r, shape_u, lvx, lvy, lnx, lny;
+    int joint_p, prim_r, pvx, pvy, consts, n_r;
+    // pose-precision copies (P-typed array): initial poses, body anchors, joint anchors/angles, dt
+    int p_body_init, p_body_anchor, p_joint, p_dt, n_p;
+    MGX_HD explicit TmplOff(const TmplHeader &h) {
+        int o = 0;
+        body_type = o; o += h.n_bodies;
+        body_parent = o; o += h.n_bodies;
+        shape_kind = o; o += h.n_shapes;
+        shape_body = o; o += h.n_shapes;
+        shape_voff = o; o += h.n_shapes;
+        shape_nv = o; o += h.n_shapes;
+        joint_kind = o; o += h.n_joints;
+        joint_a = o; o += h.n_joints;
+        joint_b = o; o += h.n_joints;
+        joint_acc = o; o += h.n_joints;
+        pair = o; o += h.n_pairs;
+        state_map = o; o += h.n_state;
+        prim_i = o; o += h.n_prims * PRIM_IWORDS;
+        body_prow = o; o += h.n_bodies * 3;   // pose-blob row of (x, y, angle) per body, -1 if not persistent
+        n_i = o;
+        o = 0;
+        body_minv = o; o += h.n_bodies;
+        body_iinv = o; o += h.n_bodies;
+        body_init = o; o += h.n_bodies * 3;
+        body_anchor = o; o += h.n_bodies * 2;
+        shape_r = o; o += h.n_shapes;
+        shape_u = o; o += h.n_shapes;
+        lvx = o; o += h.n_verts;
+        lvy = o; o += h.n_verts;
+        lnx = o; o += h.n_verts;
+        lny = o; o += h.n_verts;
+        joint_p = o; o += h.n_joints * JOINT_PARAMS;
+        prim_r = o; o += h.n_prims * PRIM_RWORDS;
+        pvx = o; o += h.n_pverts;
+        pvy = o; o += h.n_pverts;
+        consts = o; o += C_N;
+        n_r = o;
+        o = 0;
+        p_body_init = o; o += h.n_bodies * 3;
+        p_body_anchor = o; o += h.n_bodies * 2;
+        p_joint = o; o += h.n_joints * 7;
+        p_dt = o; o += 1;
+        n_p = o;
+    }
+};
+
+// misc int slots per env
+enum MiscIdx { M_NOV = 0, M_NK, M_NARB, M_NCACHE, M_NNCACHE, M_OVERFLOW, M_ACTION, M_STEPS, M_N };
+
+// per-env LDS working set: offsets in real-sized words (R region) and 32-bit words (int region)
+struct WorkOff {
+    // bodies: poses live in the pose-precision region (P words), velocities in the R region
+    int px, py, ang, c, s, n_p;
+    int vx, vy, w, vbx, vby, wb;
+    // world-space shape data
+    int wx, wy, wnx, wny, bbl, bbb, bbr, bbt;
+    // joints: anchors, effective mass (k00..k11 | n.x n.y imass -), bias(2), accumulators(2), motor rate / spring target
+    int jr1x, jr1y, jr2x, jr2y, jk0, jk1, jk2, jk3, jb0, jb1, ja0, ja1, jrate;
+    // contact points
+    int knx, kny, kr1x, kr1y, kr2x, kr2y, knm, ktm, kbias, kjb, kjn, kjt, kmu;
+    // manifold scratch per overlapping pair: n(2) + 2 x (p1, p2)(4)
+    int mn, mp;
+    // persistent contact cache impulses (jn, jt per point) and the one being built
+    int cj, ncj;
+    int n_r;
+    // int region
+    int ov, mcnt, mhash, koff, kab, kfirst, chead, nchead, cmatched, misc, flag, cnt;
+    int n_i;
+    MGX_HD explicit WorkOff(const TmplHeader &h) {
+        int nb = h.n_bodies, nv = h.n_verts, ns = h.n_shapes, nj = h.n_joints;
+        int nk = h.max_contacts, nov = h.max_overlaps, nc = h.cache_slots;
+        int o = 0;
+        px = o; o += nb; py = o; o += nb; ang = o; o += nb; c = o; o += nb; s = o; o += nb;
+        n_p = o;
+        o = 0;
+        vx = o; o += nb; vy = o; o += nb; w = o; o += nb;
+        vbx = o; o += nb; vby = o; o += nb; wb = o; o += nb;
+        wx = o; o += nv; wy = o; o += nv; wnx = o; o += nv; wny = o; o += nv;
+        bbl = o; o += ns; bbb = o; o += ns; bbr = o; o += ns; bbt = o; o += ns;
+        jr1x = o; o += nj; jr1y = o; o += nj; jr2x = o; o += nj; jr2y = o; o += nj;
+        jk0 = o; o += nj; jk1 = o; o += nj; jk2 = o; o += nj; jk3 = o; o += nj;
+        jb0 = o; o += nj; jb1 = o; o += nj; ja0 = o; o += nj; ja1 = o; o += nj; jrate = o; o += nj;
+        knx = o; o += nk; kny = o; o += nk; kr1x = o; o += nk; kr1y = o; o += nk; kr2x = o; o += nk; kr2y = o; o += nk;
+        knm = o; o += nk; ktm = o; o += nk; kbias = o; o += nk; kjb = o; o += nk; kjn = o; o += nk; kjt = o; o += nk;
+        kmu = o; o += nk;
+        mn = o; o += nov * 2; mp = o; o += nov * 8;
+        cj = o; o += nc * 4; ncj = o; o += nc * 4;
+        n_r = o;
+        o = 0;
+        ov = o; o += nov; mcnt = o; o += nov; mhash = o; o += nov; koff = o; o += nov;
+        kab = o; o += nk; kfirst = o; o += nk;
+        chead = o; o += nc; nchead = o; o += nc; cmatched = o; o += nc;
+        misc = o; o += M_N;
+        flag = o; o += (h.n_pairs + 3) / 4;   // one byte per candidate pair
+        cnt = o; o += 64;                      // per-lane counters for ordered compaction
+        n_i = o;
+    }
+};
+
+// cache entry header: pair(12) | age(2)<<12 | count(2)<<14 | hash0(8)<<16 | hash1(8)<<24
+MGX_HD uint32_t cache_pack(uint32_t pair, uint32_t age, uint32_t count, uint32_t h0, uint32_t h1) {
+    return (pair & 0xFFFu) | ((age & 3u) << 12) | ((count & 3u) << 14) | ((h0 & 0xFFu) << 16) | ((h1 & 0xFFu) << 24);
+}
+
+}  // namespace mgx

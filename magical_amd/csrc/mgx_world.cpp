@@ -1,0 +1,481 @@
+// mgx_world.cpp -- entity list -> rigid bodies / shapes / joints / collision pairs / draw list.
+// See mgx_world.h for the reference lines each builder follows.
+#include "mgx_world.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace mgx {
+
+namespace {
+
+const double PI = 3.14159265358979323846;
+const double INF = std::numeric_limits<double>::infinity();
+
+// ---- palette: magical/style.py:28-37 evaluated to RGB8; a GL float colour
+// lands in the RGBA8 framebuffer as round(c*255).  tests/ check this table against colorsys.
+struct Rgb { int r, g, b; };
+const Rgb BASE[4] = {{245, 129, 165}, {195, 208, 130}, {135, 185, 211}, {254, 213, 123}};      // red green blue yellow
+const Rgb DARK[4] = {{243, 94, 141}, {183, 198, 105}, {110, 170, 202}, {254, 201, 86}};       // darken_rgb
+const Rgb LIGHT2[4] = {{250, 190, 209}, {224, 231, 191}, {194, 219, 233}, {254, 234, 188}};   // lighten_rgb(times=2)
+const Rgb GREY = {162, 163, 175}, GREY_DARK = {144, 145, 159}, BACKGROUND = {231, 231, 234};
+const Rgb WHITE = {255, 255, 255}, PUPIL = {26, 26, 26};
+
+const double ROBOT_LINE = 0.01, SHAPE_LINE = 0.015;   // style.py:25-27
+
+Vec2 rot(Vec2 v, double a) {   // pymunk Vec2d.rotated
+    double c = std::cos(a), s = std::sin(a);
+    return {v.x * c - v.y * s, v.x * s + v.y * c};
+}
+double moment_for_circle(double m, double r_in, double r_out) { return m * 0.5 * (r_in * r_in + r_out * r_out); }
+double moment_for_poly(double m, const std::vector<Vec2> &v) {   // cpMomentForPoly, offset 0, radius ignored
+    double sum1 = 0, sum2 = 0;
+    size_t n = v.size();
+    for (size_t i = 0; i < n; i++) {
+        Vec2 v1 = v[i], v2 = v[(i + 1) % n];
+        double a = v2.x * v1.y - v2.y * v1.x;
+        double b = (v1.x * v1.x + v1.y * v1.y) + (v1.x * v2.x + v1.y * v2.y) + (v2.x * v2.x + v2.y * v2.y);
+        sum1 += a * b; sum2 += a;
+    }
+    return (m * sum1) / (6.0 * sum2);
+}
+std::vector<Vec2> rect_verts(double w, double h) {   // geom.py:101-108
+    return {{w / 2, h / 2}, {-w / 2, h / 2}, {-w / 2, -h / 2}, {w / 2, -h / 2}};
+}
+std::vector<Vec2> draw_rect(double w, double h) {    // gym_render.py:449-453
+    return {{-w / 2, h / 2}, {w / 2, h / 2}, {w / 2, -h / 2}, {-w / 2, -h / 2}};
+}
+std::vector<Vec2> regular_poly(int n, double side) { // geom.py:13-15,35-46
+    double radius = side / (2 * std::sin(PI / n));
+    std::vector<Vec2> out;
+    for (int k = 0; k < n; k++) out.push_back(rot({0, radius}, k * (2 * PI / n)));
+    return out;
+}
+double area_equiv_side(int n, double rad) {          // geom.py:18-22
+    double p_n = PI / n;
+    return 2 * rad * std::sqrt(p_n * std::tan(p_n));
+}
+std::vector<Vec2> star_verts(int n, double r_out, double r_in) {   // geom.py:49-63
+    std::vector<Vec2> out;
+    for (int k = 0; k < n; k++) {
+        out.push_back(rot({0, r_out}, k * 2 * PI / n));
+        out.push_back(rot({0, r_in}, (2 * k + 1) * PI / n));
+    }
+    return out;
+}
+// Convex parts of a star.  The reference asks Chipmunk's autogeometry (entities.py:653-654), whose
+// partition is not observable here; we use 5 tip triangles + the inner pentagon (same union).
+std::vector<std::vector<Vec2>> star_parts(const std::vector<Vec2> &sv) {
+    int n = (int)sv.size() / 2;
+    std::vector<std::vector<Vec2>> parts;
+    for (int k = 0; k < n; k++) parts.push_back({sv[2 * ((k - 1 + n) % n) + 1], sv[2 * k], sv[2 * k + 1]});
+    std::vector<Vec2> inner;
+    for (int k = 0; k < n; k++) inner.push_back(sv[2 * k + 1]);
+    parts.push_back(inner);
+    return parts;
+}
+// entities.py:193-214
+void finger_vertices(double upper_len, double fore_len, double thick, double side,
+                     std::vector<Vec2> &upper, std::vector<Vec2> &fore) {
+    double up_shift = upper_len / 2;
+    upper = rect_verts(thick, upper_len);
+    fore = rect_verts(thick, fore_len);
+    Vec2 upper_start = {side * thick / 2, upper_len / 2};
+    Vec2 off = rot({-side * thick / 2, fore_len / 2}, side * PI / 8);
+    Vec2 trans = {upper_start.x + off.x, upper_start.y + off.y + up_shift};
+    for (auto &v : fore) { Vec2 r = rot(v, side * PI / 8); v = {r.x + trans.x, r.y + trans.y}; }
+    for (auto &v : upper) v.y += up_shift;
+}
+
+JointDef joint(int kind, int a, int b) {
+    JointDef j{};
+    j.kind = kind; j.a = a; j.b = b;
+    j.error_bias = std::pow(1.0 - 0.1, 60.0);   // Chipmunk default
+    j.max_bias = INF; j.max_force = INF;
+    return j;
+}
+PrimDef prim(int kind, Rgb c, int xform, int body) {
+    PrimDef p{};
+    p.kind = kind; p.xform = xform; p.body = body; p.eye_body = -1;
+    p.rgb[0] = c.r; p.rgb[1] = c.g; p.rgb[2] = c.b;
+    return p;
+}
+
+}  // namespace
+
+int World::finalize(int max_steps, std::string &err) {
+    if (finalized) { err = "world already finalized"; return -3; }
+    max_episode_steps = max_steps;
+    const double *pv = phys_vars;
+    // body 0: every static body (space.static_body, the arena body, goal bodies) in one world frame
+    bodies.push_back({BODY_STATIC, 0, 0, 0, 0, 0, -1, 0, 0, 0});
+
+    // ---- arena (entities.py:502-537): added first by BaseEnv.reset (base_env.py:213)
+    {
+        double l = -1, r = 1, t = 1, b = -1, rad = 1;
+        Vec2 pts[4] = {{l - rad, t + rad}, {r + rad, t + rad}, {r + rad, b - rad}, {l - rad, b - rad}};
+        for (int i = 0; i < 4; i++) {
+            ShapeDef s{SH_SEGMENT, 0, rad, 0.8, 0, -1, {pts[i], pts[(i + 1) % 4]}};
+            shapes.push_back(s);
+        }
+        PrimDef q = prim(PR_POLY, WHITE, XF_WORLD, 0);
+        q.verts = draw_rect(r - l, t - b);
+        prims.push_back(q);
+        // PolyLine: attrs enabled in reverse add order (gym_render.py:306-311) -> glLineWidth(1) wins
+        PrimDef ln = prim(PR_LINELOOP, GREY, XF_WORLD, 0);
+        ln.verts = draw_rect(r - l, t - b); ln.line_width = 1.0;
+        prims.push_back(ln);
+    }
+
+    int n_blocks = 0;
+    for (size_t ei = 0; ei < entities.size(); ei++) {
+        EntityDef &e = entities[ei];
+        if (e.kind == 0) {
+            // ---------------- Robot (entities.py:238-437)
+            if (robot_body >= 0) { err = "only one robot per world"; return -1; }
+            double radius = ROBOT_RAD, mass = ROBOT_MASS;
+            int body = (int)bodies.size();
+            robot_body = body; e.body = body;
+            bodies.push_back({BODY_DYNAMIC, 1.0 / mass, 1.0 / moment_for_circle(mass, 0, radius), e.x, e.y, e.angle, -1, 0, 0, 0x1FF});
+            control_body = (int)bodies.size();
+            bodies.push_back({BODY_KINEMATIC, 0, 0, e.x, e.y, e.angle, -1, 0, 0, 0});
+            JointDef pj = joint(J_PIVOT, control_body, body);              // :255-258
+            pj.max_bias = 0; pj.max_force = pv[0];
+            joints.push_back(pj);
+            JointDef gj = joint(J_GEAR, control_body, body);               // :259-263
+            gj.p0 = 0.0; gj.p1 = 1.0; gj.error_bias = 0.0; gj.max_bias = 2.5; gj.max_force = pv[1];
+            joints.push_back(gj);
+            int eye_bodies[2];
+            for (int k = 0; k < 2; k++) {                                  // :267-277
+                double em = mass / 10;
+                eye_bodies[k] = (int)bodies.size();
+                bodies.push_back({BODY_DYNAMIC, 1.0 / em, 1.0 / moment_for_circle(em, 0, radius), 0, 0, e.angle, -1, 0, 0,
+                                  (1 << 2) | (1 << 5)});
+                JointDef sj = joint(J_SPRING, body, eye_bodies[k]);
+                sj.p0 = 0; sj.p1 = 0.1; sj.p2 = 3e-3;
+                joints.push_back(sj);
+            }
+            double thick = 0.25 * radius, upper_len = 1.1 * radius, fore_len = 0.7 * radius;   // :280-282
+            std::vector<Vec2> f_upper[2], f_fore[2], fi_upper[2], fi_fore[2];
+            for (int k = 0; k < 2; k++) {                                  // :288-354
+                double side = k == 0 ? -1.0 : 1.0;
+                finger_vertices(upper_len, fore_len, thick, side, f_upper[k], f_fore[k]);
+                finger_vertices(upper_len - ROBOT_LINE * 2, fore_len - ROBOT_LINE * 2, thick - ROBOT_LINE * 2, side,
+                                fi_upper[k], fi_fore[k]);
+                for (auto &v : fi_upper[k]) v.y += ROBOT_LINE;
+                for (auto &v : fi_fore[k]) v.y += ROBOT_LINE;
+                double lim_outer = PI / 8, lim_inner = 0.0;
+                double lo = side < 0 ? -lim_inner : -lim_outer;
+                double hi = side < 0 ? lim_outer : lim_inner;
+                double fm = mass / 8;
+                std::vector<Vec2> cat = f_upper[k];
+                cat.insert(cat.end(), f_fore[k].begin(), f_fore[k].end());
+                double fi = moment_for_poly(fm, cat);                      // 8-vertex concatenation (:314-315)
+                double delta = side < 0 ? hi : lo;
+                Vec2 rel = {side * radius * 0.45, radius * 0.1};
+                Vec2 rr = rot(rel, e.angle);
+                int fb = (int)bodies.size();
+                finger_body[k] = fb;
+                bodies.push_back({BODY_DYNAMIC, 1.0 / fm, 1.0 / fi, e.x + rr.x, e.y + rr.y, e.angle + delta, body, rel.x, rel.y, 0x1FF});
+                JointDef pin = joint(J_PIN, body, fb);                     // :334-341
+                pin.ax = rel.x; pin.ay = rel.y; pin.bx = 0; pin.by = 0; pin.error_bias = 0.0;
+                pin.p0 = 0.0;   // anchors coincide at construction -> rest length exactly 0
+                joints.push_back(pin);
+                JointDef lim = joint(J_LIMIT, body, fb);                   // :343-346
+                lim.p0 = lo; lim.p1 = hi; lim.error_bias = 0.0;
+                joints.push_back(lim);
+                JointDef mot = joint(J_MOTOR, body, fb);                   // :349-354
+                mot.max_bias = 0.0; mot.max_force = pv[2];
+                motor_joint[k] = (int)joints.size();
+                joints.push_back(mot);
+            }
+            int robot_group = 1;                                           // :358-375
+            e.shapes.push_back((int)shapes.size());
+            shapes.push_back({SH_CIRCLE, body, radius, 0.5, robot_group, (int)ei, {}});
+            for (int k = 0; k < 2; k++) {
+                e.shapes.push_back((int)shapes.size());
+                shapes.push_back({SH_POLY, finger_body[k], 0.0, 5.0, robot_group, (int)ei, f_upper[k]});
+                e.shapes.push_back((int)shapes.size());
+                shapes.push_back({SH_POLY, finger_body[k], 0.0, 5.0, robot_group, (int)ei, f_fore[k]});
+            }
+            // graphics (:377-437): finger outers, finger inners, then the body compound
+            for (int k = 0; k < 2; k++) {
+                PrimDef a = prim(PR_POLY, GREY, XF_BODY, finger_body[k]); a.verts = f_upper[k]; prims.push_back(a);
+                PrimDef b = prim(PR_POLY, GREY, XF_BODY, finger_body[k]); b.verts = f_fore[k]; prims.push_back(b);
+            }
+            for (int k = 0; k < 2; k++) {
+                PrimDef a = prim(PR_POLY, BACKGROUND, XF_BODY, finger_body[k]); a.verts = fi_upper[k]; prims.push_back(a);
+                PrimDef b = prim(PR_POLY, BACKGROUND, XF_BODY, finger_body[k]); b.verts = fi_fore[k]; prims.push_back(b);
+            }
+            PrimDef co = prim(PR_NGON, GREY_DARK, XF_BODY, body); co.ngon = 100; co.radius = radius; prims.push_back(co);
+            PrimDef ci = prim(PR_NGON, GREY, XF_BODY, body); ci.ngon = 100; ci.radius = radius - ROBOT_LINE; prims.push_back(ci);
+            for (int k = 0; k < 2; k++) {
+                double xs = k == 0 ? -1.0 : 1.0;
+                PrimDef eye = prim(PR_NGON, WHITE, XF_EYE, body);
+                eye.ngon = 20; eye.radius = 0.2 * radius; eye.eye_base[0] = xs * 0.4 * radius; eye.eye_base[1] = 0.3 * radius;
+                prims.push_back(eye);
+                PrimDef pup = prim(PR_NGON, PUPIL, XF_EYE, body);
+                pup.ngon = 10; pup.radius = 0.12 * radius; pup.eye_base[0] = eye.eye_base[0]; pup.eye_base[1] = eye.eye_base[1];
+                pup.eye_body = eye_bodies[k]; pup.eye_pre[0] = 0; pup.eye_pre[1] = radius * 0.07;
+                prims.push_back(pup);
+            }
+        } else if (e.kind == 1) {
+            // ---------------- Shape (entities.py:614-757)
+            n_blocks++;
+            double mass = SHAPE_MASS, size = SHAPE_RAD;
+            int body = (int)bodies.size();
+            e.body = body;
+            std::vector<std::vector<Vec2>> phys_parts, draw_outer, draw_inner;
+            double inertia = 0, poly_radius = 0;
+            bool circle = false;
+            int group = 0;
+            Rgb col = BASE[e.colour], dark = DARK[e.colour];
+            if (e.shape_type == 1) {                                       // SQUARE :620-635
+                double side = std::sqrt(PI) * size, hw = side / 2;
+                std::vector<Vec2> box = {{hw, -hw}, {hw, hw}, {-hw, hw}, {-hw, -hw}};   // cpBoxShapeInit2 order
+                inertia = mass * moment_for_poly(1.0, box);               // mass comes from shape.mass
+                poly_radius = 0.01 * side;
+                phys_parts = {box};
+                draw_outer = {draw_rect(side, side)};
+                draw_inner = {draw_rect(side - 2 * SHAPE_LINE, side - 2 * SHAPE_LINE)};
+            } else if (e.shape_type == 5) {                                // CIRCLE :636-645
+                inertia = moment_for_circle(mass, 0, size);
+                circle = true;
+            } else if (e.shape_type == 6) {                                // STAR :646-668
+                double r_out = 1.3 * size, r_in = 0.5 * r_out;
+                std::vector<Vec2> sv = star_verts(5, r_out, r_in);
+                std::vector<Vec2> hull;                                    // to_convex_hull -> the 5 tips
+                for (int k = 0; k < 5; k++) hull.push_back(sv[2 * k]);
+                inertia = moment_for_poly(mass, hull);
+                phys_parts = star_parts(sv);
+                group = ++group_ctr;                                       // generate_group_id :60-66
+                draw_outer = phys_parts;
+                draw_inner = star_parts(star_verts(5, r_out - SHAPE_LINE, r_in - SHAPE_LINE));
+            } else {                                                       // regular polygons :669-697
+                int ns; double factor = 1.0;
+                switch (e.shape_type) {
+                    case 0: ns = 3; factor = 0.8; break;
+                    case 2: ns = 5; break;
+                    case 3: ns = 6; break;
+                    case 4: ns = 8; break;
+                    default: err = "bad shape type"; return -1;
+                }
+                double side = factor * area_equiv_side(ns, size);
+                std::vector<Vec2> pv_ = regular_poly(ns, side);
+                inertia = moment_for_poly(mass, pv_);
+                phys_parts = {pv_};
+                double apothem = side / (2 * std::tan(PI / ns));
+                double short_side = 2 * (apothem - SHAPE_LINE) * std::tan(PI / ns);
+                draw_outer = {pv_};
+                draw_inner = {regular_poly(ns, short_side)};
+            }
+            bodies.push_back({BODY_DYNAMIC, 1.0 / mass, 1.0 / inertia, e.x, e.y, e.angle, -1, 0, 0, 0x1FF});
+            if (circle) {
+                e.shapes.push_back((int)shapes.size());
+                shapes.push_back({SH_CIRCLE, body, size, 0.5, 0, (int)ei, {}});
+            } else {
+                for (auto &part : phys_parts) {
+                    e.shapes.push_back((int)shapes.size());
+                    shapes.push_back({SH_POLY, body, poly_radius, 0.5, group, (int)ei, part});
+                }
+            }
+            JointDef tj = joint(J_PIVOT, 0, body);                         // :703-707
+            tj.max_bias = 0; tj.max_force = pv[3];
+            joints.push_back(tj);
+            JointDef rj = joint(J_GEAR, 0, body);                          // :708-711
+            rj.p0 = 0.0; rj.p1 = 1.0; rj.max_bias = 0; rj.max_force = pv[4];
+            joints.push_back(rj);
+            if (circle) {
+                PrimDef o = prim(PR_NGON, dark, XF_BODY, body); o.ngon = 100; o.radius = size; prims.push_back(o);
+                PrimDef i = prim(PR_NGON, col, XF_BODY, body); i.ngon = 100; i.radius = size - SHAPE_LINE; prims.push_back(i);
+            } else {
+                for (auto &g : draw_outer) { PrimDef o = prim(PR_POLY, dark, XF_BODY, body); o.verts = g; prims.push_back(o); }
+                for (auto &g : draw_inner) { PrimDef i = prim(PR_POLY, col, XF_BODY, body); i.verts = g; prims.push_back(i); }
+            }
+        } else {
+            // ---------------- GoalRegion (entities.py:790-819): static sensor, drawn only
+            e.body = -1;
+            double cx = e.x + e.w / 2, cy = e.y - e.h / 2;
+            std::vector<Vec2> rect = draw_rect(e.w, e.h);
+            for (auto &v : rect) { v.x += cx; v.y += cy; }
+            PrimDef fill = prim(PR_POLY, LIGHT2[e.colour], XF_WORLD, 0); fill.verts = rect; prims.push_back(fill);
+            PrimDef outl = prim(PR_LINELOOP, BASE[e.colour], XF_WORLD, 0);
+            outl.verts = rect; outl.line_width = 2.5; outl.stipple = 0x00FF;
+            prims.push_back(outl);
+        }
+    }
+    if (robot_body < 0) { err = "world has no robot"; return -1; }
+
+    // ---- filtered candidate pairs (cpSpaceCollideShapes QueryReject minus the BB test)
+    for (int i = 0; i < (int)shapes.size(); i++)
+        for (int j = i + 1; j < (int)shapes.size(); j++) {
+            const ShapeDef &a = shapes[i], &b = shapes[j];
+            if (bodies[a.body].type == BODY_STATIC && bodies[b.body].type == BODY_STATIC) continue;
+            if (a.body == b.body) continue;
+            if (a.group != 0 && a.group == b.group) continue;
+            int sa = i, sb = j;
+            if (shapes[sa].kind > shapes[sb].kind) { sa = j; sb = i; }   // cpCollide type ordering
+            pairs.push_back({sa, sb});
+        }
+    // ---- persistent state rows
+    // comp | body<<4 | row-within-blob<<12; pose components (x y a) go to the pose blob, the rest to the
+    // velocity blob
+    n_state_p = 0;
+    {
+        int row_p = 0, row_v = 0;
+        for (int b = 0; b < (int)bodies.size(); b++)
+            for (int c = 0; c < 9; c++)
+                if (bodies[b].state_mask & (1 << c)) {
+                    int row = c < 3 ? row_p++ : row_v++;
+                    state_map.push_back(c | (b << 4) | (row << 12));
+                }
+        n_state_p = row_p;
+    }
+    n_jacc = 0;
+    for (auto &j : joints) {
+        joint_acc_off.push_back(n_jacc);
+        n_jacc += (j.kind == J_PIVOT) ? 2 : (j.kind == J_SPRING ? 0 : 1);
+    }
+    cache_slots = 10 + 3 * n_blocks;
+    if (cache_slots > 60) cache_slots = 60;
+    max_contacts = 2 * cache_slots;
+    max_overlaps = 2 * cache_slots + 8;
+
+    int nverts = 0, npv = 0;
+    for (auto &s : shapes) nverts += (s.kind == SH_CIRCLE) ? 1 : (int)s.verts.size();
+    for (auto &p : prims) npv += (int)p.verts.size();
+    if ((int)bodies.size() > CAP_BODIES || (int)shapes.size() > CAP_SHAPES || nverts > CAP_VERTS ||
+        (int)joints.size() > CAP_JOINTS || (int)pairs.size() > CAP_PAIRS || (int)prims.size() > CAP_PRIMS ||
+        npv > CAP_PVERTS) {
+        err = "world exceeds compiled capacities (bodies " + std::to_string(bodies.size()) + ", shapes " +
+              std::to_string(shapes.size()) + ", verts " + std::to_string(nverts) + ", joints " +
+              std::to_string(joints.size()) + ", pairs " + std::to_string(pairs.size()) + ", prims " +
+              std::to_string(prims.size()) + ", prim verts " + std::to_string(npv) + ")";
+        return -2;
+    }
+    finalized = true;
+    return 0;
+}
+
+void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<double> &rw, std::vector<double> &pw) const {
+    std::memset(&h, 0, sizeof(h));
+    h.n_bodies = (int)bodies.size();
+    h.n_shapes = (int)shapes.size();
+    h.n_joints = (int)joints.size();
+    h.n_pairs = (int)pairs.size();
+    h.n_prims = (int)prims.size();
+    int nverts = 0, npv = 0;
+    for (auto &s : shapes) nverts += (s.kind == SH_CIRCLE) ? 1 : (int)s.verts.size();
+    for (auto &p : prims) npv += (int)p.verts.size();
+    h.n_verts = nverts; h.n_pverts = npv;
+    h.n_state = (int)state_map.size();
+    h.n_state_p = n_state_p;
+    h.n_jacc = n_jacc;
+    h.cache_slots = cache_slots; h.max_contacts = max_contacts; h.max_overlaps = max_overlaps;
+    h.robot_body = robot_body; h.control_body = control_body;
+    h.finger_body[0] = finger_body[0]; h.finger_body[1] = finger_body[1];
+    h.motor_joint[0] = motor_joint[0]; h.motor_joint[1] = motor_joint[1];
+    h.max_episode_steps = max_episode_steps;
+    TmplOff o(h);
+    h.n_words_i = o.n_i; h.n_words_r = o.n_r; h.n_words_p = o.n_p;
+    iw.assign(o.n_i, 0);
+    rw.assign(o.n_r, 0.0);
+    pw.assign(o.n_p, 0.0);
+    const double dt = 1.0 / FPS / PHYS_STEPS;
+    for (int b = 0; b < h.n_bodies; b++) {
+        const BodyDef &B = bodies[b];
+        iw[o.body_type + b] = B.type; iw[o.body_parent + b] = B.parent;
+        rw[o.body_minv + b] = B.m_inv; rw[o.body_iinv + b] = B.i_inv;
+        rw[o.body_init + 3 * b] = B.x; rw[o.body_init + 3 * b + 1] = B.y; rw[o.body_init + 3 * b + 2] = B.a;
+        rw[o.body_anchor + 2 * b] = B.ax; rw[o.body_anchor + 2 * b + 1] = B.ay;
+        pw[o.p_body_init + 3 * b] = B.x; pw[o.p_body_init + 3 * b + 1] = B.y; pw[o.p_body_init + 3 * b + 2] = B.a;
+        pw[o.p_body_anchor + 2 * b] = B.ax; pw[o.p_body_anchor + 2 * b + 1] = B.ay;
+    }
+    int voff = 0;
+    for (int s = 0; s < h.n_shapes; s++) {
+        const ShapeDef &S = shapes[s];
+        int nv = (S.kind == SH_CIRCLE) ? 1 : (int)S.verts.size();
+        iw[o.shape_kind + s] = S.kind; iw[o.shape_body + s] = S.body;
+        iw[o.shape_voff + s] = voff; iw[o.shape_nv + s] = nv;
+        rw[o.shape_r + s] = S.radius; rw[o.shape_u + s] = S.friction;
+        if (S.kind == SH_CIRCLE) {
+            rw[o.lvx + voff] = 0; rw[o.lvy + voff] = 0;
+        } else {
+            for (int i = 0; i < nv; i++) { rw[o.lvx + voff + i] = S.verts[i].x; rw[o.lvy + voff + i] = S.verts[i].y; }
+            if (S.kind == SH_SEGMENT) {
+                // a segment is treated as a 2-vertex polygon: plane 1 = edge (a -> b) carries
+                // cpSegmentShape's n = rperp(normalize(b - a)), plane 0 = edge (b -> a) carries -n
+                double dx = S.verts[1].x - S.verts[0].x, dy = S.verts[1].y - S.verts[0].y;
+                double len = std::sqrt(dx * dx + dy * dy);
+                rw[o.lnx + voff + 1] = dy / len; rw[o.lny + voff + 1] = -dx / len;
+                rw[o.lnx + voff] = -dy / len; rw[o.lny + voff] = dx / len;
+            } else {
+                // cpPolyShape SetVerts: plane i = edge (i-1 -> i), outward normal rperp(b - a)/|b - a|
+                for (int i = 0; i < nv; i++) {
+                    Vec2 a = S.verts[(i - 1 + nv) % nv], b = S.verts[i];
+                    double ex = b.x - a.x, ey = b.y - a.y, len = std::sqrt(ex * ex + ey * ey);
+                    rw[o.lnx + voff + i] = ey / len; rw[o.lny + voff + i] = -ex / len;
+                }
+            }
+        }
+        voff += nv;
+    }
+    for (int j = 0; j < h.n_joints; j++) {
+        const JointDef &J = joints[j];
+        iw[o.joint_kind + j] = J.kind; iw[o.joint_a + j] = J.a; iw[o.joint_b + j] = J.b;
+        iw[o.joint_acc + j] = joint_acc_off[j];
+        double *p = &rw[o.joint_p + j * JOINT_PARAMS];
+        double ia = bodies[J.a].i_inv, ib = bodies[J.b].i_inv;
+        p[0] = J.ax; p[1] = J.ay; p[2] = J.bx; p[3] = J.by; p[4] = J.p0; p[5] = J.p1; p[6] = J.p2;
+        {
+            double *q = &pw[o.p_joint + j * 7];
+            q[0] = J.ax; q[1] = J.ay; q[2] = J.bx; q[3] = J.by; q[4] = J.p0; q[5] = J.p1; q[6] = J.p2;
+        }
+        p[7] = (1.0 - std::pow(J.error_bias, dt)) / dt;   // bias_coef / dt
+        p[8] = J.max_bias;
+        p[9] = J.max_force * dt;
+        switch (J.kind) {                                   // constant angular effective masses
+            case J_GEAR: p[0] = 1.0 / (ia * (1.0 / J.p1) + J.p1 * ib); break;
+            case J_LIMIT: case J_MOTOR: p[0] = 1.0 / (ia + ib); break;
+            case J_SPRING:
+                p[0] = 1.0 / (ia + ib);
+                p[5] = J.p1 * dt;                            // stiffness * dt
+                p[6] = 1.0 - std::exp(-J.p2 * dt * (ia + ib));   // w_coef
+                break;
+            default: break;
+        }
+    }
+    for (int k = 0; k < h.n_pairs; k++) iw[o.pair + k] = pairs[k].first | (pairs[k].second << 8);
+    for (int k = 0; k < h.n_state; k++) iw[o.state_map + k] = state_map[k];
+    for (int k = 0; k < 3 * h.n_bodies; k++) iw[o.body_prow + k] = -1;
+    for (int k = 0; k < h.n_state; k++) {
+        int m = state_map[k], comp = m & 15, b = (m >> 4) & 0xFF, row = m >> 12;
+        if (comp < 3) iw[o.body_prow + 3 * b + comp] = row;
+    }
+    int pvoff = 0;
+    for (int k = 0; k < h.n_prims; k++) {
+        const PrimDef &P = prims[k];
+        int32_t *pi = &iw[o.prim_i + k * PRIM_IWORDS];
+        double *pr = &rw[o.prim_r + k * PRIM_RWORDS];
+        int nv = (P.kind == PR_NGON) ? P.ngon : (int)P.verts.size();
+        pi[0] = P.kind; pi[1] = nv; pi[2] = pvoff;
+        pi[3] = P.xform | (P.body << 8) | ((P.eye_body + 1) << 16);
+        pi[4] = P.rgb[0] | (P.rgb[1] << 8) | (P.rgb[2] << 16);
+        pi[5] = P.stipple;
+        pr[0] = P.eye_base[0]; pr[1] = P.eye_base[1]; pr[2] = P.eye_pre[0]; pr[3] = P.eye_pre[1];
+        pr[4] = 0.5 * (P.line_width + 1.0);
+        pr[5] = P.radius;
+        for (size_t i = 0; i < P.verts.size(); i++) { rw[o.pvx + pvoff + i] = P.verts[i].x; rw[o.pvy + pvoff + i] = P.verts[i].y; }
+        pvoff += (int)P.verts.size();
+    }
+    double *c = &rw[o.consts];
+    c[C_DT] = dt;
+    pw[o.p_dt] = dt;
+    c[C_CONTACT_BIAS_RATE] = (1.0 - std::pow(std::pow(1.0 - 0.1, 60.0), dt)) / dt;   // collision_bias default
+    c[C_SLOP] = COLLISION_SLOP;
+    c[C_SPEED_FWD] = 4.0 * ROBOT_RAD; c[C_SPEED_BACK] = 3.0 * ROBOT_RAD; c[C_TURN] = 1.5;   // entities.py:439-451
+    c[C_FINGER_OPEN] = PI / 8; c[C_FINGER_CLOSED] = 0.0;                                       // :227-228,452-457
+}
+
+}  // namespace mgx

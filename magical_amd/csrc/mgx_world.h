@@ -1,0 +1,86 @@
+// mgx_world.h -- host-side world description and template builder (C++, fp64).
+//
+// Restates the physical + visual spec the reference builds at reset time:
+//   base_env.py:177-234 (space params, arena first), entities.py:217-437 (Robot.setup),
+//   :502-537 (ArenaBoundaries.setup), :614-757 (Shape.setup), :790-819 (GoalRegion.setup),
+//   geom.py:13-63,101-108 (vertex maths), style.py (palette).
+// Independent of oracle/ (which holds its own Python restatement); tests compare the two.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "mgx_tmpl.h"
+
+namespace mgx {
+
+struct Vec2 { double x, y; };
+
+struct BodyDef {
+    int type;
+    double m_inv, i_inv;
+    double x, y, a;          // initial pose
+    int parent;              // >= 0: position = parent pose applied to (ax, ay) at reset (finger roots)
+    double ax, ay;
+    int state_mask;          // bit c set: component c (x y a vx vy w vbx vby wb) is persistent state
+};
+struct ShapeDef {
+    int kind, body;
+    double radius, friction;
+    int group, entity;
+    std::vector<Vec2> verts;  // local; circle: none; segment: 2
+};
+struct JointDef {
+    int kind, a, b;
+    double ax, ay, bx, by, p0, p1, p2;
+    double error_bias, max_bias, max_force;
+};
+struct PrimDef {
+    int kind, xform, body, eye_body;
+    std::vector<Vec2> verts;
+    int rgb[3];
+    double eye_base[2], eye_pre[2];
+    double line_width; int stipple;
+    double radius; int ngon;
+};
+struct EntityDef {
+    int kind;                // 0 robot, 1 shape, 2 goal
+    int shape_type, colour;
+    double x, y, angle, h, w;
+    int body;                // main body index after finalize (-1 for goals)
+    std::vector<int> shapes;
+};
+
+struct World {
+    double phys_vars[5] = {3.0, 1.0, 4.0, 1.5, 0.1};   // base_env.py:49-57
+    std::vector<EntityDef> entities;
+    bool finalized = false;
+    int max_episode_steps = 0;
+    // built by finalize()
+    std::vector<BodyDef> bodies;
+    std::vector<ShapeDef> shapes;
+    std::vector<JointDef> joints;
+    std::vector<PrimDef> prims;
+    std::vector<std::pair<int, int>> pairs;
+    std::vector<int> state_map;        // comp | body<<4 | row<<12
+    int n_state_p = 0;
+    std::vector<int> joint_acc_off;
+    int n_jacc = 0, cache_slots = 0, max_contacts = 0, max_overlaps = 0;
+    int robot_body = -1, control_body = -1, finger_body[2] = {-1, -1}, motor_joint[2] = {-1, -1};
+    int group_ctr = 999;
+
+    int finalize(int max_steps, std::string &err);
+    // serialise: header + int words + real words (as double; caller narrows to float if needed)
+    void serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<double> &rw, std::vector<double> &pw) const;
+};
+
+// physics constants of the reference (base_env.py:62-64,194-196,236-239; benchmarks/__init__.py:401-404)
+constexpr double ROBOT_RAD = 0.2;
+constexpr double ROBOT_MASS = 1.0;
+constexpr double SHAPE_RAD = ROBOT_RAD * 0.6;
+constexpr double SHAPE_MASS = 0.5;
+constexpr double FPS = 8.0;
+constexpr int PHYS_STEPS = 10;
+constexpr int PHYS_ITER = 10;
+constexpr double COLLISION_SLOP = 0.01;
+
+}  // namespace mgx

@@ -1,0 +1,111 @@
+// tests/emu/mgx_emu.cpp -- HOST EMULATION OF THE KERNEL PHASES (test harness only).
+//
+// Compiles magical_amd/csrc/mgx_sim.h as plain C++ and runs the lane-parallel phases of the
+// HIP step kernel sequentially (all lanes of phase k, then phase k+1), so the phase logic can
+// be compared with the oracle on a machine without a GPU.  It is NOT a product fallback: the
+// magical_amd package never loads this library, and the product path fails loudly without the
+// HIP extension.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../magical_amd/csrc/mgx_sim.h"
+#include "../../magical_amd/csrc/mgx_world.h"
+
+using namespace mgx;
+
+struct EmuBase {
+    virtual ~EmuBase() {}
+    TmplHeader h;
+    std::vector<int32_t> ti;
+    int n_envs;
+    virtual void reset(void *sp, void *sf, int32_t *si, const uint8_t *mask) = 0;
+    virtual void run(void *sp, void *sf, int32_t *si, const int32_t *actions, int n_sub, int nl, bool count_step, uint8_t *done) = 0;
+    virtual int contacts(double *out, int max_rows) = 0;
+};
+
+template <typename R, typename P> struct Emu : EmuBase {
+    std::vector<R> tr; std::vector<P> tp;
+    std::vector<R> wr; std::vector<P> wp; std::vector<int32_t> wi;
+    Emu(const World &w, int n) {
+        n_envs = n;
+        std::vector<double> rw, pw;
+        w.serialise(h, ti, rw, pw);
+        tr.resize(rw.size()); tp.resize(pw.size());
+        for (size_t i = 0; i < rw.size(); i++) tr[i] = (R)rw[i];
+        for (size_t i = 0; i < pw.size(); i++) tp[i] = (P)pw[i];
+        WorkOff wo(h);
+        wr.assign(wo.n_r, R(0)); wp.assign(wo.n_p, P(0)); wi.assign(wo.n_i, 0);
+    }
+    Env<R, P> env() { return Env<R, P>(&h, ti.data(), tr.data(), tp.data(), wr.data(), wp.data(), wi.data()); }
+    void reset(void *sp, void *sf, int32_t *si, const uint8_t *mask) override {
+        for (int e = 0; e < n_envs; e++)
+            if (!mask || mask[e]) reset_env_state<R, P>(h, ti.data(), tp.data(), (P *)sp, (R *)sf, si, n_envs, e);
+    }
+    void run(void *sp_, void *sf_, int32_t *si, const int32_t *actions, int n_sub, int nl, bool count_step, uint8_t *done) override {
+        P *sp = (P *)sp_; R *sf = (R *)sf_;
+        const int iterations = 10;
+        for (int ei = 0; ei < n_envs; ei++) {
+            Env<R, P> e = env();
+#define RUN(stmt) for (int lane = 0; lane < nl; lane++) { stmt; }
+            RUN(ph_init_work(e, lane, nl))
+            RUN(ph_load_state(e, sp, sf, si, (long)n_envs, (long)ei, lane, nl))
+            RUN(ph_refresh_trig(e, lane, nl))
+            e.wi[e.wo.misc + M_ACTION] = actions[ei];
+            ph_control(e);
+            for (int sub = 0; sub < n_sub; sub++) { MGX_SUBSTEP_PHASES(RUN) }
+            if (count_step) {
+                e.wi[e.wo.misc + M_STEPS] += 1;
+                if (done) done[ei] = e.wi[e.wo.misc + M_STEPS] >= h.max_episode_steps ? 1 : 0;
+            }
+            RUN(ph_store_state(e, sp, sf, si, (long)n_envs, (long)ei, lane, nl))
+#undef RUN
+        }
+    }
+    // debug: contacts of the LAST env processed: rows [a, b, nx, ny, p1x, p1y, p2x, p2y, jn, jt, first]
+    int contacts(double *out, int max_rows) override {
+        Env<R, P> e = env();
+        int nk = e.wi[e.wo.misc + M_NK];
+        for (int k = 0; k < nk && k < max_rows; k++) {
+            int ab = e.wi[e.wo.kab + k], a = ab & 0xFF, b = ab >> 8;
+            double *o = out + 11 * k;
+            o[0] = a; o[1] = b; o[2] = e.wr[e.wo.knx + k]; o[3] = e.wr[e.wo.kny + k];
+            o[4] = (double)e.wp[e.wo.px + a] + e.wr[e.wo.kr1x + k]; o[5] = (double)e.wp[e.wo.py + a] + e.wr[e.wo.kr1y + k];
+            o[6] = (double)e.wp[e.wo.px + b] + e.wr[e.wo.kr2x + k]; o[7] = (double)e.wp[e.wo.py + b] + e.wr[e.wo.kr2y + k];
+            o[8] = e.wr[e.wo.kjn + k]; o[9] = e.wr[e.wo.kjt + k]; o[10] = e.wi[e.wo.kfirst + k];
+        }
+        return nk;
+    }
+};
+
+struct EmuHandle { World world; EmuBase *emu[3] = {nullptr, nullptr, nullptr}; };   // 0: f32/f32, 1: f32 + f64 poses, 2: f64
+
+extern "C" {
+void *emu_world_new() { return new EmuHandle(); }
+void emu_free(void *p) { EmuHandle *h = (EmuHandle *)p; for (auto *e : h->emu) delete e; delete h; }
+void emu_add_robot(void *p, double x, double y, double a) { EntityDef e{}; e.kind = 0; e.x = x; e.y = y; e.angle = a; ((EmuHandle *)p)->world.entities.push_back(e); }
+void emu_add_shape(void *p, int st, int col, double x, double y, double a) { EntityDef e{}; e.kind = 1; e.shape_type = st; e.colour = col; e.x = x; e.y = y; e.angle = a; ((EmuHandle *)p)->world.entities.push_back(e); }
+void emu_add_goal(void *p, double x, double y, double hh, double ww, int col) { EntityDef e{}; e.kind = 2; e.x = x; e.y = y; e.h = hh; e.w = ww; e.colour = col; ((EmuHandle *)p)->world.entities.push_back(e); }
+int emu_finalize(void *p, int max_steps, int n_envs) {
+    EmuHandle *h = (EmuHandle *)p; std::string err;
+    int rc = h->world.finalize(max_steps, err);
+    if (rc) return rc;
+    h->emu[0] = new Emu<float, float>(h->world, n_envs);
+    h->emu[1] = new Emu<float, double>(h->world, n_envs);
+    h->emu[2] = new Emu<double, double>(h->world, n_envs);
+    return 0;
+}
+int emu_rows(void *p, int which) {
+    const TmplHeader &h = ((EmuHandle *)p)->emu[0]->h;
+    return which == 0 ? state_rows_p(h) : (which == 1 ? state_rows_f(h) : state_rows_i(h));
+}
+int emu_n_state(void *p) { return ((EmuHandle *)p)->emu[0]->h.n_state; }
+int emu_state_row(void *p, int row) { EmuHandle *h = (EmuHandle *)p; TmplOff o(h->emu[0]->h); return h->emu[0]->ti[o.state_map + row]; }
+int emu_n_bodies(void *p) { return ((EmuHandle *)p)->emu[0]->h.n_bodies; }
+int emu_contacts(void *p, int mode, double *out, int max_rows) { return ((EmuHandle *)p)->emu[mode]->contacts(out, max_rows); }
+void emu_reset(void *p, int mode, void *sp, void *sf, int32_t *si, const uint8_t *mask) { ((EmuHandle *)p)->emu[mode]->reset(sp, sf, si, mask); }
+void emu_run(void *p, int mode, void *sp, void *sf, int32_t *si, const int32_t *actions, int n_sub, int nl, int count_step, uint8_t *done) {
+    ((EmuHandle *)p)->emu[mode]->run(sp, sf, si, actions, n_sub, nl, count_step != 0, done);
+}
+}

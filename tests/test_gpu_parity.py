@@ -1,0 +1,239 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle.
+
+Run on the MI355X box with `pytest -m gpu`.  Tolerances are stated per test; see DESIGN.md for
+why free-running pose parity is only meaningful over short horizons (the reference dynamics
+amplify 1e-16 perturbations to 1e-3 within ~20 env-steps).
+"""
+import numpy as np
+import pytest
+
+from tests.util import TASKS, comparable_mask, new_ref, ref_body_index
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(name, n, **kw):
+    import magical_amd
+    return magical_amd.make(name, n_envs=n, device='cuda:0', **kw)
+
+
+def _tape(seed, t, n):
+    return np.random.RandomState(seed).randint(0, 18, size=(t, n)).astype(np.int32)
+
+
+def test_native_library_is_loaded():
+    import torch
+    from magical_amd import _native
+    assert torch.cuda.is_available()
+    L = _native.lib()
+    assert L.mgx_version() == 1
+    env = _make('MoveToCorner-Demo-v0', 64)
+    assert env.lanes_per_env in (4, 8, 16, 32, 64)
+    env.close()
+
+
+@pytest.mark.parametrize('task', TASKS)
+def test_f64_engine_tracks_oracle(task):
+    """All-fp64 build, free running from reset: identical algorithm => agreement to round-off for the first
+    env-steps (before the dynamics' own chaos amplifies 1e-16 differences)."""
+    n, t = 8, 6
+    tape = _tape(3, t, n)
+    env = _make(f'{task}-Demo-v0', n, dtype='f64')
+    env.reset()
+    refs = [new_ref(task) for _ in range(n)]
+    idx, mask = ref_body_index(refs[0]), comparable_mask(refs[0])
+    for s in range(t):
+        env.step(tape[s])
+        got = env.get_bodies()[:, 1:, :3]
+        for k, r in enumerate(refs):
+            r.step(tape[s, k])
+            want = r.bodies()[idx][:, :3]
+            assert np.abs(got[k] - want)[mask].max() < 1e-9, (task, s, k)
+    env.close()
+
+
+@pytest.mark.parametrize('task', ['MoveToCorner', 'ClusterColour', 'FindDupe'])
+def test_f32_engine_one_step_error(task):
+    """Shipped precision (fp32 velocities/impulses, fp64 poses): starting each env-step from the oracle's
+    body state, the pose error after one full env-step (10 substeps) is <= 2e-4 worst case, ~1e-7 typical."""
+    n, t = 32, 40
+    tape = _tape(5, t, n)
+    env = _make(f'{task}-Demo-v0', n)
+    env.reset()
+    refs = [new_ref(task) for _ in range(n)]
+    idx, mask = ref_body_index(refs[0]), comparable_mask(refs[0])
+    errs = []
+    for s in range(t):
+        b = env.get_bodies()
+        for k, r in enumerate(refs):
+            b[k, 1:, :] = r.bodies()[idx]
+        env.set_bodies(b)
+        env.step(tape[s])
+        got = env.get_bodies()[:, 1:, :3]
+        for k, r in enumerate(refs):
+            r.step(tape[s, k])
+            errs.append(np.abs(got[k] - r.bodies()[idx][:, :3])[mask].max())
+    errs = np.array(errs)
+    print(f'{task}: one-step pose error median {np.median(errs):.2e} p99 {np.percentile(errs, 99):.2e} max {errs.max():.2e}')
+    assert np.median(errs) < 1e-6
+    assert errs.max() < 2e-4
+    env.close()
+
+
+def test_f32_free_running_drift_report():
+    """Free-running drift of the shipped engine vs the oracle on MoveToCorner (BASELINE.json asks for <1e-3
+    'over 200 steps'; the oracle itself moves by 4e-4 after ONE env-step under a 1e-13 perturbation, so this
+    is reported, with a loose gate)."""
+    n, t = 64, 20
+    tape = _tape(7, t, n)
+    env = _make('MoveToCorner-Demo-v0', n)
+    env.reset()
+    refs = [new_ref('MoveToCorner') for _ in range(n)]
+    idx, mask = ref_body_index(refs[0]), comparable_mask(refs[0])
+    drift = np.zeros((t, n))
+    for s in range(t):
+        env.step(tape[s])
+        got = env.get_bodies()[:, 1:, :3]
+        for k, r in enumerate(refs):
+            r.step(tape[s, k])
+            drift[s, k] = np.abs(got[k] - r.bodies()[idx][:, :3])[mask].max()
+    for s in (0, 1, 4, 9, 19):
+        print(f'env-step {s + 1:3d} (substep {10 * (s + 1)}): drift median {np.median(drift[s]):.2e} max {drift[s].max():.2e}')
+    assert np.median(drift[0]) < 1e-5
+    assert np.median(drift[19]) < 5e-2
+    env.close()
+
+
+def test_determinism_and_lockstep():
+    """Same tape twice -> identical bytes; identical per-env tapes -> identical envs."""
+    import torch
+    n, t = 256, 25
+    tape = np.repeat(_tape(11, t, 1), n, axis=1)
+    outs = []
+    for _ in range(2):
+        env = _make('ClusterColour-Demo-v0', n)
+        env.reset()
+        for s in range(t):
+            env.step(tape[s])
+        outs.append((env.state_p.cpu().clone(), env.state_f.cpu().clone(), env.state_i.cpu().clone()))
+        env.close()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    sp = outs[0][0]
+    assert torch.equal(sp, sp[:, :1].expand_as(sp))
+
+
+@pytest.mark.parametrize('task', TASKS)
+def test_render_matches_oracle_bit_exact(task):
+    """96x96 ego frames (and the 384x384 native views) of the HIP rasteriser equal the oracle's on the same poses."""
+    import torch
+    n, t = 4, 12
+    tape = _tape(13, t, n)
+    env = _make(f'{task}-Demo-v0', n, dtype='f64')
+    env.reset()
+    refs = [new_ref(task) for _ in range(n)]
+    frame = torch.zeros((n, 96, 96, 3), dtype=torch.uint8, device='cuda:0')
+    for s in range(t):
+        env.step(tape[s])
+        for k, r in enumerate(refs):
+            r.step(tape[s, k])
+    # put the oracle's poses into the engine so both rasterise the same state
+    b = env.get_bodies()
+    idx = ref_body_index(refs[0])
+    for k, r in enumerate(refs):
+        b[k, 1:, :] = r.bodies()[idx]
+    env.set_bodies(b)
+    for view in ('ego', 'allo'):
+        env.render_frames(frame, view=view, layout='frame')
+        got = frame.cpu().numpy()
+        for k, r in enumerate(refs):
+            want = r.render_lores(view)
+            diff = np.abs(got[k].astype(int) - want.astype(int))
+            assert diff.max() == 0, (task, view, k, int((diff > 0).sum()), int(diff.max()))
+    native = env.render(env=1)
+    assert np.array_equal(native['ego'], refs[1].render('ego'))
+    assert np.array_equal(native['allo'], refs[1].render('allo'))
+    env.close()
+
+
+def test_lores4e_stack_and_autoreset():
+    """FlattenFrameStack semantics on device: reset fills 4 copies, step shifts by one frame, auto-reset refills;
+    compared with the oracle's LoRes4E pipeline for the first steps."""
+    from oracle.env_ref import LoRes4ERef, RefEnv
+    n = 3
+    env = _make('MoveToCorner-Demo-LoRes4E-v0', n, dtype='f64', max_episode_steps=5)
+    obs = env.reset().cpu().numpy()
+    refs = [LoRes4ERef(RefEnv('MoveToCorner', max_episode_steps=5)) for _ in range(n)]
+    ref_obs = [r.reset() for r in refs]
+    assert obs.shape == (n, 96, 96, 12)
+    for k in range(n):
+        assert np.array_equal(obs[k], ref_obs[k])
+    tape = _tape(17, 5, n)
+    for s in range(5):
+        obs, rew, done, info = env.step(tape[s])
+        obs = obs.cpu().numpy()
+        for k, r in enumerate(refs):
+            o, _, d, inf = r.step(tape[s, k])
+            assert d == done[k]
+            if not d:
+                assert np.array_equal(obs[k], o), (s, k)
+            else:
+                assert inf['eval_score'] == info['eval_score'][k]
+    assert done.all()
+    # after auto-reset the stack holds 4 copies of the first frame of the new episode
+    for k in range(n):
+        assert np.array_equal(obs[k], ref_obs[k])
+    assert float(rew.sum()) == 0.0
+    env.close()
+
+
+@pytest.mark.parametrize('task', TASKS)
+def test_scores_bit_exact_on_engine_poses(task):
+    """score_on_end_of_traj(): the product's batched host scoring equals the oracle's per-env restatement,
+    bit for bit, on the poses the engine produced."""
+    n = 16
+    env = _make(f'{task}-Demo-v0', n)
+    env.reset()
+    t = env.max_episode_steps
+    tape = _tape(19, t, n)
+    ref = new_ref(task)
+    idx = ref_body_index(ref)
+    env.auto_reset = False
+    for s in range(t):
+        obs, rew, done, info = env.step(tape[s])
+    assert done.all()
+    poses = env.get_poses()
+    for k in range(n):
+        b = ref.bodies()
+        b[idx, :3] = poses[k, 1:, :]
+        ref.set_bodies(b)
+        assert float(ref.task.score_on_end_of_traj()) == info['eval_score'][k], (task, k)
+    env.close()
+
+
+def test_full_size_properties_4096():
+    """BASELINE.json size: 4096 envs.  Size-independent properties: per-env tapes replicated in blocks give
+    replicated states; walls contain every body; episode counters and auto-reset line up."""
+    import torch
+    n, t = 4096, 85
+    base = _tape(23, t, 64)
+    tape = np.tile(base, (1, n // 64))
+    env = _make('MoveToCorner-Demo-LoRes4E-v0', n)
+    obs = env.reset()
+    first = obs.clone()
+    n_done = 0
+    for s in range(t):
+        obs, rew, done, info = env.step(tape[s])
+        n_done += int(done.sum())
+        if s == 79:
+            assert done.all() and (info['eval_score'] >= 0).all() and (info['eval_score'] <= 1).all()
+            assert torch.equal(obs, first)          # auto-reset: first observation of the next episode
+        else:
+            assert not done.any()
+    assert n_done == n
+    sp = env.state_p.cpu()
+    assert torch.equal(sp[:, :64], sp[:, 64:128]) and torch.equal(sp[:, :64], sp[:, -64:])
+    poses = env.get_poses()
+    assert np.all(np.abs(poses[:, 1:, :2]) < 1.2)
+    assert int(env.state_i[2].sum()) == 0           # no contact-cache / overlap-list overflow
+    env.close()
