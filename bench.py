@@ -52,7 +52,18 @@ def cpu_baseline(seconds=12.0):
     env per process, random actions, physics + 384x384 ego render + 4-frame stack + INTER_AREA, like
     misc/benchmark_env_perf.py:12-18 drives the reference."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    # cores this process may actually use (the GPU box exposes 256 logical CPUs; affinity/cgroups can be narrower)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:   # cgroup v2 CPU quota ("max" or "<quota> <period>")
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    cores = min(cores, 64)
     ctx = mp.get_context('spawn')
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(1000 + k, seconds) for k in range(cores)])

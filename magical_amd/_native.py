@@ -53,6 +53,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own ROCm runtime; it must be in the process before ours resolves libamdhip64, or the
+    # two HIP runtimes fight over the device ("no HIP device visible")
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise MgxError(f'{LIB_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py`); '
                        'magical_amd has no CPU fallback')

@@ -301,7 +301,11 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
         RasterOff ro(e->h);
         e->rdev.words = e->d_raster; e->rdev.n_words = total; e->rdev.off_i = off_i; e->rdev.off_q = off_q;
         e->rdev.lds_tmpl_words = total; e->rdev.scratch_d = ro.n_d; e->rdev.bg_rgb = BG_RGB;
-        e->lds_raster = (size_t)(total + 2 * ro.n_d + ro.n_i) * 4;
+        int off_tiles = even(2 * ro.n_d + ro.n_i);
+        e->rdev.off_tiles = off_tiles;
+        // per-tile (u64 mask + i32 base) + queue (u64 mask + 2 x i32) + counter
+        int extra = N_TILES * 3 + QCAP * 4 + 2;
+        e->lds_raster = (size_t)(total + off_tiles + extra) * 4;
     }
     *out = e;
     return MGX_OK;

@@ -18,13 +18,13 @@ namespace mgx {
 
 constexpr int NATIVE_RES = 384;   // benchmarks/__init__.py:23 DEFAULT_RES
 constexpr int LORES = 96;         // LoRes* preprocessors
-constexpr double BLOCK_HALF_DIAG = 2.1213203435596424 + 1e-9;   // 1.5*sqrt(2): 4x4 sample block half diagonal
 constexpr double CLASS_EPS = 1e-9;
 
 // per-env raster scratch (LDS on device)
 struct RasterOff {
     int bx, by, ba, bc, bs;             // per body pose (doubles)
-    int svx, svy, ea, eb, ec;           // per prim vertex: screen position + edge function of edge (i -> i+1)
+    int svx, svy, ea, eb, ec;           // per prim vertex: screen position + normalised edge function of edge (i -> i+1)
+    int elen, earc;                     // line loops: segment length and arclength at the segment start
     int pcx, pcy, prad, papo, pphi;     // per prim (n-gon centre/radius/apothem/phase; line half width in prad)
     int n_d;
     int bb;                             // per prim bbox in 384-grid units: x0 y0 x1 y1 (ints, inclusive, may be empty)
@@ -33,6 +33,7 @@ struct RasterOff {
         int o = 0;
         bx = o; o += h.n_bodies; by = o; o += h.n_bodies; ba = o; o += h.n_bodies; bc = o; o += h.n_bodies; bs = o; o += h.n_bodies;
         svx = o; o += h.n_pverts; svy = o; o += h.n_pverts; ea = o; o += h.n_pverts; eb = o; o += h.n_pverts; ec = o; o += h.n_pverts;
+        elen = o; o += h.n_pverts; earc = o; o += h.n_pverts;
         pcx = o; o += h.n_prims; pcy = o; o += h.n_prims; prad = o; o += h.n_prims; papo = o; o += h.n_prims; pphi = o; o += h.n_prims;
         n_d = o;
         o = 0;
@@ -153,19 +154,27 @@ MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl) {
         if (kind == PR_LINELOOP) { RD(prad, k) = rs.prim_r(k, 4); pad = rs.prim_r(k, 4) + 1.0; }
         RI(bb, 4 * k) = (int)rz_floor(minx - pad - 0.5); RI(bb, 4 * k + 1) = (int)rz_floor(miny - pad - 0.5);
         RI(bb, 4 * k + 2) = (int)ceil(maxx + pad - 0.5); RI(bb, 4 * k + 3) = (int)ceil(maxy + pad - 0.5);
-        if (kind == PR_POLY) {
-            double area2 = 0.0;
-            for (int i = 0; i < nv; i++) {
-                int j = (i + 1) % nv;
-                area2 += RD(svx, vo + i) * RD(svy, vo + j) - RD(svy, vo + i) * RD(svx, vo + j);
+        {
+            // normalised edge functions E(p) = sgn * cross(e, p - a) / |e|: >= 0 inside a polygon; for a line
+            // loop |E| is the distance to the segment's carrier line and (eb, -ea) is its unit direction
+            double sgn = 1.0;
+            if (kind == PR_POLY) {
+                double area2 = 0.0;
+                for (int i = 0; i < nv; i++) {
+                    int j = (i + 1) % nv;
+                    area2 += RD(svx, vo + i) * RD(svy, vo + j) - RD(svy, vo + i) * RD(svx, vo + j);
+                }
+                sgn = area2 >= 0.0 ? 1.0 : -1.0;
             }
-            double sgn = area2 >= 0.0 ? 1.0 : -1.0;
+            double arc = 0.0;
             for (int i = 0; i < nv; i++) {
                 int j = (i + 1) % nv;
                 double ax = RD(svx, vo + i), ay = RD(svy, vo + i), ex = RD(svx, vo + j) - ax, ey = RD(svy, vo + j) - ay;
-                double inv = sgn / sqrt(ex * ex + ey * ey);
-                // E(p) = sgn * cross(e, p - a) / |e|   (>= 0 inside)
+                double len = sqrt(ex * ex + ey * ey);
+                double inv = sgn / len;
                 RD(ea, vo + i) = -ey * inv; RD(eb, vo + i) = ex * inv; RD(ec, vo + i) = (ey * ax - ex * ay) * inv;
+                RD(elen, vo + i) = len; RD(earc, vo + i) = arc;
+                arc += len;
             }
         }
     }
@@ -196,22 +205,20 @@ MGX_HD bool ngon_contains(const Raster &rs, int k, double x, double y) {
 // alpha = clamp(halfwidth - dist, 0, 1), halfwidth = (w + 1) / 2, 16-px stipple by arclength.
 MGX_HD double lineloop_alpha(const Raster &rs, int k, double x, double y) {
     int nv = rs.prim_nv(k), vo = rs.prim_voff(k), stipple = rs.prim_stipple(k);
-    double hw = RD(prad, k), best = 0.0, arc = 0.0;
+    double hw = RD(prad, k), best = 0.0;
     for (int i = 0; i < nv; i++) {
-        int j = (i + 1) % nv;
-        double ax = RD(svx, vo + i), ay = RD(svy, vo + i), dx = RD(svx, vo + j) - ax, dy = RD(svy, vo + j) - ay;
-        double l2 = dx * dx + dy * dy;
-        double t = l2 > 0.0 ? r_clamp01(((x - ax) * dx + (y - ay) * dy) / l2) : 0.0;
-        double ex = x - (ax + dx * t), ey = y - (ay + dy * t);
-        double dist = sqrt(ex * ex + ey * ey);
-        double alpha = r_clamp01(hw - dist);
-        double len = sqrt(l2);
+        double a = RD(ea, vo + i), b = RD(eb, vo + i);
+        double e = a * x + b * y + RD(ec, vo + i);
+        if (r_abs(e) >= hw) continue;                       // distance to the segment >= distance to its line
+        double ax = RD(svx, vo + i), ay = RD(svy, vo + i), len = RD(elen, vo + i);
+        double sl = r_clamp((x - ax) * b - (y - ay) * a, 0.0, len);   // arclength of the closest point
+        double qx = x - (ax + b * sl), qy = y - (ay - a * sl);
+        double alpha = r_clamp01(hw - sqrt(qx * qx + qy * qy));
         if (alpha > 0.0 && stipple) {
-            int bit = ((int)rz_floor(arc + t * len)) & 15;
+            int bit = ((int)rz_floor(RD(earc, vo + i) + sl)) & 15;
             if (!((stipple >> bit) & 1)) alpha = 0.0;
         }
         if (alpha > best) best = alpha;
-        arc += len;
     }
     return best;
 }
@@ -239,67 +246,268 @@ MGX_HD int raster_sample(const Raster &rs, double x, double y, uint64_t mask, in
 }
 
 enum { CLS_NONE = 0, CLS_ALL = 1, CLS_MIXED = 2 };
-// classify prim k against the 4x4 sample block centred at (xc, yc)
-MGX_HD int classify_block(const Raster &rs, int k, double xc, double yc) {
+// Classify prim k against the block of 384-grid samples centred at (xc, yc) with half extents (hx, hy)
+// (sample centres, so a 4x4 block has hx = hy = 1.5): ALL = every sample inside an opaque prim, NONE = no
+// sample touched, MIXED = decide per sample.  Division- and sqrt-free; conservative by CLASS_EPS.
+MGX_HD int classify_rect(const Raster &rs, int k, double xc, double yc, double hx, double hy) {
     int kind = rs.prim_kind(k);
     if (kind == PR_POLY) {
         int nv = rs.prim_nv(k), vo = rs.prim_voff(k);
         bool all = true;
         for (int i = 0; i < nv; i++) {
             double a = RD(ea, vo + i), b = RD(eb, vo + i);
-            double ec = a * xc + b * yc + RD(ec, vo + i);
-            double ext = 1.5 * (r_abs(a) + r_abs(b)) + CLASS_EPS;
-            if (ec + ext < 0.0) return CLS_NONE;
-            if (ec - ext < 0.0) all = false;
+            double e = a * xc + b * yc + RD(ec, vo + i);
+            double ext = hx * r_abs(a) + hy * r_abs(b) + CLASS_EPS;
+            if (e + ext < 0.0) return CLS_NONE;
+            if (e - ext < 0.0) all = false;
         }
         return all ? CLS_ALL : CLS_MIXED;
     } else if (kind == PR_NGON) {
-        double qx = xc - RD(pcx, k), qy = yc - RD(pcy, k);
-        double dc = sqrt(qx * qx + qy * qy);
-        if (dc + BLOCK_HALF_DIAG < RD(papo, k) - CLASS_EPS) return CLS_ALL;
-        if (dc - BLOCK_HALF_DIAG > RD(prad, k) + CLASS_EPS) return CLS_NONE;
+        double qx = r_abs(xc - RD(pcx, k)), qy = r_abs(yc - RD(pcy, k));
+        double nx = r_max(qx - hx, 0.0), ny = r_max(qy - hy, 0.0);          // nearest point of the rect
+        double fx = qx + hx, fy = qy + hy;                                    // farthest corner
+        double apo = RD(papo, k) - CLASS_EPS, rad = RD(prad, k) + CLASS_EPS;
+        if (fx * fx + fy * fy < apo * apo) return CLS_ALL;
+        if (nx * nx + ny * ny > rad * rad) return CLS_NONE;
         return CLS_MIXED;
     } else {
         int nv = rs.prim_nv(k), vo = rs.prim_voff(k);
-        double hw = RD(prad, k);
+        double hw = RD(prad, k) + CLASS_EPS;
         for (int i = 0; i < nv; i++) {
-            int j = (i + 1) % nv;
-            double ax = RD(svx, vo + i), ay = RD(svy, vo + i), dx = RD(svx, vo + j) - ax, dy = RD(svy, vo + j) - ay;
-            double l2 = dx * dx + dy * dy;
-            double t = l2 > 0.0 ? r_clamp01(((xc - ax) * dx + (yc - ay) * dy) / l2) : 0.0;
-            double ex = xc - (ax + dx * t), ey = yc - (ay + dy * t);
-            if (sqrt(ex * ex + ey * ey) - BLOCK_HALF_DIAG <= hw + CLASS_EPS) return CLS_MIXED;
+            double a = RD(ea, vo + i), b = RD(eb, vo + i);
+            double e = a * xc + b * yc + RD(ec, vo + i);
+            if (r_abs(e) - (hx * r_abs(a) + hy * r_abs(b)) > hw) continue;       // off the carrier line
+            double sl = (xc - RD(svx, vo + i)) * b - (yc - RD(svy, vo + i)) * a;  // along the segment
+            double es = hx * r_abs(b) + hy * r_abs(a);
+            if (sl + es < -hw || sl - es > RD(elen, vo + i) + hw) continue;       // beyond its ends
+            return CLS_MIXED;
         }
         return CLS_NONE;
     }
 }
 
-// one 96x96 output pixel (X, Y), Y = 0 at the top; `tile_mask`: prims whose bbox touches the tile
-MGX_HD int raster_pixel_lores(const Raster &rs, int X, int Y, uint64_t tile_mask, int bg_rgb) {
+constexpr int TILE_W = 16, TILE_H = 4, TILES_X = LORES / TILE_W, TILES_Y = LORES / TILE_H;
+
+// tile (tcol, trow) of 16x4 output pixels = 64x16 samples: class of prim k for the whole tile
+MGX_HD int classify_tile(const Raster &rs, int k, int tcol, int trow) {
+    const int gx0 = 4 * TILE_W * tcol, gx1 = gx0 + 4 * TILE_W - 1;
+    const int gy1 = NATIVE_RES - 1 - 4 * TILE_H * trow, gy0 = gy1 - 4 * TILE_H + 1;
+    if (RI(bb, 4 * k) > gx1 || RI(bb, 4 * k + 2) < gx0 || RI(bb, 4 * k + 1) > gy1 || RI(bb, 4 * k + 3) < gy0) return CLS_NONE;
+    return classify_rect(rs, k, 0.5 * (gx0 + gx1 + 1), 0.5 * (gy0 + gy1 + 1), 2.0 * TILE_W - 0.5, 2.0 * TILE_H - 0.5);
+}
+// combine the per-prim tile classes (as bit masks) into the tile's base colour and its set of undecided prims
+MGX_HD void tile_resolve(const Raster &rs, uint64_t all_mask, uint64_t &mixed_mask, int &base_rgb) {
+    if (all_mask) {
+        int ka = 63 - __builtin_clzll(all_mask);
+        base_rgb = rs.prim_rgb(ka);
+        mixed_mask &= ~((2ull << ka) - 1ull);       // everything at or below the topmost covering prim is hidden
+    }
+}
+
+// 16-bit coverage of the 4x4 sample block whose top-left sample is (x0, y0) (bit 4*j + i = sample (x0 + i, y0 - j))
+MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, double x0, double y0) {
+    int nv = rs.prim_nv(k), vo = rs.prim_voff(k);
+    uint32_t cov = 0xFFFFu;
+    for (int e = 0; e < nv && cov; e++) {
+        double a = RD(ea, vo + e), b = RD(eb, vo + e);
+        double row = a * x0 + b * y0 + RD(ec, vo + e);
+        // the block spans x0..x0+3, y0-3..y0: if even its worst corner is inside this edge, nothing to test
+        double worst = row + r_min(0.0, 3.0 * a) - r_max(0.0, 3.0 * b);
+        if (worst >= CLASS_EPS) continue;
+        uint32_t m = 0;
+        for (int j = 0; j < 4; j++) {
+            double v = row;
+            for (int i = 0; i < 4; i++) { m |= (v >= 0.0 ? 1u : 0u) << (4 * j + i); v += a; }
+            row -= b;
+        }
+        cov &= m;
+    }
+    return cov;
+}
+MGX_HD uint32_t ngon_coverage16(const Raster &rs, int k, double x0, double y0) {
+    double cx = RD(pcx, k), cy = RD(pcy, k);
+    double apo = RD(papo, k) - CLASS_EPS, rad = RD(prad, k) + CLASS_EPS, apo2 = apo * apo, rad2 = rad * rad;
+    uint32_t cov = 0;
+    for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 4; i++) {
+            double qx = x0 + i - cx, qy = y0 - j - cy, d2 = qx * qx + qy * qy;
+            bool in = d2 <= apo2;
+            if (!in && d2 <= rad2) in = ngon_contains(rs, k, x0 + i, y0 - j);     // thin annulus: exact sector test
+            cov |= (in ? 1u : 0u) << (4 * j + i);
+        }
+    return cov;
+}
+
+// max line-loop alpha for the 4 samples (x0 + i, y), i = 0..3: segment parameters are loaded once per row
+MGX_HD void lineloop_alpha_row(const Raster &rs, int k, double x0, double y, uint32_t segmask, double *best) {
+    int nv = rs.prim_nv(k), vo = rs.prim_voff(k), stipple = rs.prim_stipple(k);
+    double hw = RD(prad, k);
+    best[0] = best[1] = best[2] = best[3] = 0.0;
+    for (int i = 0; i < nv; i++) {
+        if (!((segmask >> i) & 1u)) continue;
+        double a = RD(ea, vo + i), b = RD(eb, vo + i);
+        double e0 = a * x0 + b * y + RD(ec, vo + i);
+        // all four samples off this segment's carrier line?  (e is affine in x)
+        double e3 = e0 + 3.0 * a;
+        if ((e0 >= hw && e3 >= hw) || (e0 <= -hw && e3 <= -hw)) continue;
+        double ax = RD(svx, vo + i), ay = RD(svy, vo + i), len = RD(elen, vo + i), arc = RD(earc, vo + i);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int t = 0; t < 4; t++) {
+            double x = x0 + t, e = a * x + b * y + RD(ec, vo + i);
+            if (r_abs(e) >= hw) continue;
+            double sl = r_clamp((x - ax) * b - (y - ay) * a, 0.0, len);
+            double qx = x - (ax + b * sl), qy = y - (ay - a * sl);
+            double alpha = r_clamp01(hw - sqrt(qx * qx + qy * qy));
+            if (alpha > 0.0 && stipple) {
+                int bit = ((int)rz_floor(arc + sl)) & 15;
+                if (!((stipple >> bit) & 1)) alpha = 0.0;
+            }
+            if (alpha > best[t]) best[t] = alpha;
+        }
+    }
+}
+
+// segments of line loop k that can touch the 4x4 block whose top-left sample is (x0, y0)
+MGX_HD uint32_t lineloop_block_segments(const Raster &rs, int k, double x0, double y0) {
+    int nv = rs.prim_nv(k), vo = rs.prim_voff(k);
+    double hw = RD(prad, k) + CLASS_EPS, xc = x0 + 1.5, yc = y0 - 1.5;
+    uint32_t mask = 0;
+    for (int i = 0; i < nv && i < 16; i++) {
+        double a = RD(ea, vo + i), b = RD(eb, vo + i);
+        double e = a * xc + b * yc + RD(ec, vo + i);
+        if (r_abs(e) - 1.5 * (r_abs(a) + r_abs(b)) > hw) continue;
+        double sl = (xc - RD(svx, vo + i)) * b - (yc - RD(svy, vo + i)) * a, es = 1.5 * (r_abs(a) + r_abs(b));
+        if (sl + es < -hw || sl - es > RD(elen, vo + i) + hw) continue;
+        mask |= 1u << i;
+    }
+    return mask;
+}
+
+// Painter's-order resolution of the prims in `lower` (which contains at least one line loop) for the samples in
+// `remaining`, accumulated into (sr, sg, sb).  Opaque prims act through coverage masks, line loops blend row by row.
+MGX_HD void resolve_lower_stack(const Raster &rs, uint64_t lower, double x0, double y0, int base, uint32_t remaining,
+                                int &sr, int &sg, int &sb) {
+    constexpr int MAXL = 6;
+    int lk[MAXL]; uint32_t lcov[MAXL]; int nl = 0;
+    uint64_t m = lower;
+    while (m && nl < MAXL) {
+        int k = __builtin_ctzll(m);
+        m &= m - 1;
+        int kind = rs.prim_kind(k);
+        lk[nl] = k;
+        // line loops: bit 16 marks the kind, bits 0..15 the segments that can touch this block
+        lcov[nl] = kind == PR_POLY ? poly_coverage16(rs, k, x0, y0)
+                 : (kind == PR_NGON ? ngon_coverage16(rs, k, x0, y0) : (0x10000u | lineloop_block_segments(rs, k, x0, y0)));
+        nl++;
+    }
+    if (m) {   // unusually deep translucent stack: plain per-sample painter
+        for (int s = 0; s < 16; s++)
+            if ((remaining >> s) & 1u) {
+                int c = raster_sample(rs, x0 + (s & 3), y0 - (s >> 2), lower, base);
+                sr += c & 0xFF; sg += (c >> 8) & 0xFF; sb += (c >> 16) & 0xFF;
+            }
+        return;
+    }
+    for (int j = 0; j < 4; j++) {
+        uint32_t rm = (remaining >> (4 * j)) & 0xFu;
+        if (!rm) continue;
+        int c[4] = {base, base, base, base};
+        for (int q = 0; q < nl; q++) {
+            if (lcov[q] & 0x10000u) {
+                if (!(lcov[q] & 0xFFFFu)) continue;
+                double best[4];
+                lineloop_alpha_row(rs, lk[q], x0, y0 - j, lcov[q] & 0xFFFFu, best);
+                int col = rs.prim_rgb(lk[q]);
+                double lr = (double)(col & 0xFF), lg = (double)((col >> 8) & 0xFF), lb = (double)((col >> 16) & 0xFF);
+                for (int t = 0; t < 4; t++)
+                    if (best[t] > 0.0) {
+                        double a = best[t];
+                        int r = (int)rz_floor(a * lr + (1.0 - a) * (double)(c[t] & 0xFF) + 0.5);
+                        int g = (int)rz_floor(a * lg + (1.0 - a) * (double)((c[t] >> 8) & 0xFF) + 0.5);
+                        int b = (int)rz_floor(a * lb + (1.0 - a) * (double)((c[t] >> 16) & 0xFF) + 0.5);
+                        c[t] = r | (g << 8) | (b << 16);
+                    }
+            } else {
+                uint32_t cv = (lcov[q] >> (4 * j)) & 0xFu;
+                int col = rs.prim_rgb(lk[q]);
+                for (int t = 0; t < 4; t++) if ((cv >> t) & 1u) c[t] = col;
+            }
+        }
+        for (int t = 0; t < 4; t++)
+            if ((rm >> t) & 1u) { sr += c[t] & 0xFF; sg += (c[t] >> 8) & 0xFF; sb += (c[t] >> 16) & 0xFF; }
+    }
+}
+
+// ---- one 96x96 output pixel (X, Y), Y = 0 at the top, in two steps
+// step 1: classify the tile's undecided prims against this pixel's 4x4 sample block.  Returns the prims still
+// undecided (0 = the pixel is `base`, done) and updates `base` to the colour under them.
+MGX_HD uint64_t pixel_classify(const Raster &rs, int X, int Y, uint64_t tile_mixed, int &base) {
     const double xc = 4.0 * X + 2.0, yc = (double)NATIVE_RES - 4.0 * Y - 2.0;
     const int gx0 = 4 * X, gx1 = 4 * X + 3, gy1 = NATIVE_RES - 1 - 4 * Y, gy0 = gy1 - 3;   // 384-grid index range of the block
-    int base = bg_rgb;
     uint64_t mixed = 0;
-    // front to back: stop at the topmost primitive that covers the whole block
-    uint64_t m = tile_mask;
+    // front to back: stop at the topmost primitive that covers the whole 4x4 block
+    uint64_t m = tile_mixed;
     while (m) {
         int k = 63 - __builtin_clzll(m);
         m &= ~(1ull << k);
         if (RI(bb, 4 * k) > gx1 || RI(bb, 4 * k + 2) < gx0 || RI(bb, 4 * k + 1) > gy1 || RI(bb, 4 * k + 3) < gy0) continue;
-        int cls = classify_block(rs, k, xc, yc);
+        int cls = classify_rect(rs, k, xc, yc, 1.5, 1.5);
         if (cls == CLS_ALL) { base = rs.prim_rgb(k); break; }
         if (cls == CLS_MIXED) mixed |= 1ull << k;
     }
-    if (!mixed) return base;
+    return mixed;
+}
+// step 2: resolve the 16 samples of an undecided pixel.  Opaque prims (front to back) claim samples through
+// coverage masks; once a translucent line loop is reached, the samples still unclaimed are blended per sample.
+MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int base) {
+    const double x0 = 4.0 * X + 0.5, y0 = (double)NATIVE_RES - 0.5 - 4.0 * Y;
+    uint32_t remaining = 0xFFFFu;
     int sr = 0, sg = 0, sb = 0;
-    for (int j = 0; j < 4; j++)
-        for (int i = 0; i < 4; i++) {
-            int c = raster_sample(rs, 4.0 * X + i + 0.5, (double)NATIVE_RES - 0.5 - 4.0 * Y - j, mixed, base);
-            sr += c & 0xFF; sg += (c >> 8) & 0xFF; sb += (c >> 16) & 0xFF;
+    uint64_t m = mixed;
+    while (m && remaining) {
+        int k = 63 - __builtin_clzll(m);
+        m &= ~(1ull << k);
+        int kind = rs.prim_kind(k);
+        if (kind == PR_LINELOOP) {
+            // translucent: everything from here down is blended per sample, for the samples nobody above claimed
+            resolve_lower_stack(rs, mixed & ((2ull << k) - 1ull), x0, y0, base, remaining, sr, sg, sb);
+            remaining = 0;
+            break;
         }
+        uint32_t cov = (kind == PR_POLY ? poly_coverage16(rs, k, x0, y0) : ngon_coverage16(rs, k, x0, y0)) & remaining;
+        if (cov) {
+            int n = __builtin_popcount(cov), col = rs.prim_rgb(k);
+            sr += n * (col & 0xFF); sg += n * ((col >> 8) & 0xFF); sb += n * ((col >> 16) & 0xFF);
+            remaining &= ~cov;
+        }
+    }
+    if (remaining) {
+        int n = __builtin_popcount(remaining);
+        sr += n * (base & 0xFF); sg += n * ((base >> 8) & 0xFF); sb += n * ((base >> 16) & 0xFF);
+    }
     // cv2 INTER_AREA integer-factor path: saturate_cast<uchar>(sum * (1/16)) = round half to even
     int r = (sr + 7 + ((sr >> 4) & 1)) >> 4, g = (sg + 7 + ((sg >> 4) & 1)) >> 4, b = (sb + 7 + ((sb >> 4) & 1)) >> 4;
     return r | (g << 8) | (b << 16);
+}
+MGX_HD int raster_pixel_lores(const Raster &rs, int X, int Y, uint64_t tile_mixed, int base) {
+    uint64_t mixed = pixel_classify(rs, X, Y, tile_mixed, base);
+    return mixed ? pixel_resolve(rs, X, Y, mixed, base) : base;
+}
+
+// whole-tile classification of every prim (one lane per tile): base colour + undecided set
+MGX_HD void classify_tile_all(const Raster &rs, int tile, int bg_rgb, int &base, uint64_t &mixed) {
+    const int tcol = tile % TILES_X, trow = tile / TILES_X;
+    uint64_t all_mask = 0, mixed_mask = 0;
+    for (int k = rs.h->n_prims - 1; k >= 0; k--) {       // front to back: nothing under a covering prim matters
+        int cls = classify_tile(rs, k, tcol, trow);
+        if (cls == CLS_ALL) { all_mask = 1ull << k; break; }
+        if (cls == CLS_MIXED) mixed_mask |= 1ull << k;
+    }
+    base = bg_rgb;
+    tile_resolve(rs, all_mask, mixed_mask, base);
+    mixed = mixed_mask;
 }
 
 }  // namespace mgx

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _SO = os.path.join(_HERE, 'libmgx_emu.so')
 _SRCS = [os.path.join(_HERE, 'mgx_emu.cpp')] + [
-    os.path.join(_ROOT, 'magical_amd', 'csrc', f) for f in ('mgx_world.cpp', 'mgx_world.h', 'mgx_sim.h', 'mgx_tmpl.h')]
+    os.path.join(_ROOT, 'magical_amd', 'csrc', f) for f in ('mgx_world.cpp', 'mgx_world.h', 'mgx_sim.h', 'mgx_tmpl.h', 'mgx_raster.h')]
 
 MODES = {'f32': 0, 'mixed': 1, 'f64': 2}
 
@@ -37,6 +37,7 @@ def lib():
             'emu_finalize': [C.c_void_p, C.c_int, C.c_int], 'emu_rows': [C.c_void_p, C.c_int],
             'emu_n_state': [C.c_void_p], 'emu_state_row': [C.c_void_p, C.c_int], 'emu_n_bodies': [C.c_void_p],
             'emu_contacts': [C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+            'emu_render': [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
             'emu_reset': [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
             'emu_run': [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                         C.c_int, C.c_void_p],
@@ -105,3 +106,9 @@ class EmuBatch:
         buf = np.zeros((max_rows, 11), dtype=np.float64)
         n = self.L.emu_contacts(self.h, self.mode, buf.ctypes.data, max_rows)
         return buf[:n]
+
+    def render(self, env=0, view='ego', native=False):
+        res = 384 if native else 96
+        out = np.zeros((res, res, 3), dtype=np.uint8)
+        self.L.emu_render(self.h, self.mode, self.sp.ctypes.data, env, 0 if view == 'ego' else 1, int(native), out.ctypes.data)
+        return out

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "../../magical_amd/csrc/mgx_raster.h"
 #include "../../magical_amd/csrc/mgx_sim.h"
 #include "../../magical_amd/csrc/mgx_world.h"
 
@@ -79,6 +80,40 @@ template <typename R, typename P> struct Emu : EmuBase {
     }
 };
 
+static long g_stat[8];
+// host emulation of the raster kernel: same setup + per-pixel functions, tiles replaced by a plain loop
+template <typename P>
+static void emu_raster(const World &w, const P *sp, int n_envs, int env, int view, int native, uint8_t *out) {
+    TmplHeader h; std::vector<int32_t> ti; std::vector<double> rw, pw;
+    w.serialise(h, ti, rw, pw);
+    TmplOff o(h); RasterOff ro(h);
+    std::vector<double> d(ro.n_d, 0.0); std::vector<int32_t> iv(ro.n_i, 0);
+    Raster rs(&h, ti.data(), rw.data() + o.prim_r, d.data(), iv.data(), view);
+    const int nl = 7;   // odd lane count on purpose
+    for (int lane = 0; lane < nl; lane++) raster_setup_bodies<P>(rs, sp, (long)n_envs, (long)env, lane, nl);
+    for (int lane = 0; lane < nl; lane++) raster_setup_prims(rs, lane, nl);
+    const int bg = 231 | (231 << 8) | (234 << 16);
+    const uint64_t all = h.n_prims >= 64 ? ~0ull : ((1ull << h.n_prims) - 1ull);
+    if (native) {
+        for (int row = 0; row < NATIVE_RES; row++) for (int col = 0; col < NATIVE_RES; col++) {
+            int c = raster_sample(rs, col + 0.5, (double)(NATIVE_RES - 1 - row) + 0.5, all, bg);
+            uint8_t *q = out + 3 * (row * NATIVE_RES + col); q[0] = c & 0xFF; q[1] = (c >> 8) & 0xFF; q[2] = (c >> 16) & 0xFF;
+        }
+    } else {
+        for (int trow = 0; trow < TILES_Y; trow++) for (int tcol = 0; tcol < TILES_X; tcol++) {
+            int base; uint64_t mixed_mask;
+            classify_tile_all(rs, trow * TILES_X + tcol, bg, base, mixed_mask);
+            g_stat[0]++; if (mixed_mask) { g_stat[1]++; g_stat[2] += __builtin_popcountll(mixed_mask); }
+            for (int ty = 0; ty < TILE_H; ty++) for (int tx = 0; tx < TILE_W; tx++) {
+                int X = tcol * TILE_W + tx, Y = trow * TILE_H + ty;
+                int c = base;
+                if (mixed_mask) { uint64_t pm = pixel_classify(rs, X, Y, mixed_mask, c); g_stat[3]++; if (pm) { g_stat[4]++; c = pixel_resolve(rs, X, Y, pm, c); } }
+                uint8_t *q = out + 3 * (Y * LORES + X); q[0] = c & 0xFF; q[1] = (c >> 8) & 0xFF; q[2] = (c >> 16) & 0xFF;
+            }
+        }
+    }
+}
+
 struct EmuHandle { World world; EmuBase *emu[3] = {nullptr, nullptr, nullptr}; };   // 0: f32/f32, 1: f32 + f64 poses, 2: f64
 
 extern "C" {
@@ -104,6 +139,12 @@ int emu_n_state(void *p) { return ((EmuHandle *)p)->emu[0]->h.n_state; }
 int emu_state_row(void *p, int row) { EmuHandle *h = (EmuHandle *)p; TmplOff o(h->emu[0]->h); return h->emu[0]->ti[o.state_map + row]; }
 int emu_n_bodies(void *p) { return ((EmuHandle *)p)->emu[0]->h.n_bodies; }
 int emu_contacts(void *p, int mode, double *out, int max_rows) { return ((EmuHandle *)p)->emu[mode]->contacts(out, max_rows); }
+void emu_stats(long *out) { for (int i = 0; i < 8; i++) { out[i] = g_stat[i]; g_stat[i] = 0; } }
+void emu_render(void *p, int mode, const void *sp, int env, int view, int native, uint8_t *out) {
+    EmuHandle *h = (EmuHandle *)p;
+    if (mode == 0) emu_raster<float>(h->world, (const float *)sp, h->emu[0]->n_envs, env, view, native, out);
+    else emu_raster<double>(h->world, (const double *)sp, h->emu[0]->n_envs, env, view, native, out);
+}
 void emu_reset(void *p, int mode, void *sp, void *sf, int32_t *si, const uint8_t *mask) { ((EmuHandle *)p)->emu[mode]->reset(sp, sf, si, mask); }
 void emu_run(void *p, int mode, void *sp, void *sf, int32_t *si, const int32_t *actions, int n_sub, int nl, int count_step, uint8_t *done) {
     ((EmuHandle *)p)->emu[mode]->run(sp, sf, si, actions, n_sub, nl, count_step != 0, done);

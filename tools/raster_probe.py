@@ -1,0 +1,33 @@
+"""GPU probe: k_raster launch time vs state / layout / view (development tool)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import magical_amd
+
+def timeit(env, out, view, layout, fill=None, n=20):
+    for _ in range(3):
+        env.render_frames(out, view=view, layout=layout, fill_mask=fill)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        env.render_frames(out, view=view, layout=layout, fill_mask=fill)
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+
+task = sys.argv[1] if len(sys.argv) > 1 else 'MoveToCorner-Demo-v0'
+N = 4096
+env = magical_amd.make(task, n_envs=N, device='cuda:0')
+env.reset()
+frame = torch.zeros((N, 96, 96, 3), dtype=torch.uint8, device='cuda:0')
+stack = torch.zeros((N, 96, 96, 12), dtype=torch.uint8, device='cuda:0')
+ones = torch.ones(N, dtype=torch.uint8, device='cuda:0')
+print('reset state: ego frame %.3f ms, ego stack4 %.3f ms, ego stack4(fill) %.3f, allo frame %.3f ms' % (
+    timeit(env, frame, 'ego', 'frame'), timeit(env, stack, 'ego', 'stack4'), timeit(env, stack, 'ego', 'stack4', ones), timeit(env, frame, 'allo', 'frame')))
+tape = torch.as_tensor(np.random.RandomState(0).randint(0, 18, size=(60, N)).astype(np.int32), device='cuda:0')
+for s in range(60):
+    env.step(tape[s])
+    if s in (0, 4, 19, 59):
+        print('after %d steps: ego frame %.3f ms, ego stack4 %.3f ms, allo frame %.3f ms' % (
+            s + 1, timeit(env, frame, 'ego', 'frame'), timeit(env, stack, 'ego', 'stack4'), timeit(env, frame, 'allo', 'frame')))
+# copy bandwidth reference
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20): stack.copy_(stack + 0)
+torch.cuda.synchronize(); print('torch read+write of the stack tensor x2: %.3f ms' % ((time.perf_counter() - t0) / 20 * 1e3))
