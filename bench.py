@@ -88,12 +88,8 @@ def main():
 
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world)      # "nccl" == RCCL on ROCm
+    from magical_amd.distributed import gather_rollout_results, init_from_env
+    rank, world, local_rank = init_from_env(backend='nccl')      # "nccl" == RCCL on ROCm
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
@@ -113,7 +109,7 @@ def main():
         torch.cuda.synchronize()
 
     env.set_timing(True)
-    score_sum = torch.zeros(1, dtype=torch.float64, device=device)
+    last_score = torch.zeros(n, dtype=torch.float64, device=device)      # per-env result of the rollout
     n_eps = 0
     barrier()
     t0 = time.perf_counter()
@@ -121,12 +117,10 @@ def main():
         obs, rew, done, info = env.step(tape[s])
         if done.any():
             n_eps += int(done.sum())
-            score_sum += float(info['eval_score'][done].sum())
-    if world > 1:
-        # end-of-rollout gather over xGMI (RCCL): per-rank score sums; observations never leave their GPU
-        gathered = torch.zeros(world, dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(gathered, score_sum)
-        score_sum = gathered.sum(dim=0, keepdim=True)
+            idx = torch.as_tensor(np.nonzero(done)[0], device=device)
+            last_score[idx] = torch.as_tensor(info['eval_score'][done], device=device)
+    # end-of-rollout gather over xGMI (RCCL): per-env scores of every rank; observations never leave their GPU
+    all_scores = gather_rollout_results(last_score, n * world)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -158,7 +152,7 @@ def main():
             'config': {'workload': f'{args.task}, {n} envs per GPU, random actions, auto-reset every {env.max_episode_steps} steps, '
                                    'obs u8[N,96,96,12] (4 ego frames, oldest first)',
                        'n_envs_per_gpu': n, 'lanes_per_env': env.lanes_per_env, 'episodes_finished': n_eps * world,
-                       'mean_eval_score': float(score_sum.item()) / max(n_eps * world, 1),
+                       'mean_eval_score': float(all_scores.mean().item()),
                        'arith': 'fp32 velocities/impulses/contacts + fp64 poses; fp64 rasteriser' if args.dtype == 'f32' else args.dtype},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': None,

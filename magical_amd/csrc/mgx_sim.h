@@ -421,6 +421,7 @@ template <typename R, typename P> MGX_HD void ph_arbiters_joints(Env<R, P> &e, i
     for (int q = lane; q < nov; q += nl) {
         for (; scanned < q; scanned++) { int c = E_I(mcnt, scanned); if (c > 0 && koff + c <= kcap && rank < ccap) { koff += c; rank++; } }
         int cnt = E_I(mcnt, q);
+        scanned = q + 1;                                      // this entry is accounted for right below
         if (cnt == 0) continue;
         if (koff + cnt > kcap || rank >= ccap) continue;     // dropped: counted by lane 0 below
         int p = E_I(ov, q), pr = T_I(pair, p), sa = pr & 0xFF, sb = pr >> 8;

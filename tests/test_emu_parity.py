@@ -1,0 +1,133 @@
+"""CPU checks of the KERNEL LOGIC: magical_amd/csrc/mgx_sim.h + mgx_raster.h compiled for the host
+(tests/emu, a test harness that the product never loads) against the oracle.  These run without a GPU and
+catch algorithmic mismatches (SAT narrowphase vs GJK/EPA, contact cache, joint solver, rasteriser
+classification) before GPU time is spent; the real parity tests through the C ABI are in test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+from tests.emu.emu import EmuBatch
+from tests.util import TASKS, comparable_mask, new_ref, ref_body_index, ref_entities_as_tuples
+
+
+def _pair(task, mode, n=1):
+    ref = new_ref(task)
+    em = EmuBatch(ref_entities_as_tuples(ref), ref.max_episode_steps, n, mode=mode)
+    em.reset()
+    return ref, em
+
+
+@pytest.mark.parametrize('task', TASKS)
+def test_reset_state_matches_oracle(task):
+    ref, em = _pair(task, 'f64')
+    idx, mask = ref_body_index(ref), comparable_mask(ref)
+    got = em.bodies()[0, 1:, :3]
+    want = ref.bodies()[idx][:, :3]
+    assert np.array_equal(got[mask], want[mask])          # bit-identical initial poses (incl. finger roots)
+    assert np.all(em.bodies()[0, :, 3:] == 0)
+
+
+@pytest.mark.parametrize('task', TASKS)
+@pytest.mark.parametrize('nl', [1, 4, 16])
+def test_f64_phases_one_step_equivalence(task, nl):
+    """Teacher-forced: every env-step starts from the oracle's body state; the fp64 phases then reproduce the
+    oracle's next state to round-off, for any lane count (the phases are lane-count independent)."""
+    ref, em = _pair(task, 'f64')
+    idx, mask = ref_body_index(ref), comparable_mask(ref)
+    rng = np.random.RandomState(hash(task) % 1000)
+    worst = 0.0
+    for t in range(40):
+        a = rng.randint(18) if t % 3 else 1       # bias towards driving forward into things
+        eb = em.bodies()
+        eb[0, 1:, :] = ref.bodies()[idx]
+        em.set_bodies(eb)
+        ref.step(a)
+        em.run([a], nl=nl)
+        worst = max(worst, np.abs(em.bodies()[0, 1:, :3] - ref.bodies()[idx][:, :3])[mask].max())
+    assert worst < 1e-9, worst
+    assert em.si[2, 0] == 0      # no contact-cache / overlap-list overflow
+
+
+def test_f64_free_running_with_contacts():
+    """Free run while the robot shoves the block into the wall: contacts, warm starting and the cache are exercised
+    continuously; agreement stays at round-off for the first env-steps (the dynamics then amplify it)."""
+    ref, em = _pair('MoveToCorner', 'f64')
+    idx, mask = ref_body_index(ref), comparable_mask(ref)
+    # face the block and push
+    seen_contacts = 0
+    for t, a in enumerate([3, 3, 3, 1, 1, 1, 1, 10, 10, 10, 10, 10]):
+        ref.step(a)
+        em.run([a], nl=8)
+        seen_contacts += len(ref.contacts())
+        d = np.abs(em.bodies()[0, 1:, :3] - ref.bodies()[idx][:, :3])[mask].max()
+        assert d < (1e-12 if t < 4 else 1e-6), (t, d)
+    assert seen_contacts > 0
+
+
+def test_contacts_match_oracle_when_pushing():
+    """Contact normals / points / accumulated impulses of the SAT narrowphase + cache equal the oracle's GJK/EPA ones."""
+    n_checked = 0
+    # free-running comparison of the contact set on a deterministic push
+    ref, em = _pair('MoveToCorner', 'f64')
+    for a in [2] * 6 + [7] * 8 + [1] * 25:
+        ref.set_action(a)
+        for _ in range(10):
+            ref.substep()
+            em.run([a], n_sub=1, nl=4, count_step=False)
+            rc, ec = ref.contacts(), em.contacts()
+            npts = int(sum(r[4] for r in rc))
+            assert npts == len(ec)
+            if npts:
+                pts_ref = np.array([r[5 + 7 * k: 5 + 7 * k + 2] for r in rc for k in range(int(r[4]))])
+                assert np.abs(pts_ref - ec[:, 4:6]).max() < 1e-4
+                n_checked += npts
+    assert n_checked > 20
+
+
+@pytest.mark.parametrize('mode,p99_max,abs_max', [('mixed', 1e-5, 5e-3), ('f32', 5e-3, 5e-2)])
+def test_reduced_precision_one_step_error(mode, p99_max, abs_max):
+    """The shipped arithmetic (fp32 motion + fp64 poses) vs an all-fp32 build, teacher-forced one-step pose error."""
+    ref, em = _pair('MoveToCorner', mode)
+    idx, mask = ref_body_index(ref), comparable_mask(ref)
+    rng = np.random.RandomState(0)
+    errs = []
+    for t in range(80):
+        a = rng.randint(18)
+        eb = em.bodies()
+        eb[0, 1:, :] = ref.bodies()[idx]
+        em.set_bodies(eb)
+        ref.step(a)
+        em.run([a], nl=4)
+        errs.append(np.abs(em.bodies()[0, 1:, :3] - ref.bodies()[idx][:, :3])[mask].max())
+    errs = np.array(errs)
+    assert np.percentile(errs, 99) < p99_max and errs.max() < abs_max
+    if mode == 'mixed':
+        assert np.median(errs) < 1e-7
+
+
+@pytest.mark.parametrize('task', TASKS)
+def test_raster_logic_bit_exact(task):
+    """Tile classification + pixel classification + coverage masks + line blending == the oracle's brute-force
+    384x384 painter + 4x4 box filter, bit for bit, ego and allo."""
+    ref, em = _pair(task, 'f64')
+    idx = ref_body_index(ref)
+    rng = np.random.RandomState(7)
+    for rep in range(3):
+        for _ in range(7):
+            ref.step(rng.randint(18))
+        eb = em.bodies()
+        eb[0, 1:, :] = ref.bodies()[idx]
+        em.set_bodies(eb)
+        for view in ('ego', 'allo'):
+            assert np.array_equal(em.render(0, view), ref.render_lores(view)), (task, rep, view)
+    assert np.array_equal(em.render(0, 'ego', native=True), ref.render('ego'))
+
+
+def test_episode_counter_and_done_flags():
+    ref, em = _pair('MoveToRegion', 'mixed', n=3)
+    for t in range(40):
+        done = em.run([0, 1, 2], nl=4)
+        assert done.all() == (t == 39) and done.any() == (t == 39)
+    assert list(em.si[0]) == [40, 40, 40]
+    em.reset(mask=[1, 0, 1])
+    assert list(em.si[0]) == [0, 40, 0]

@@ -1,0 +1,124 @@
+"""Host-side (no GPU) checks: env-name registry, action table, C-ABI export list, scoring parity with the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_matches_reference_name_surface():
+    import magical_amd as m
+    m.register_envs()
+    assert m.register_envs() is False                         # idempotent (benchmarks/__init__.py:396-399)
+    assert len(m.ALL_REGISTERED_ENVS) == 366                  # 60 x (1 + 5) + 6
+    assert len(set(m.ALL_REGISTERED_ENVS)) == 366
+    assert 'MoveToCorner-Demo-LoRes4E-v0' in m.ALL_REGISTERED_ENVS
+    assert 'ClusterColour-TestAll-LoResCHW4E-v0' in m.ALL_REGISTERED_ENVS
+    assert len(m.DEMO_ENVS_TO_TEST_ENVS_MAP) == 48            # 8 tasks x 6 name forms
+    assert 'MoveToCorner-TestAll-v0' in m.DEMO_ENVS_TO_TEST_ENVS_MAP['MoveToCorner-Demo-v0']
+    e = m.EnvName('MatchRegions-TestJitter-LoRes4A-v0')
+    assert (e.task, e.variant, e.preproc, e.version, e.is_test) == ('MatchRegions', 'TestJitter', 'LoRes4A', 'v0', True)
+    assert e.demo_env_name == 'MatchRegions-Demo-LoRes4A-v0'
+    assert m.update_magical_env_name('FixColour-Demo-v0', preproc='LoRes4E', variant='TestAll') == 'FixColour-TestAll-LoRes4E-v0'
+    with pytest.raises(ValueError):
+        m.EnvName('NotAnEnv')
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/magical'), reason='reference only exists in the build container')
+def test_registry_names_equal_the_reference_source():
+    """Every name string the reference registers appears in ours (parsed from its source text, not imported)."""
+    import magical_amd as m
+    m.register_envs()
+    src = open('/root/reference/magical/benchmarks/__init__.py').read()
+    base_names = set(re.findall(r"'([A-Za-z]+-(?:Demo|Test[A-Za-z]*)-v0)'", src))
+    assert len(base_names) == 60
+    assert base_names <= set(m.ALL_REGISTERED_ENVS)
+
+
+def test_action_table():
+    from magical_amd import entities as en
+    A = en.RobotAction
+    assert len(en.ACTION_NUMS_FLAGS_NAMES) == 18
+    assert en.ACTION_ID_TO_FLAGS[0] == (A.NONE, A.NONE, A.OPEN)
+    assert en.ACTION_ID_TO_FLAGS[4] == (A.UP, A.LEFT, A.OPEN) and en.ACTION_NUMS_FLAGS_NAMES[4][2] == 'UpLeftOpen'
+    assert en.ACTION_ID_TO_FLAGS[17] == (A.DOWN, A.RIGHT, A.CLOSE) and en.ACTION_NUMS_FLAGS_NAMES[17][2] == 'DownRightClose'
+    for i in range(18):
+        assert en.FLAGS_TO_ACTION_ID[en.ACTION_ID_TO_FLAGS[i]] == i
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libmagical_hip.so loads (no GPU needed) and exports every function include/mgx.h declares."""
+    from magical_amd import _native
+    header = open(os.path.join(ROOT, 'include', 'mgx.h')).read()
+    declared = set(re.findall(r'\b(mgx_[a-z_0-9]+)\s*\(', header))
+    assert declared == set(_native.EXPORTED_SYMBOLS), declared ^ set(_native.EXPORTED_SYMBOLS)
+    if not os.path.exists(_native.LIB_PATH):
+        pytest.skip('HIP library not built in this checkout (run `python __graft_entry__.py`)')
+    L = ctypes.CDLL(_native.LIB_PATH)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import magical_amd
+    with pytest.raises(Exception) as ei:
+        magical_amd.make('MoveToCorner-Demo-v0', n_envs=4, device='cpu')
+    assert 'no CPU fallback' in str(ei.value)
+
+
+def test_world_builder_matches_oracle_tables():
+    """The C++ world builder (product) and the Python entity restatement (oracle) agree on masses, inertias,
+    initial poses and collision geometry for every task."""
+    from magical_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        pytest.skip('HIP library not built')
+    from tests.util import TASKS, new_ref, ref_body_index, ref_entities_as_tuples
+    L = _native.lib()
+    for task in TASKS:
+        ref = new_ref(task)
+        w = ctypes.c_void_p()
+        _native.check(L.mgx_world_create(ctypes.byref(w)))
+        for ent in ref_entities_as_tuples(ref):
+            if ent[0] == 'robot':
+                _native.check(L.mgx_world_add_robot(w, *ent[1:]))
+            elif ent[0] == 'shape':
+                _native.check(L.mgx_world_add_shape(w, *ent[1:]))
+            else:
+                _native.check(L.mgx_world_add_goal(w, *ent[1:]))
+        _native.check(L.mgx_world_finalize(w, 100))
+        out = ctypes.c_int()
+        _native.check(L.mgx_world_info(w, _native.INFO['n_bodies'], ctypes.byref(out)))
+        nb = out.value
+        idx = ref_body_index(ref)
+        assert nb == len(idx) + 1
+        mass = (ctypes.c_double * (2 * nb))()
+        pose = (ctypes.c_double * (3 * nb))()
+        _native.check(L.mgx_world_body_table(w, mass, pose))
+        rm, rb = ref.body_mass()[idx], ref.bodies()[idx]
+        assert np.allclose(np.array(mass).reshape(nb, 2)[1:], rm, rtol=1e-14, atol=0)
+        got_pose = np.array(pose).reshape(nb, 3)[1:]
+        mask = np.ones_like(got_pose, dtype=bool)
+        assert np.allclose(got_pose[mask], rb[:, :3][mask], rtol=0, atol=1e-15)
+        _native.check(L.mgx_world_info(w, _native.INFO['n_joints'], ctypes.byref(out)))
+        assert out.value == ref.L.ref_njoints(ref.h)
+        L.mgx_world_destroy(w)
+
+
+def test_palette_table_matches_colorsys():
+    """The RGB8 palette baked into mgx_world.cpp equals style.py evaluated with colorsys (oracle/style_ref.py)."""
+    from oracle.style_ref import COLOURS_RGB, darken_rgb, lighten_rgb, to_u8
+    src = open(os.path.join(ROOT, 'magical_amd', 'csrc', 'mgx_world.cpp')).read()
+
+    def table(name):
+        body = re.search(name + r'\[4\] = \{(.*?)\};', src).group(1)
+        return [tuple(int(v) for v in t.split(',')) for t in re.findall(r'\{(\d+, \d+, \d+)\}', body)]
+    order = ['red', 'green', 'blue', 'yellow']
+    assert table('BASE') == [to_u8(COLOURS_RGB[c]) for c in order]
+    assert table('DARK') == [to_u8(darken_rgb(COLOURS_RGB[c])) for c in order]
+    assert table('LIGHT2') == [to_u8(lighten_rgb(COLOURS_RGB[c], 2)) for c in order]
