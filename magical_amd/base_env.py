@@ -283,7 +283,9 @@ class BaseEnv(abc.ABC):
     def substeps(self, actions, n):
         """n physics substeps under `actions` without advancing the episode counter (parity tests)."""
         import torch
-        actions = torch.as_tensor(np.asarray(actions), device=self.device).to(torch.int32).contiguous()
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions))
+        actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
         nat.check(self._lib.mgx_engine_substeps(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
                                                 self.state_i.data_ptr(), actions.data_ptr(), int(n), self._stream()))
 

@@ -40,6 +40,7 @@ struct mgx_engine {
     RasterDev rdev{};
     size_t lds_step = 0, lds_raster = 0;
     bool timing = false;
+    int dbg_iterations = -1;    // development probe: override the solver iteration count
     std::vector<hipEvent_t> ev[2];      // per kernel kind: start/stop pairs
     int ev_count[2] = {0, 0};
 };
@@ -220,7 +221,7 @@ static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const i
     }
     int epb = 64 / L, blocks = (e->n_envs + epb - 1) / epb;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, st, e->tdev, (P *)sp, (R *)sf, si, actions, done, e->n_envs, n_sub,
-                       count_step, PHYS_ITER);
+                       count_step, e->dbg_iterations >= 0 ? e->dbg_iterations : PHYS_ITER);
     HIP_OK(hipGetLastError());
     return MGX_OK;
 }
@@ -406,6 +407,8 @@ int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_
     HIP_OK(hipGetLastError());
     return MGX_OK;
 }
+int mgx_engine_debug_raster_clocks(mgx_engine *e, void *buf) { if (e) e->rdev.dbg_clk = (unsigned long long *)buf; return MGX_OK; }
+int mgx_engine_debug_iterations(mgx_engine *e, int it) { if (e) e->dbg_iterations = it; return MGX_OK; }
 int mgx_engine_set_timing(mgx_engine *e, int enable) {
     if (!e) return fail(MGX_ERR_ARG, "engine is NULL");
     e->timing = enable != 0;

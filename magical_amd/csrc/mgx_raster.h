@@ -19,6 +19,7 @@ namespace mgx {
 constexpr int NATIVE_RES = 384;   // benchmarks/__init__.py:23 DEFAULT_RES
 constexpr int LORES = 96;         // LoRes* preprocessors
 constexpr double CLASS_EPS = 1e-9;
+constexpr float CLASS_EPS_F = 2e-3f;   // fp32 classification margin (px): covers coefficient + evaluation rounding at |x|,|y| <= 384
 
 // per-env raster scratch (LDS on device)
 struct RasterOff {
@@ -28,6 +29,8 @@ struct RasterOff {
     int pcx, pcy, prad, papo, pphi;     // per prim (n-gon centre/radius/apothem/phase; line half width in prad)
     int n_d;
     int bb;                             // per prim bbox in 384-grid units: x0 y0 x1 y1 (ints, inclusive, may be empty)
+    // fp32 classification items (8 words each) in FRONT-TO-BACK prim order + per-prim (start | count << 16)
+    int items, pitem, n_items;
     int n_i;
     MGX_HD explicit RasterOff(const TmplHeader &h) {
         int o = 0;
@@ -38,6 +41,10 @@ struct RasterOff {
         n_d = o;
         o = 0;
         bb = o; o += 4 * h.n_prims;
+        n_items = h.n_pverts + h.n_prims;          // upper bound: one per polygon edge / line segment / n-gon
+        o = (o + 3) & ~3;                          // 16-byte aligned records
+        items = o; o += 8 * n_items;
+        pitem = o; o += h.n_prims;
         n_i = o;
     }
 };
@@ -67,6 +74,7 @@ struct Raster {
 
 #define RD(field, k) rs.d[rs.ro.field + (k)]
 #define RI(field, k) rs.i[rs.ro.field + (k)]
+#define RF(field, k) reinterpret_cast<float *>(rs.i)[rs.ro.field + (k)]
 
 MGX_HD double rz_floor(double x) { return floor(x); }
 
@@ -245,269 +253,135 @@ MGX_HD int raster_sample(const Raster &rs, double x, double y, uint64_t mask, in
     return r | (g << 8) | (b << 16);
 }
 
-enum { CLS_NONE = 0, CLS_ALL = 1, CLS_MIXED = 2 };
-// Classify prim k against the block of 384-grid samples centred at (xc, yc) with half extents (hx, hy)
-// (sample centres, so a 4x4 block has hx = hy = 1.5): ALL = every sample inside an opaque prim, NONE = no
-// sample touched, MIXED = decide per sample.  Division- and sqrt-free; conservative by CLASS_EPS.
-MGX_HD int classify_rect(const Raster &rs, int k, double xc, double yc, double hx, double hy) {
-    int kind = rs.prim_kind(k);
-    if (kind == PR_POLY) {
-        int nv = rs.prim_nv(k), vo = rs.prim_voff(k);
-        bool all = true;
-        for (int i = 0; i < nv; i++) {
-            double a = RD(ea, vo + i), b = RD(eb, vo + i);
-            double e = a * xc + b * yc + RD(ec, vo + i);
-            double ext = hx * r_abs(a) + hy * r_abs(b) + CLASS_EPS;
-            if (e + ext < 0.0) return CLS_NONE;
-            if (e - ext < 0.0) all = false;
-        }
-        return all ? CLS_ALL : CLS_MIXED;
-    } else if (kind == PR_NGON) {
-        double qx = r_abs(xc - RD(pcx, k)), qy = r_abs(yc - RD(pcy, k));
-        double nx = r_max(qx - hx, 0.0), ny = r_max(qy - hy, 0.0);          // nearest point of the rect
-        double fx = qx + hx, fy = qy + hy;                                    // farthest corner
-        double apo = RD(papo, k) - CLASS_EPS, rad = RD(prad, k) + CLASS_EPS;
-        if (fx * fx + fy * fy < apo * apo) return CLS_ALL;
-        if (nx * nx + ny * ny > rad * rad) return CLS_NONE;
-        return CLS_MIXED;
-    } else {
-        int nv = rs.prim_nv(k), vo = rs.prim_voff(k);
-        double hw = RD(prad, k) + CLASS_EPS;
-        for (int i = 0; i < nv; i++) {
-            double a = RD(ea, vo + i), b = RD(eb, vo + i);
-            double e = a * xc + b * yc + RD(ec, vo + i);
-            if (r_abs(e) - (hx * r_abs(a) + hy * r_abs(b)) > hw) continue;       // off the carrier line
-            double sl = (xc - RD(svx, vo + i)) * b - (yc - RD(svy, vo + i)) * a;  // along the segment
-            double es = hx * r_abs(b) + hy * r_abs(a);
-            if (sl + es < -hw || sl - es > RD(elen, vo + i) + hw) continue;       // beyond its ends
-            return CLS_MIXED;
-        }
-        return CLS_NONE;
-    }
-}
-
+// ---------------------------------------------------------------- fp32 classification items
+// The conservative ALL / NONE / MIXED classification runs in fp32 on a flat list of ITEMS -- one per polygon
+// edge, per n-gon, per line-loop segment -- stored front-to-back.  A wavefront loads up to 64 items (one per
+// lane) and every lane (a tile in phase C, an output pixel in phase T) consumes them through v_readlane
+// broadcasts: the item fields become scalar operands, the loop is wave-uniform and touches no LDS.
+enum { IT_EDGE = 0, IT_NGON = 1, IT_SEG = 2 };
+constexpr int IT_LAST = 4;      // meta bit: last item of its primitive
+struct Item {
+    float a, b, c;              // EDGE/SEG: normalised line a x + b y + c;  NGON: centre x, y, apothem
+    float g0, g1, g2, g3;       // SEG: start x, start y, length, half width;  NGON: g0 = circumradius
+    int meta;                   // kind | IT_LAST | prim << 8
+};
 constexpr int TILE_W = 16, TILE_H = 4, TILES_X = LORES / TILE_W, TILES_Y = LORES / TILE_H;
 
-// tile (tcol, trow) of 16x4 output pixels = 64x16 samples: class of prim k for the whole tile
-MGX_HD int classify_tile(const Raster &rs, int k, int tcol, int trow) {
-    const int gx0 = 4 * TILE_W * tcol, gx1 = gx0 + 4 * TILE_W - 1;
-    const int gy1 = NATIVE_RES - 1 - 4 * TILE_H * trow, gy0 = gy1 - 4 * TILE_H + 1;
-    if (RI(bb, 4 * k) > gx1 || RI(bb, 4 * k + 2) < gx0 || RI(bb, 4 * k + 1) > gy1 || RI(bb, 4 * k + 3) < gy0) return CLS_NONE;
-    return classify_rect(rs, k, 0.5 * (gx0 + gx1 + 1), 0.5 * (gy0 + gy1 + 1), 2.0 * TILE_W - 0.5, 2.0 * TILE_H - 0.5);
-}
-// combine the per-prim tile classes (as bit masks) into the tile's base colour and its set of undecided prims
-MGX_HD void tile_resolve(const Raster &rs, uint64_t all_mask, uint64_t &mixed_mask, int &base_rgb) {
-    if (all_mask) {
-        int ka = 63 - __builtin_clzll(all_mask);
-        base_rgb = rs.prim_rgb(ka);
-        mixed_mask &= ~((2ull << ka) - 1ull);       // everything at or below the topmost covering prim is hidden
-    }
-}
+MGX_HD int prim_item_count(const Raster &rs, int k) { return rs.prim_kind(k) == PR_NGON ? 1 : rs.prim_nv(k); }
 
-// 16-bit coverage of the 4x4 sample block whose top-left sample is (x0, y0) (bit 4*j + i = sample (x0 + i, y0 - j))
-MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, double x0, double y0) {
-    int nv = rs.prim_nv(k), vo = rs.prim_voff(k);
-    uint32_t cov = 0xFFFFu;
-    for (int e = 0; e < nv && cov; e++) {
-        double a = RD(ea, vo + e), b = RD(eb, vo + e);
-        double row = a * x0 + b * y0 + RD(ec, vo + e);
-        // the block spans x0..x0+3, y0-3..y0: if even its worst corner is inside this edge, nothing to test
-        double worst = row + r_min(0.0, 3.0 * a) - r_max(0.0, 3.0 * b);
-        if (worst >= CLASS_EPS) continue;
-        uint32_t m = 0;
-        for (int j = 0; j < 4; j++) {
-            double v = row;
-            for (int i = 0; i < 4; i++) { m |= (v >= 0.0 ? 1u : 0u) << (4 * j + i); v += a; }
-            row -= b;
-        }
-        cov &= m;
-    }
-    return cov;
-}
-MGX_HD uint32_t ngon_coverage16(const Raster &rs, int k, double x0, double y0) {
-    double cx = RD(pcx, k), cy = RD(pcy, k);
-    double apo = RD(papo, k) - CLASS_EPS, rad = RD(prad, k) + CLASS_EPS, apo2 = apo * apo, rad2 = rad * rad;
-    uint32_t cov = 0;
-    for (int j = 0; j < 4; j++)
-        for (int i = 0; i < 4; i++) {
-            double qx = x0 + i - cx, qy = y0 - j - cy, d2 = qx * qx + qy * qy;
-            bool in = d2 <= apo2;
-            if (!in && d2 <= rad2) in = ngon_contains(rs, k, x0 + i, y0 - j);     // thin annulus: exact sector test
-            cov |= (in ? 1u : 0u) << (4 * j + i);
-        }
-    return cov;
-}
-
-// max line-loop alpha for the 4 samples (x0 + i, y), i = 0..3: segment parameters are loaded once per row
-MGX_HD void lineloop_alpha_row(const Raster &rs, int k, double x0, double y, uint32_t segmask, double *best) {
-    int nv = rs.prim_nv(k), vo = rs.prim_voff(k), stipple = rs.prim_stipple(k);
-    double hw = RD(prad, k);
-    best[0] = best[1] = best[2] = best[3] = 0.0;
-    for (int i = 0; i < nv; i++) {
-        if (!((segmask >> i) & 1u)) continue;
-        double a = RD(ea, vo + i), b = RD(eb, vo + i);
-        double e0 = a * x0 + b * y + RD(ec, vo + i);
-        // all four samples off this segment's carrier line?  (e is affine in x)
-        double e3 = e0 + 3.0 * a;
-        if ((e0 >= hw && e3 >= hw) || (e0 <= -hw && e3 <= -hw)) continue;
-        double ax = RD(svx, vo + i), ay = RD(svy, vo + i), len = RD(elen, vo + i), arc = RD(earc, vo + i);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int t = 0; t < 4; t++) {
-            double x = x0 + t, e = a * x + b * y + RD(ec, vo + i);
-            if (r_abs(e) >= hw) continue;
-            double sl = r_clamp((x - ax) * b - (y - ay) * a, 0.0, len);
-            double qx = x - (ax + b * sl), qy = y - (ay - a * sl);
-            double alpha = r_clamp01(hw - sqrt(qx * qx + qy * qy));
-            if (alpha > 0.0 && stipple) {
-                int bit = ((int)rz_floor(arc + sl)) & 15;
-                if (!((stipple >> bit) & 1)) alpha = 0.0;
-            }
-            if (alpha > best[t]) best[t] = alpha;
-        }
-    }
-}
-
-// segments of line loop k that can touch the 4x4 block whose top-left sample is (x0, y0)
-MGX_HD uint32_t lineloop_block_segments(const Raster &rs, int k, double x0, double y0) {
-    int nv = rs.prim_nv(k), vo = rs.prim_voff(k);
-    double hw = RD(prad, k) + CLASS_EPS, xc = x0 + 1.5, yc = y0 - 1.5;
-    uint32_t mask = 0;
-    for (int i = 0; i < nv && i < 16; i++) {
-        double a = RD(ea, vo + i), b = RD(eb, vo + i);
-        double e = a * xc + b * yc + RD(ec, vo + i);
-        if (r_abs(e) - 1.5 * (r_abs(a) + r_abs(b)) > hw) continue;
-        double sl = (xc - RD(svx, vo + i)) * b - (yc - RD(svy, vo + i)) * a, es = 1.5 * (r_abs(a) + r_abs(b));
-        if (sl + es < -hw || sl - es > RD(elen, vo + i) + hw) continue;
-        mask |= 1u << i;
-    }
-    return mask;
-}
-
-// Painter's-order resolution of the prims in `lower` (which contains at least one line loop) for the samples in
-// `remaining`, accumulated into (sr, sg, sb).  Opaque prims act through coverage masks, line loops blend row by row.
-MGX_HD void resolve_lower_stack(const Raster &rs, uint64_t lower, double x0, double y0, int base, uint32_t remaining,
-                                int &sr, int &sg, int &sb) {
-    constexpr int MAXL = 6;
-    int lk[MAXL]; uint32_t lcov[MAXL]; int nl = 0;
-    uint64_t m = lower;
-    while (m && nl < MAXL) {
-        int k = __builtin_ctzll(m);
-        m &= m - 1;
-        int kind = rs.prim_kind(k);
-        lk[nl] = k;
-        // line loops: bit 16 marks the kind, bits 0..15 the segments that can touch this block
-        lcov[nl] = kind == PR_POLY ? poly_coverage16(rs, k, x0, y0)
-                 : (kind == PR_NGON ? ngon_coverage16(rs, k, x0, y0) : (0x10000u | lineloop_block_segments(rs, k, x0, y0)));
-        nl++;
-    }
-    if (m) {   // unusually deep translucent stack: plain per-sample painter
-        for (int s = 0; s < 16; s++)
-            if ((remaining >> s) & 1u) {
-                int c = raster_sample(rs, x0 + (s & 3), y0 - (s >> 2), lower, base);
-                sr += c & 0xFF; sg += (c >> 8) & 0xFF; sb += (c >> 16) & 0xFF;
-            }
-        return;
-    }
-    for (int j = 0; j < 4; j++) {
-        uint32_t rm = (remaining >> (4 * j)) & 0xFu;
-        if (!rm) continue;
-        int c[4] = {base, base, base, base};
-        for (int q = 0; q < nl; q++) {
-            if (lcov[q] & 0x10000u) {
-                if (!(lcov[q] & 0xFFFFu)) continue;
-                double best[4];
-                lineloop_alpha_row(rs, lk[q], x0, y0 - j, lcov[q] & 0xFFFFu, best);
-                int col = rs.prim_rgb(lk[q]);
-                double lr = (double)(col & 0xFF), lg = (double)((col >> 8) & 0xFF), lb = (double)((col >> 16) & 0xFF);
-                for (int t = 0; t < 4; t++)
-                    if (best[t] > 0.0) {
-                        double a = best[t];
-                        int r = (int)rz_floor(a * lr + (1.0 - a) * (double)(c[t] & 0xFF) + 0.5);
-                        int g = (int)rz_floor(a * lg + (1.0 - a) * (double)((c[t] >> 8) & 0xFF) + 0.5);
-                        int b = (int)rz_floor(a * lb + (1.0 - a) * (double)((c[t] >> 16) & 0xFF) + 0.5);
-                        c[t] = r | (g << 8) | (b << 16);
-                    }
-            } else {
-                uint32_t cv = (lcov[q] >> (4 * j)) & 0xFu;
-                int col = rs.prim_rgb(lk[q]);
-                for (int t = 0; t < 4; t++) if ((cv >> t) & 1u) c[t] = col;
+// setup phase 3 (lane per prim, after raster_setup_prims + barrier): write the prim's items
+MGX_HD void raster_setup_items(Raster &rs, int lane, int nl) {
+    const TmplHeader &h = *rs.h;
+    for (int k = lane; k < h.n_prims; k += nl) {
+        int start = 0;
+        for (int kk = h.n_prims - 1; kk > k; kk--) start += prim_item_count(rs, kk);     // front (top) prims first
+        int kind = rs.prim_kind(k), nv = rs.prim_nv(k), vo = rs.prim_voff(k), cnt = prim_item_count(rs, k);
+        RI(pitem, k) = start | (cnt << 16);
+        Item *it = reinterpret_cast<Item *>(&RI(items, 8 * start));
+        if (kind == PR_NGON) {
+            it[0].a = (float)RD(pcx, k); it[0].b = (float)RD(pcy, k); it[0].c = (float)RD(papo, k); it[0].g0 = (float)RD(prad, k);
+            it[0].g1 = it[0].g2 = it[0].g3 = 0.0f;
+            it[0].meta = IT_NGON | IT_LAST | (k << 8);
+        } else {
+            for (int i = 0; i < nv; i++) {
+                it[i].a = (float)RD(ea, vo + i); it[i].b = (float)RD(eb, vo + i); it[i].c = (float)RD(ec, vo + i);
+                it[i].g0 = (float)RD(svx, vo + i); it[i].g1 = (float)RD(svy, vo + i); it[i].g2 = (float)RD(elen, vo + i);
+                it[i].g3 = kind == PR_LINELOOP ? (float)RD(prad, k) : 0.0f;
+                it[i].meta = (kind == PR_POLY ? IT_EDGE : IT_SEG) | (i == nv - 1 ? IT_LAST : 0) | (k << 8);
             }
         }
-        for (int t = 0; t < 4; t++)
-            if ((rm >> t) & 1u) { sr += c[t] & 0xFF; sg += (c[t] >> 8) & 0xFF; sb += (c[t] >> 16) & 0xFF; }
+    }
+}
+MGX_HD int raster_total_items(const Raster &rs) {
+    int pi = RI(pitem, 0);                      // prim 0 is the rearmost: its items end the list
+    return (pi & 0xFFFF) + (pi >> 16);
+}
+MGX_HD Item load_item(const Raster &rs, int idx) { return reinterpret_cast<const Item *>(&RI(items, 0))[idx]; }
+
+// item index of `slot` in the concatenation (front to back) of the items of the prims in `mask`; -1 past the end
+MGX_HD int masked_item_index(const Raster &rs, uint64_t mask, int slot, int &n_total) {
+    int acc = 0, found = -1;
+    while (mask) {
+        int k = 63 - __builtin_clzll(mask);
+        mask &= ~(1ull << k);
+        int pi = RI(pitem, k), start = pi & 0xFFFF, cnt = pi >> 16;
+        if (slot >= acc && slot < acc + cnt) found = start + (slot - acc);
+        acc += cnt;
+    }
+    n_total = acc;
+    return found;
+}
+
+// per-lane classification state carried across item chunks
+struct ClassState {
+    uint64_t mixed; int base; bool decided, none, partial, hit;
+    MGX_HD void init(int bg) { mixed = 0; base = bg; decided = false; none = false; partial = false; hit = false; }
+};
+// Consume one item for the sample block centred at (xc, yc) with half extents (hx, hy) (sample centres: a 4x4
+// block has hx = hy = 1.5).  ALL = every sample inside an opaque prim, NONE = no sample touched, MIXED = decide
+// per sample; conservative by CLASS_EPS_F.  `I` is wave-uniform on the device (readlane), so every branch on its
+// kind is a scalar branch.
+MGX_HD void classify_item(const Raster &rs, const Item &I, float xc, float yc, float hx, float hy, ClassState &st) {
+    const int kind = I.meta & 3;
+    if (kind == IT_EDGE) {
+        float e = I.a * xc + I.b * yc + I.c;
+        float ext = hx * r_abs(I.a) + hy * r_abs(I.b) + CLASS_EPS_F;
+        st.none |= e + ext < 0.0f;
+        st.partial |= e - ext < 0.0f;
+    } else if (kind == IT_NGON) {
+        float qx = r_abs(xc - I.a), qy = r_abs(yc - I.b);
+        float nx = r_max(qx - hx, 0.0f), ny = r_max(qy - hy, 0.0f);          // nearest point of the rect
+        float fx = qx + hx, fy = qy + hy;                                      // farthest corner
+        float apo = I.c - CLASS_EPS_F, rad = I.g0 + CLASS_EPS_F;
+        st.partial = !(apo > 0.0f && fx * fx + fy * fy < apo * apo);
+        st.none = nx * nx + ny * ny > rad * rad;
+    } else {
+        float hw = I.g3 + CLASS_EPS_F;
+        float e = I.a * xc + I.b * yc + I.c;
+        bool off_line = r_abs(e) - (hx * r_abs(I.a) + hy * r_abs(I.b)) > hw;   // off the carrier line
+        float sl = (xc - I.g0) * I.b - (yc - I.g1) * I.a;                        // along the segment
+        float es = hx * r_abs(I.b) + hy * r_abs(I.a);
+        bool off_ends = sl + es < -hw || sl - es > I.g2 + hw;                   // beyond its ends
+        st.hit |= !(off_line || off_ends);
+    }
+    if (I.meta & IT_LAST) {
+        const int k = I.meta >> 8;
+        if (!st.decided) {
+            if (kind == IT_SEG) { if (st.hit) st.mixed |= 1ull << k; }
+            else if (!st.none) {
+                if (st.partial) st.mixed |= 1ull << k;
+                else { st.base = rs.prim_rgb(k); st.decided = true; }      // topmost covering prim: everything below is hidden
+            }
+        }
+        st.none = false; st.partial = false; st.hit = false;
     }
 }
 
-// ---- one 96x96 output pixel (X, Y), Y = 0 at the top, in two steps
-// step 1: classify the tile's undecided prims against this pixel's 4x4 sample block.  Returns the prims still
-// undecided (0 = the pixel is `base`, done) and updates `base` to the colour under them.
-MGX_HD uint64_t pixel_classify(const Raster &rs, int X, int Y, uint64_t tile_mixed, int &base) {
-    const double xc = 4.0 * X + 2.0, yc = (double)NATIVE_RES - 4.0 * Y - 2.0;
-    const int gx0 = 4 * X, gx1 = 4 * X + 3, gy1 = NATIVE_RES - 1 - 4 * Y, gy0 = gy1 - 3;   // 384-grid index range of the block
-    uint64_t mixed = 0;
-    // front to back: stop at the topmost primitive that covers the whole 4x4 block
-    uint64_t m = tile_mixed;
-    while (m) {
-        int k = 63 - __builtin_clzll(m);
-        m &= ~(1ull << k);
-        if (RI(bb, 4 * k) > gx1 || RI(bb, 4 * k + 2) < gx0 || RI(bb, 4 * k + 1) > gy1 || RI(bb, 4 * k + 3) < gy0) continue;
-        int cls = classify_rect(rs, k, xc, yc, 1.5, 1.5);
-        if (cls == CLS_ALL) { base = rs.prim_rgb(k); break; }
-        if (cls == CLS_MIXED) mixed |= 1ull << k;
-    }
-    return mixed;
+// host-side item source (the device uses registers + readlane, see mgx_raster.hip)
+MGX_HD void classify_items_array(const Raster &rs, const Item *items, int n, float xc, float yc, float hx, float hy, ClassState &st) {
+    for (int i = 0; i < n && !st.decided; i++) classify_item(rs, items[i], xc, yc, hx, hy, st);
 }
-// step 2: resolve the 16 samples of an undecided pixel.  Opaque prims (front to back) claim samples through
-// coverage masks; once a translucent line loop is reached, the samples still unclaimed are blended per sample.
-MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int base) {
-    const double x0 = 4.0 * X + 0.5, y0 = (double)NATIVE_RES - 0.5 - 4.0 * Y;
-    uint32_t remaining = 0xFFFFu;
-    int sr = 0, sg = 0, sb = 0;
-    uint64_t m = mixed;
-    while (m && remaining) {
-        int k = 63 - __builtin_clzll(m);
-        m &= ~(1ull << k);
-        int kind = rs.prim_kind(k);
-        if (kind == PR_LINELOOP) {
-            // translucent: everything from here down is blended per sample, for the samples nobody above claimed
-            resolve_lower_stack(rs, mixed & ((2ull << k) - 1ull), x0, y0, base, remaining, sr, sg, sb);
-            remaining = 0;
-            break;
-        }
-        uint32_t cov = (kind == PR_POLY ? poly_coverage16(rs, k, x0, y0) : ngon_coverage16(rs, k, x0, y0)) & remaining;
-        if (cov) {
-            int n = __builtin_popcount(cov), col = rs.prim_rgb(k);
-            sr += n * (col & 0xFF); sg += n * ((col >> 8) & 0xFF); sb += n * ((col >> 16) & 0xFF);
-            remaining &= ~cov;
-        }
-    }
-    if (remaining) {
-        int n = __builtin_popcount(remaining);
-        sr += n * (base & 0xFF); sg += n * ((base >> 8) & 0xFF); sb += n * ((base >> 16) & 0xFF);
-    }
-    // cv2 INTER_AREA integer-factor path: saturate_cast<uchar>(sum * (1/16)) = round half to even
+
+MGX_HD void tile_centre(int tile, float &xc, float &yc) {
+    const int tcol = tile % TILES_X, trow = tile / TILES_X;
+    const int gx0 = 4 * TILE_W * tcol, gy1 = NATIVE_RES - 1 - 4 * TILE_H * trow, gy0 = gy1 - 4 * TILE_H + 1;
+    xc = 0.5f * (gx0 + gx0 + 4 * TILE_W); yc = 0.5f * (gy0 + gy1 + 1);
+}
+constexpr float TILE_HX = 2.0f * TILE_W - 0.5f, TILE_HY = 2.0f * TILE_H - 0.5f;
+
+// exact 4x4-sample mean of an undecided pixel, one sample at a time (the device spreads the 16 samples over 16 lanes)
+MGX_HD int pixel_sample(const Raster &rs, int X, int Y, int s, uint64_t mixed, int base) {
+    return raster_sample(rs, 4.0 * X + (s & 3) + 0.5, (double)NATIVE_RES - 0.5 - 4.0 * Y - (s >> 2), mixed, base);
+}
+// cv2 INTER_AREA integer-factor path: saturate_cast<uchar>(sum * (1/16)) = round half to even
+MGX_HD int mean16(int sr, int sg, int sb) {
     int r = (sr + 7 + ((sr >> 4) & 1)) >> 4, g = (sg + 7 + ((sg >> 4) & 1)) >> 4, b = (sb + 7 + ((sb >> 4) & 1)) >> 4;
     return r | (g << 8) | (b << 16);
 }
-MGX_HD int raster_pixel_lores(const Raster &rs, int X, int Y, uint64_t tile_mixed, int base) {
-    uint64_t mixed = pixel_classify(rs, X, Y, tile_mixed, base);
-    return mixed ? pixel_resolve(rs, X, Y, mixed, base) : base;
-}
-
-// whole-tile classification of every prim (one lane per tile): base colour + undecided set
-MGX_HD void classify_tile_all(const Raster &rs, int tile, int bg_rgb, int &base, uint64_t &mixed) {
-    const int tcol = tile % TILES_X, trow = tile / TILES_X;
-    uint64_t all_mask = 0, mixed_mask = 0;
-    for (int k = rs.h->n_prims - 1; k >= 0; k--) {       // front to back: nothing under a covering prim matters
-        int cls = classify_tile(rs, k, tcol, trow);
-        if (cls == CLS_ALL) { all_mask = 1ull << k; break; }
-        if (cls == CLS_MIXED) mixed_mask |= 1ull << k;
-    }
-    base = bg_rgb;
-    tile_resolve(rs, all_mask, mixed_mask, base);
-    mixed = mixed_mask;
+MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int base) {
+    int sr = 0, sg = 0, sb = 0;
+    for (int s = 0; s < 16; s++) { int c = pixel_sample(rs, X, Y, s, mixed, base); sr += c & 0xFF; sg += (c >> 8) & 0xFF; sb += (c >> 16) & 0xFF; }
+    return mean16(sr, sg, sb);
 }
 
 }  // namespace mgx

@@ -23,10 +23,11 @@ struct RasterDev {
     int scratch_d;           // doubles of per-env scratch
     int bg_rgb;
     int off_tiles;           // word offset (inside the scratch area) of the per-tile / queue region, 8-byte aligned
+    unsigned long long *dbg_clk;   // development probe: per-block phase clocks [n_envs][8] (NULL = off)
 };
 
 constexpr int N_TILES = TILES_X * TILES_Y;
-constexpr int QCAP = 1024;     // LDS queue of undecided pixels per env (overflow is resolved in place)
+constexpr int QCAP = 2048;     // LDS queue of undecided pixels per env (overflow is resolved in place)
 
 // FlattenFrameStack shift of one pixel: 12 B read-modify-write (or 4 copies of the frame after a reset)
 __device__ __forceinline__ void store_stack4(uint8_t *frame, int X, int Y, int c, bool fill) {
@@ -50,13 +51,42 @@ __device__ __forceinline__ void store_frame_px(uint8_t *frame, int X, int Y, int
     q[0] = c & 0xFF; q[1] = (c >> 8) & 0xFF; q[2] = (c >> 16) & 0xFF;
 }
 
+// one Item per lane; get(i) broadcasts lane i's record to the whole wave as scalar operands
+struct RegItems {
+    Item my;
+    __device__ __forceinline__ Item get(int i) const {
+        Item r;
+        r.a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my.a), i));
+        r.b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my.b), i));
+        r.c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my.c), i));
+        r.g0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my.g0), i));
+        r.g1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my.g1), i));
+        r.g2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my.g2), i));
+        r.g3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my.g3), i));
+        r.meta = __builtin_amdgcn_readlane(my.meta, i);
+        return r;
+    }
+};
+// consume items [0, n) held one per lane; stops early once every lane of the wave is decided
+__device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegItems &src, int n, float xc, float yc, float hx, float hy,
+                                                    ClassState &st, bool active) {
+    for (int i = 0; i < n; i++) {
+        if (__all(st.decided || !active)) break;
+        const Item I = src.get(i);
+        classify_item(rs, I, xc, yc, hx, hy, st);
+    }
+}
+
 template <typename P, int LAYOUT>
 __global__ __launch_bounds__(256) void k_raster(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
                                                 long env_stride, int view, const uint8_t *__restrict__ fill_mask, int n_envs) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
+    unsigned long long clk0 = wall_clock64();
+#define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 8 + (i)] = wall_clock64() - clk0;
     for (int i = tid; i < t.n_words; i += 256) lds[i] = t.words[i];
     __syncthreads();
+    CLK(0)
     const long env = blockIdx.x;
     const TmplHeader *h = reinterpret_cast<const TmplHeader *>(lds);
     uint32_t *scratch = lds + t.lds_tmpl_words;
@@ -70,21 +100,38 @@ __global__ __launch_bounds__(256) void k_raster(RasterDev t, const P *__restrict
     int32_t *q_base = q_pix + QCAP;
     int32_t *q_count = q_base + QCAP;
     if (tid == 0) *q_count = 0;
-    // phase S: screen-space setup (lane per body, then lane per primitive)
+    // phase S: screen-space setup (lane per body, lane per primitive, lane per primitive again for the item list)
     raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
     __syncthreads();
     raster_setup_prims(rs, tid, 256);
     __syncthreads();
-    // phase C: one lane per 16x4 tile classifies every primitive against it (uniform loops, broadcast LDS reads)
-    if (tid < N_TILES) {
-        int base; uint64_t mixed;
-        classify_tile_all(rs, tid, t.bg_rgb, base, mixed);
-        tile_base[tid] = base; tile_mixed[tid] = mixed;
+    raster_setup_items(rs, tid, 256);
+    __syncthreads();
+    CLK(1)
+    const int wave = tid >> 6, lane = tid & 63;
+    // phase C: one lane per 16x4 tile; the whole item list streams through the wave's registers 64 items at a time
+    {
+        const int n_items = raster_total_items(rs);
+        const int tile = tid;                       // waves 0..2 cover the 144 tiles
+        if (wave * 64 < N_TILES) {
+            const bool active = tile < N_TILES;
+            float xc = 0.0f, yc = 0.0f;
+            if (active) tile_centre(tile, xc, yc);
+            ClassState st; st.init(t.bg_rgb);
+            for (int c0 = 0; c0 < n_items; c0 += 64) {
+                RegItems src;
+                const int idx = c0 + lane;
+                src.my = load_item(rs, idx < n_items ? idx : 0);
+                const int n = n_items - c0 < 64 ? n_items - c0 : 64;
+                classify_items_regs(rs, src, n, xc, yc, TILE_HX, TILE_HY, st, active);
+            }
+            if (active) { tile_base[tile] = st.base; tile_mixed[tile] = st.mixed; }
+        }
     }
     __syncthreads();
+    CLK(2)
 
     // phase T: each wavefront walks its tiles, one lane per output pixel
-    const int wave = tid >> 6, lane = tid & 63;
     const int tx = lane & (TILE_W - 1), ty = lane >> 4;
     const bool fill = LAYOUT == 1 && fill_mask != nullptr && fill_mask[env] != 0;
     uint8_t *frame = out + env * env_stride;
@@ -107,28 +154,58 @@ __global__ __launch_bounds__(256) void k_raster(RasterDev t, const P *__restrict
             }
             continue;
         }
-        const uint64_t pmixed = pixel_classify(rs, X, Y, tmixed, c);
-        if (pmixed == 0) {
+        // undecided tile: gather the items of its undecided prims (front to back), one per lane, and classify
+        // every pixel's 4x4 sample block against them
+        ClassState st; st.init(c);
+        const float xc = 4.0f * X + 2.0f, yc = (float)NATIVE_RES - 4.0f * Y - 2.0f;
+        int n_total = 0;
+        for (int c0 = 0;; c0 += 64) {
+            RegItems src;
+            const int idx = masked_item_index(rs, tmixed, c0 + lane, n_total);
+            src.my = load_item(rs, idx >= 0 ? idx : 0);
+            const int n = n_total - c0 < 64 ? n_total - c0 : 64;
+            classify_items_regs(rs, src, n, xc, yc, 1.5f, 1.5f, st, true);
+            if (c0 + 64 >= n_total) break;
+        }
+        c = st.base;
+        if (st.mixed == 0) {
             if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
         } else {
-            // undecided: hand the pixel to phase Q so that finished lanes do not wait for it
+            // undecided pixel: queue it for phase Q so that finished lanes do not wait for it
             int slot = atomicAdd(q_count, 1);
             if (slot < QCAP) {
-                q_mask[slot] = pmixed; q_pix[slot] = X | (Y << 8); q_base[slot] = c;
+                q_mask[slot] = st.mixed; q_pix[slot] = X | (Y << 8); q_base[slot] = c;
             } else {
-                c = pixel_resolve(rs, X, Y, pmixed, c);
+                c = pixel_resolve(rs, X, Y, st.mixed, c);
                 if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
             }
         }
     }
     __syncthreads();
-    // phase Q: all 256 lanes resolve the queued pixels (16 samples each)
+    CLK(3)
+    // phase Q: 16 lanes per queued pixel, one exact fp64 sample each, reduced with cross-lane shuffles
     const int nq = *q_count < QCAP ? *q_count : QCAP;
-    for (int i = tid; i < nq; i += 256) {
-        const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;
-        const int c = pixel_resolve(rs, X, Y, q_mask[i], q_base[i]);
-        if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
+    const int sub = tid & 15;
+    for (int q0 = 0; q0 < nq; q0 += 16) {
+        const int q = q0 + (tid >> 4);
+        int sr = 0, sg = 0, sb = 0, X = 0, Y = 0;
+        if (q < nq) {
+            X = q_pix[q] & 0xFF; Y = q_pix[q] >> 8;
+            const int cs = pixel_sample(rs, X, Y, sub, q_mask[q], q_base[q]);
+            sr = cs & 0xFF; sg = (cs >> 8) & 0xFF; sb = (cs >> 16) & 0xFF;
+        }
+        int rg = sr | (sg << 16);
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { rg += __shfl_xor(rg, m, 16); sb += __shfl_xor(sb, m, 16); }
+        if (q < nq && sub == 0) {
+            const int c = mean16(rg & 0xFFFF, rg >> 16, sb);
+            if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
+        }
     }
+    __syncthreads();
+    CLK(4)
+    if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 8 + 5] = nq;
+#undef CLK
 }
 
 // 384x384x3 point-sampled frame of ONE env (no box filter): parity tests against the oracle / reference PNGs

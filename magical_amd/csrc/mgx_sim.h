@@ -664,35 +664,166 @@ template <typename R, typename P> MGX_HD void contact_apply_impulse(Env<R, P> &e
     STOREV(a, va); STOREV(b, vb);
 }
 
-// ---------------------------------------------------------------- phase: sequential solve (one lane)
-// cache carry-over (cpSpaceArbiterSetFilter), spring preStep, warm start, 10 Gauss-Seidel
-// iterations, then next substep's Robot.update.
-template <typename R, typename P> MGX_HD void ph_solve(Env<R, P> &e, int iterations, bool control_after) {
-    int nk = E_I(misc, M_NK), narb = E_I(misc, M_NARB), ncache = E_I(misc, M_NCACHE);
-    // untouched cached arbiters age; they survive collision_persistence = 3 steps
-    int n = narb;
-    for (int c = 0; c < ncache; c++) {
-        if (E_I(cmatched, c)) { E_I(cmatched, c) = 0; continue; }
-        uint32_t hd = (uint32_t)E_I(chead, c);
-        uint32_t age = ((hd >> 12) & 3u) + 1u;
-        if (age <= 2u && n < e.h->cache_slots) {
-            E_I(nchead, n) = (int32_t)((hd & ~(3u << 12)) | (age << 12));
-            for (int i = 0; i < 4; i++) E_R(ncj, 4 * n + i) = E_R(cj, 4 * c + i);
-            E_I(koff, n) = -1;
-            n++;
-        }
+// ---------------------------------------------------------------- solve
+// Chipmunk's order per substep: (arbiter preStep, joint preStep incl. the spring torque) -> cached arbiter
+// impulses -> cached joint impulses -> 10 x { all arbiters in pair order ; all joints in insertion order }.
+// Joints only couple bodies inside an ISLAND (the robot's 10 joints; each block's {pivot, gear} to the static
+// body), so inside the joint half of an iteration islands can run on different lanes and still apply, to every
+// body, exactly the sequence of impulses the serial order applies: the result is bit-identical.  The robot
+// island is solved entirely in registers (6 bodies x 3 velocities + 10 unrolled joint rows); contacts stay
+// sequential on lane 0 against the LDS copy of the velocities, with a store / barrier / load hand-over around
+// them only when the env has contacts at all.
+
+constexpr int RI_JOINTS = 10, RI_BODIES = 6;   // Robot.setup (entities.py:238-354): pivot gear spring spring {pin limit motor} x2
+// kinds and body slots (0 control, 1 robot, 2 eye L, 3 eye R, 4 finger L, 5 finger R) of the robot's joints
+#define RI_KIND(j) ((j) == 0 ? J_PIVOT : (j) == 1 ? J_GEAR : (j) <= 3 ? J_SPRING : ((j) - 4) % 3 == 0 ? J_PIN : ((j) - 4) % 3 == 1 ? J_LIMIT : J_MOTOR)
+#define RI_SA(j) ((j) <= 1 ? 0 : 1)
+#define RI_SB(j) ((j) <= 1 ? 1 : (j) == 2 ? 2 : (j) == 3 ? 3 : (j) <= 6 ? 4 : 5)
+
+template <typename R> struct SolveCtx {
+    // robot island (only meaningful on lane 0 of the env's group)
+    R vx[RI_BODIES], vy[RI_BODIES], w[RI_BODIES], minv[RI_BODIES], iinv[RI_BODIES];
+    R f[RI_JOINTS][12], lim[RI_JOINTS];
+    // one block island per lane (lanes 1..): pivot k (2x2), accumulators, limits, gear effective mass
+    R bvx, bvy, bw, bminv, biinv, bk[4], bacc[3], blim[2], bgear, bbias[3];
+    int bbody, bj;            // body / first joint of the register-resident block (-1: none)
+    int has_contacts;
+};
+
+template <typename R> MGX_HD void reg_apply_joint(int kind, R *f, R lim, R ma, R ia, R mb, R ib,
+                                                  R &avx, R &avy, R &aw, R &bvx, R &bvy, R &bw) {
+    switch (kind) {
+    case J_PIVOT: {   // f: r1x r1y r2x r2y k0 k1 k2 k3 bias0 bias1 acc0 acc1
+        R vrx = (bvx - f[3] * bw) - (avx - f[1] * aw), vry = (bvy + f[2] * bw) - (avy + f[0] * aw);
+        R dx = f[8] - vrx, dy = f[9] - vry;
+        R jx = dx * f[4] + dy * f[5], jy = dx * f[6] + dy * f[7];
+        R ox = f[10], oy = f[11];
+        R nxv = ox + jx, nyv = oy + jy;
+        R l2 = nxv * nxv + nyv * nyv;
+        if (l2 > lim * lim) { R sc = lim / (r_sqrt(l2) + r_tiny<R>()); nxv *= sc; nyv *= sc; }
+        f[10] = nxv; f[11] = nyv;
+        jx = nxv - ox; jy = nyv - oy;
+        avx -= jx * ma; avy -= jy * ma; aw -= ia * (f[0] * jy - f[1] * jx);
+        bvx += jx * mb; bvy += jy * mb; bw += ib * (f[2] * jy - f[3] * jx);
+    } break;
+    case J_GEAR: {    // f: imass bias acc ratio
+        R ratio = f[3], ratio_inv = R(1) / ratio;
+        R wr = bw * ratio - aw;
+        R jj = (f[1] - wr) * f[0];
+        R jold = f[2];
+        R jn = r_clamp(jold + jj, -lim, lim);
+        f[2] = jn; jj = jn - jold;
+        aw = aw - jj * ia * ratio_inv; bw = bw + jj * ib;
+    } break;
+    case J_SPRING: {  // f: imass w_coef target_wrn
+        R wrn = aw - bw;
+        R w_damp = (f[2] - wrn) * f[1];
+        f[2] = wrn + w_damp;
+        R j_damp = w_damp * f[0];
+        aw = aw + j_damp * ia; bw = bw - j_damp * ib;
+    } break;
+    case J_PIN: {     // f: r1x r1y r2x r2y nx ny nmass bias acc
+        R vrx = (bvx - f[3] * bw) - (avx - f[1] * aw), vry = (bvy + f[2] * bw) - (avy + f[0] * aw);
+        R vrn = vrx * f[4] + vry * f[5];
+        R jn = (f[7] - vrn) * f[6];
+        R jold = f[8];
+        R jnew = r_clamp(jold + jn, -lim, lim);
+        f[8] = jnew; jn = jnew - jold;
+        R jx = f[4] * jn, jy = f[5] * jn;
+        avx -= jx * ma; avy -= jy * ma; aw -= ia * (f[0] * jy - f[1] * jx);
+        bvx += jx * mb; bvy += jy * mb; bw += ib * (f[2] * jy - f[3] * jx);
+    } break;
+    case J_LIMIT: {   // f: imass bias acc
+        R bias = f[1];
+        if (bias == R(0)) return;
+        R wr = bw - aw;
+        R jj = -(bias + wr) * f[0];
+        R jold = f[2];
+        R jn = bias < R(0) ? r_clamp(jold + jj, R(0), lim) : r_clamp(jold + jj, -lim, R(0));
+        f[2] = jn; jj = jn - jold;
+        aw = aw - jj * ia; bw = bw + jj * ib;
+    } break;
+    default: {        // J_MOTOR, f: imass rate acc
+        R wr = bw - aw + f[1];
+        R jj = -wr * f[0];
+        R jold = f[2];
+        R jn = r_clamp(jold + jj, -lim, lim);
+        f[2] = jn; jj = jn - jold;
+        aw = aw - jj * ia; bw = bw + jj * ib;
+    } break;
     }
-    E_I(misc, M_NNCACHE) = n;
-    // cpDampedRotarySpring preStep: applies the spring torque immediately, in joint order
-    for (int j = 0; j < e.h->n_joints; j++) {
-        if (T_I(joint_kind, j) != J_SPRING) continue;
-        int a = T_I(joint_a, j), b = T_I(joint_b, j);
-        const R *p = &T_R(joint_p, j * JOINT_PARAMS);
-        E_R(jrate, j) = R(0);                                // target_wrn
-        R j_spring = R((E_P(ang, a) - E_P(ang, b)) - T_P(p_joint, j * 7 + 4)) * p[5];
-        E_R(w, a) -= j_spring * T_R(body_iinv, a); E_R(w, b) += j_spring * T_R(body_iinv, b);
+}
+template <typename R> MGX_HD void reg_apply_cached(int kind, const R *f, R ma, R ia, R mb, R ib,
+                                                   R &avx, R &avy, R &aw, R &bvx, R &bvy, R &bw) {
+    if (kind == J_PIVOT || kind == J_PIN) {
+        R jx, jy;
+        if (kind == J_PIVOT) { jx = f[10]; jy = f[11]; } else { jx = f[4] * f[8]; jy = f[5] * f[8]; }
+        avx -= jx * ma; avy -= jy * ma; aw -= ia * (f[0] * jy - f[1] * jx);
+        bvx += jx * mb; bvy += jy * mb; bw += ib * (f[2] * jy - f[3] * jx);
+    } else if (kind == J_GEAR) {
+        R jj = f[2];
+        aw -= jj * ia * (R(1) / f[3]); bw += jj * ib;
+    } else if (kind == J_LIMIT || kind == J_MOTOR) {
+        R jj = f[2];
+        aw -= jj * ia; bw += jj * ib;
     }
-    // warm start (dt_coef == 1: fixed dt; accumulators are zero on the first step after reset)
+}
+
+template <typename R, typename P> MGX_HD int ri_body(const Env<R, P> &e, int slot) {
+    const TmplHeader &h = *e.h;
+    return slot == 0 ? h.control_body : slot == 1 ? h.robot_body : slot == 2 ? h.eye_body[0] : slot == 3 ? h.eye_body[1]
+         : slot == 4 ? h.finger_body[0] : h.finger_body[1];
+}
+template <typename R, typename P> MGX_HD void ri_load_vel(const Env<R, P> &e, SolveCtx<R> &c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 0; s < RI_BODIES; s++) { int b = ri_body(e, s); c.vx[s] = E_R(vx, b); c.vy[s] = E_R(vy, b); c.w[s] = E_R(w, b); }
+}
+template <typename R, typename P> MGX_HD void ri_store_vel(Env<R, P> &e, const SolveCtx<R> &c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 1; s < RI_BODIES; s++) { int b = ri_body(e, s); E_R(vx, b) = c.vx[s]; E_R(vy, b) = c.vy[s]; E_R(w, b) = c.w[s]; }
+}
+// which block (island) does this lane keep in registers?  lane 1 + k <-> island k when every island gets a lane
+template <typename R, typename P> MGX_HD int lane_island(const Env<R, P> &e, int lane, int nl) {
+    return (e.h->n_islands <= nl - 1 && lane >= 1 && lane - 1 < e.h->n_islands) ? lane - 1 : -1;
+}
+template <typename R, typename P> MGX_HD void bi_load_vel(const Env<R, P> &e, SolveCtx<R> &c) {
+    if (c.bbody >= 0) { c.bvx = E_R(vx, c.bbody); c.bvy = E_R(vy, c.bbody); c.bw = E_R(w, c.bbody); }
+}
+template <typename R, typename P> MGX_HD void bi_store_vel(Env<R, P> &e, const SolveCtx<R> &c) {
+    if (c.bbody >= 0) { E_R(vx, c.bbody) = c.bvx; E_R(vy, c.bbody) = c.bvy; E_R(w, c.bbody) = c.bw; }
+}
+template <typename R> MGX_HD void bi_iterate(SolveCtx<R> &c) {
+    if (c.bbody < 0) return;
+    // PivotJoint(static, block): a = static (m_inv = i_inv = 0, v = 0), r1 = r2 = 0
+    {
+        R dx = c.bbias[0] - c.bvx, dy = c.bbias[1] - c.bvy;
+        R jx = dx * c.bk[0] + dy * c.bk[1], jy = dx * c.bk[2] + dy * c.bk[3];
+        R ox = c.bacc[0], oy = c.bacc[1];
+        R nxv = ox + jx, nyv = oy + jy, lim = c.blim[0];
+        R l2 = nxv * nxv + nyv * nyv;
+        if (l2 > lim * lim) { R sc = lim / (r_sqrt(l2) + r_tiny<R>()); nxv *= sc; nyv *= sc; }
+        c.bacc[0] = nxv; c.bacc[1] = nyv;
+        jx = nxv - ox; jy = nyv - oy;
+        c.bvx += jx * c.bminv; c.bvy += jy * c.bminv; c.bw += c.biinv * (R(0) * jy - R(0) * jx);
+    }
+    // GearJoint(static, block, 0, 1)
+    {
+        R wr = c.bw * R(1) - R(0);
+        R jj = (c.bbias[2] - wr) * c.bgear;
+        R jold = c.bacc[2];
+        R jn = r_clamp(jold + jj, -c.blim[1], c.blim[1]);
+        c.bacc[2] = jn; jj = jn - jold;
+        c.bw = c.bw + jj * c.biinv;
+    }
+}
+
+// cpArbiterApplyCachedImpulse for every warm contact (lane 0, LDS velocities)
+template <typename R, typename P> MGX_HD void contacts_warm_start(Env<R, P> &e) {
+    int nk = E_I(misc, M_NK);
     for (int k = 0; k < nk; k++) {
         if (E_I(kfirst, k)) continue;
         int ab = E_I(kab, k), a = ab & 0xFF, b = ab >> 8;
@@ -702,12 +833,155 @@ template <typename R, typename P> MGX_HD void ph_solve(Env<R, P> &e, int iterati
         E_R(vx, a) -= jx * T_R(body_minv, a); E_R(vy, a) -= jy * T_R(body_minv, a); E_R(w, a) -= T_R(body_iinv, a) * (r1x * jy - r1y * jx);
         E_R(vx, b) += jx * T_R(body_minv, b); E_R(vy, b) += jy * T_R(body_minv, b); E_R(w, b) += T_R(body_iinv, b) * (r2x * jy - r2y * jx);
     }
-    for (int j = 0; j < e.h->n_joints; j++) joint_apply_cached(e, j);
-    for (int it = 0; it < iterations; it++) {
-        for (int k = 0; k < nk; k++) contact_apply_impulse(e, k);
-        for (int j = 0; j < e.h->n_joints; j++) joint_apply_impulse(e, j);
+}
+
+// solve step A (after the preStep phase): lane 0 ages the contact cache, loads the robot island into registers and
+// applies the spring torques (cpDampedRotarySpring preStep, in joint order); block lanes load their island
+template <typename R, typename P> MGX_HD void solve_begin(Env<R, P> &e, SolveCtx<R> &c, int lane, int nl) {
+    const TmplHeader &h = *e.h;
+    c.has_contacts = E_I(misc, M_NK) > 0;
+    c.bbody = -1; c.bj = -1;
+    if (lane == 0) {
+        int narb = E_I(misc, M_NARB), ncache = E_I(misc, M_NCACHE);
+        // untouched cached arbiters age; they survive collision_persistence = 3 steps (cpSpaceArbiterSetFilter)
+        int n = narb;
+        for (int q = 0; q < ncache; q++) {
+            if (E_I(cmatched, q)) { E_I(cmatched, q) = 0; continue; }
+            uint32_t hd = (uint32_t)E_I(chead, q);
+            uint32_t age = ((hd >> 12) & 3u) + 1u;
+            if (age <= 2u && n < h.cache_slots) {
+                E_I(nchead, n) = (int32_t)((hd & ~(3u << 12)) | (age << 12));
+                for (int i = 0; i < 4; i++) E_R(ncj, 4 * n + i) = E_R(cj, 4 * q + i);
+                E_I(koff, n) = -1;
+                n++;
+            }
+        }
+        E_I(misc, M_NNCACHE) = n;
+        ri_load_vel(e, c);
+        int j0 = h.robot_j0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int s = 0; s < RI_BODIES; s++) { int b = ri_body(e, s); c.minv[s] = T_R(body_minv, b); c.iinv[s] = T_R(body_iinv, b); }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int j = 0; j < RI_JOINTS; j++) {
+            const int kind = RI_KIND(j), jj = j0 + j;
+            const R *p = &T_R(joint_p, jj * JOINT_PARAMS);
+            R *f = c.f[j];
+            c.lim[j] = p[9];
+            if (kind == J_PIVOT || kind == J_PIN) {
+                f[0] = E_R(jr1x, jj); f[1] = E_R(jr1y, jj); f[2] = E_R(jr2x, jj); f[3] = E_R(jr2y, jj);
+                if (kind == J_PIVOT) {
+                    f[4] = E_R(jk0, jj); f[5] = E_R(jk1, jj); f[6] = E_R(jk2, jj); f[7] = E_R(jk3, jj);
+                    f[8] = E_R(jb0, jj); f[9] = E_R(jb1, jj); f[10] = E_R(ja0, jj); f[11] = E_R(ja1, jj);
+                } else {
+                    f[4] = E_R(jk0, jj); f[5] = E_R(jk1, jj); f[6] = E_R(jk2, jj); f[7] = E_R(jb0, jj); f[8] = E_R(ja0, jj);
+                }
+            } else if (kind == J_GEAR) {
+                f[0] = p[0]; f[1] = E_R(jb0, jj); f[2] = E_R(ja0, jj); f[3] = p[5];
+            } else if (kind == J_SPRING) {
+                f[0] = p[0]; f[1] = p[6]; f[2] = R(0);
+                // spring torque, applied right here exactly as cpDampedRotarySpring's preStep does
+                int a = T_I(joint_a, jj), b = T_I(joint_b, jj);
+                R j_spring = R((E_P(ang, a) - E_P(ang, b)) - T_P(p_joint, jj * 7 + 4)) * p[5];
+                c.w[RI_SA(j)] -= j_spring * c.iinv[RI_SA(j)]; c.w[RI_SB(j)] += j_spring * c.iinv[RI_SB(j)];
+            } else if (kind == J_LIMIT) {
+                f[0] = p[0]; f[1] = E_R(jb0, jj); f[2] = E_R(ja0, jj);
+            } else {
+                f[0] = p[0]; f[1] = E_R(jrate, jj); f[2] = E_R(ja0, jj);
+            }
+        }
+        ri_store_vel(e, c);       // the contact warm start (next step) must see the spring impulses
+    } else {
+        int isl = lane_island(e, lane, nl);
+        if (isl >= 0) {
+            int jp = T_I(island_j, isl), jg = jp + 1, b = T_I(joint_b, jp);
+            c.bbody = b; c.bj = jp;
+            c.bminv = T_R(body_minv, b); c.biinv = T_R(body_iinv, b);
+            c.bk[0] = E_R(jk0, jp); c.bk[1] = E_R(jk1, jp); c.bk[2] = E_R(jk2, jp); c.bk[3] = E_R(jk3, jp);
+            c.bbias[0] = E_R(jb0, jp); c.bbias[1] = E_R(jb1, jp); c.bbias[2] = E_R(jb0, jg);
+            c.bacc[0] = E_R(ja0, jp); c.bacc[1] = E_R(ja1, jp); c.bacc[2] = E_R(ja0, jg);
+            c.blim[0] = T_R(joint_p, jp * JOINT_PARAMS + 9); c.blim[1] = T_R(joint_p, jg * JOINT_PARAMS + 9);
+            c.bgear = T_R(joint_p, jg * JOINT_PARAMS);
+        }
     }
-    if (control_after) ph_control(e);
+}
+// solve step B: cached arbiter impulses (lane 0, LDS)
+template <typename R, typename P> MGX_HD void solve_warm_contacts(Env<R, P> &e, int lane) {
+    if (lane == 0) contacts_warm_start(e);
+}
+// solve step C: islands pick up the velocities and apply their cached joint impulses
+template <typename R, typename P> MGX_HD void solve_warm_joints(Env<R, P> &e, SolveCtx<R> &c, int lane, int nl) {
+    if (lane == 0) {
+        ri_load_vel(e, c);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int j = 0; j < RI_JOINTS; j++)
+            reg_apply_cached<R>(RI_KIND(j), c.f[j], c.minv[RI_SA(j)], c.iinv[RI_SA(j)], c.minv[RI_SB(j)], c.iinv[RI_SB(j)],
+                                c.vx[RI_SA(j)], c.vy[RI_SA(j)], c.w[RI_SA(j)], c.vx[RI_SB(j)], c.vy[RI_SB(j)], c.w[RI_SB(j)]);
+    }
+    if (c.bbody >= 0) {
+        bi_load_vel(e, c);
+        // pivot then gear cached impulses (a = static body)
+        c.bvx += c.bacc[0] * c.bminv; c.bvy += c.bacc[1] * c.bminv; c.bw += c.biinv * (R(0) * c.bacc[1] - R(0) * c.bacc[0]);
+        c.bw += c.bacc[2] * c.biinv;
+    } else if (lane != 0 || e.h->n_islands > nl - 1) {
+        // islands without a lane of their own: through LDS (lane 0 takes them all when L is small)
+        if (e.h->n_islands > nl - 1 && lane == 0)
+            for (int k = 0; k < e.h->n_islands; k++) { int jp = T_I(island_j, k); joint_apply_cached(e, jp); joint_apply_cached(e, jp + 1); }
+    }
+}
+// solve step D1 / D2 / D3: one Gauss-Seidel iteration = [publish island velocities] [contacts] [islands]
+template <typename R, typename P> MGX_HD void solve_iter_publish(Env<R, P> &e, SolveCtx<R> &c, int lane) {
+    if (!c.has_contacts) return;
+    if (lane == 0) ri_store_vel(e, c);
+    bi_store_vel(e, c);
+}
+template <typename R, typename P> MGX_HD void solve_iter_contacts(Env<R, P> &e, SolveCtx<R> &c, int lane) {
+    if (!c.has_contacts || lane != 0) return;
+    int nk = E_I(misc, M_NK);
+    for (int k = 0; k < nk; k++) contact_apply_impulse(e, k);
+}
+template <typename R, typename P> MGX_HD void solve_iter_joints(Env<R, P> &e, SolveCtx<R> &c, int lane, int nl) {
+    if (c.has_contacts) { if (lane == 0) ri_load_vel(e, c); bi_load_vel(e, c); }
+    if (lane == 0) {
+        if (e.h->n_islands > nl - 1) {
+            // not enough lanes for the block islands: lane 0 runs them through LDS, in joint order relative to the robot
+            if (!c.has_contacts) { /* LDS copy of block velocities is current: blocks never enter the robot's registers */ }
+            for (int k = 0; k < e.h->n_islands; k++) { int jp = T_I(island_j, k); joint_apply_impulse(e, jp); joint_apply_impulse(e, jp + 1); }
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int j = 0; j < RI_JOINTS; j++)
+            reg_apply_joint<R>(RI_KIND(j), c.f[j], c.lim[j], c.minv[RI_SA(j)], c.iinv[RI_SA(j)], c.minv[RI_SB(j)], c.iinv[RI_SB(j)],
+                               c.vx[RI_SA(j)], c.vy[RI_SA(j)], c.w[RI_SA(j)], c.vx[RI_SB(j)], c.vy[RI_SB(j)], c.w[RI_SB(j)]);
+    }
+    bi_iterate(c);
+}
+// solve step E: write velocities and accumulators back, then next substep's Robot.update
+template <typename R, typename P> MGX_HD void solve_end(Env<R, P> &e, SolveCtx<R> &c, int lane) {
+    if (lane == 0) {
+        ri_store_vel(e, c);
+        int j0 = e.h->robot_j0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int j = 0; j < RI_JOINTS; j++) {
+            const int kind = RI_KIND(j), jj = j0 + j;
+            if (kind == J_PIVOT) { E_R(ja0, jj) = c.f[j][10]; E_R(ja1, jj) = c.f[j][11]; }
+            else if (kind == J_PIN) E_R(ja0, jj) = c.f[j][8];
+            else if (kind != J_SPRING) E_R(ja0, jj) = c.f[j][2];
+        }
+        ph_control(e);
+    }
+    if (c.bbody >= 0) {
+        bi_store_vel(e, c);
+        E_R(ja0, c.bj) = c.bacc[0]; E_R(ja1, c.bj) = c.bacc[1]; E_R(ja0, c.bj + 1) = c.bacc[2];
+    }
 }
 
 // ---------------------------------------------------------------- phase: publish the contact cache for the next substep
@@ -857,6 +1131,18 @@ MGX_HD void reset_env_state(const TmplHeader &h, const int32_t *ti, const P *tp,
     X(ph_broad_write(e, lane, nl))                                 \
     X(ph_narrow(e, lane, nl))                                      \
     X(ph_arbiters_joints(e, lane, nl))                             \
-    X(if (lane == 0) ph_solve(e, iterations, true))                \
+    X(solve_begin(e, ctx, lane, nl))                               \
+    X(solve_warm_contacts(e, lane))                                \
+    X(solve_warm_joints(e, ctx, lane, nl))                         \
+    MGX_SOLVE_ITERATIONS(X)                                        \
+    X(solve_end(e, ctx, lane))                                     \
     X(ph_cache_commit(e, lane, nl))
+
+// `iterations` Gauss-Seidel sweeps; each is three lane-group-synchronised steps (ctx = this lane's SolveCtx)
+#define MGX_SOLVE_ITERATIONS(X)                                    \
+    for (int it_ = 0; it_ < iterations; it_++) {                   \
+        X(solve_iter_publish(e, ctx, lane))                        \
+        X(solve_iter_contacts(e, ctx, lane))                       \
+        X(solve_iter_joints(e, ctx, lane, nl))                     \
+    }
 

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *_
     Env<R, P> e(h, ti, tr, tp, reinterpret_cast<R *>(slab + t.env_off_r), reinterpret_cast<P *>(slab),
                 reinterpret_cast<int32_t *>(slab + t.env_off_i));
     const long stride = n_envs;
+    SolveCtx<R> ctx;
 
 #define SYNC(stmt) stmt; __syncthreads();
     SYNC(ph_init_work(e, lane, nl))

@@ -41,6 +41,9 @@ struct TmplHeader {
     int32_t n_state, n_state_p, n_jacc, cache_slots, max_contacts, max_overlaps;   // n_state_p of the n_state rows are pose rows
     int32_t robot_body, control_body, finger_body[2], motor_joint[2];
     int32_t max_episode_steps, n_words_i, n_words_r, n_words_p;
+    // joint islands (sets of joints that share no dynamic body with any other set): the robot's 10 joints
+    // start at robot_j0 in Robot.setup order; every block contributes {pivot, gear} at island_j[k], +1
+    int32_t robot_j0, n_islands, eye_body[2], pad_[2];
 };
 
 // indices into the consts block
@@ -52,7 +55,7 @@ enum ConstIdx {
 struct TmplOff {
     // ints
     int body_type, body_parent, shape_kind, shape_body, shape_voff, shape_nv;
-    int joint_kind, joint_a, joint_b, joint_acc, pair, state_map, prim_i, body_prow, n_i;
+    int joint_kind, joint_a, joint_b, joint_acc, pair, state_map, prim_i, body_prow, island_j, n_i;
     // reals
     int body_minv, body_iinv, body_init, body_anchor, shape_r, shape_u, lvx, lvy, lnx, lny;
     int joint_p, prim_r, pvx, pvy, consts, n_r;
@@ -74,6 +77,7 @@ struct TmplOff {
         state_map = o; o += h.n_state;
         prim_i = o; o += h.n_prims * PRIM_IWORDS;
         body_prow = o; o += h.n_bodies * 3;   // pose-blob row of (x, y, angle) per body, -1 if not persistent
+        island_j = o; o += h.n_islands;
         n_i = o;
         o = 0;
         body_minv = o; o += h.n_bodies;

@@ -140,6 +140,7 @@ int World::finalize(int max_steps, std::string &err) {
             bodies.push_back({BODY_DYNAMIC, 1.0 / mass, 1.0 / moment_for_circle(mass, 0, radius), e.x, e.y, e.angle, -1, 0, 0, 0x1FF});
             control_body = (int)bodies.size();
             bodies.push_back({BODY_KINEMATIC, 0, 0, e.x, e.y, e.angle, -1, 0, 0, 0});
+            robot_j0 = (int)joints.size();
             JointDef pj = joint(J_PIVOT, control_body, body);              // :255-258
             pj.max_bias = 0; pj.max_force = pv[0];
             joints.push_back(pj);
@@ -150,6 +151,7 @@ int World::finalize(int max_steps, std::string &err) {
             for (int k = 0; k < 2; k++) {                                  // :267-277
                 double em = mass / 10;
                 eye_bodies[k] = (int)bodies.size();
+                eye_body[k] = eye_bodies[k];
                 bodies.push_back({BODY_DYNAMIC, 1.0 / em, 1.0 / moment_for_circle(em, 0, radius), 0, 0, e.angle, -1, 0, 0,
                                   (1 << 2) | (1 << 5)});
                 JointDef sj = joint(J_SPRING, body, eye_bodies[k]);
@@ -280,6 +282,7 @@ int World::finalize(int max_steps, std::string &err) {
                     shapes.push_back({SH_POLY, body, poly_radius, 0.5, group, (int)ei, part});
                 }
             }
+            island_j.push_back((int)joints.size());
             JointDef tj = joint(J_PIVOT, 0, body);                         // :703-707
             tj.max_bias = 0; tj.max_force = pv[3];
             joints.push_back(tj);
@@ -377,6 +380,7 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
     h.finger_body[0] = finger_body[0]; h.finger_body[1] = finger_body[1];
     h.motor_joint[0] = motor_joint[0]; h.motor_joint[1] = motor_joint[1];
     h.max_episode_steps = max_episode_steps;
+    h.robot_j0 = robot_j0; h.n_islands = (int)island_j.size(); h.eye_body[0] = eye_body[0]; h.eye_body[1] = eye_body[1];
     TmplOff o(h);
     h.n_words_i = o.n_i; h.n_words_r = o.n_r; h.n_words_p = o.n_p;
     iw.assign(o.n_i, 0);
@@ -448,6 +452,7 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
     }
     for (int k = 0; k < h.n_pairs; k++) iw[o.pair + k] = pairs[k].first | (pairs[k].second << 8);
     for (int k = 0; k < h.n_state; k++) iw[o.state_map + k] = state_map[k];
+    for (int k = 0; k < h.n_islands; k++) iw[o.island_j + k] = island_j[k];
     for (int k = 0; k < 3 * h.n_bodies; k++) iw[o.body_prow + k] = -1;
     for (int k = 0; k < h.n_state; k++) {
         int m = state_map[k], comp = m & 15, b = (m >> 4) & 0xFF, row = m >> 12;

@@ -67,6 +67,8 @@ struct World {
     int n_jacc = 0, cache_slots = 0, max_contacts = 0, max_overlaps = 0;
     int robot_body = -1, control_body = -1, finger_body[2] = {-1, -1}, motor_joint[2] = {-1, -1};
     int group_ctr = 999;
+    int robot_j0 = -1, eye_body[2] = {-1, -1};
+    std::vector<int> island_j;         // first joint (pivot) of every block's {pivot, gear} pair
 
     int finalize(int max_steps, std::string &err);
     // serialise: header + int words + real words (as double; caller narrows to float if needed)

@@ -49,7 +49,8 @@ template <typename R, typename P> struct Emu : EmuBase {
         const int iterations = 10;
         for (int ei = 0; ei < n_envs; ei++) {
             Env<R, P> e = env();
-#define RUN(stmt) for (int lane = 0; lane < nl; lane++) { stmt; }
+            std::vector<SolveCtx<R>> ctxs(nl);
+#define RUN(stmt) for (int lane = 0; lane < nl; lane++) { SolveCtx<R> &ctx = ctxs[lane]; (void)ctx; stmt; }
             RUN(ph_init_work(e, lane, nl))
             RUN(ph_load_state(e, sp, sf, si, (long)n_envs, (long)ei, lane, nl))
             RUN(ph_refresh_trig(e, lane, nl))
@@ -92,6 +93,7 @@ static void emu_raster(const World &w, const P *sp, int n_envs, int env, int vie
     const int nl = 7;   // odd lane count on purpose
     for (int lane = 0; lane < nl; lane++) raster_setup_bodies<P>(rs, sp, (long)n_envs, (long)env, lane, nl);
     for (int lane = 0; lane < nl; lane++) raster_setup_prims(rs, lane, nl);
+    for (int lane = 0; lane < nl; lane++) raster_setup_items(rs, lane, nl);
     const int bg = 231 | (231 << 8) | (234 << 16);
     const uint64_t all = h.n_prims >= 64 ? ~0ull : ((1ull << h.n_prims) - 1ull);
     if (native) {
@@ -100,14 +102,33 @@ static void emu_raster(const World &w, const P *sp, int n_envs, int env, int vie
             uint8_t *q = out + 3 * (row * NATIVE_RES + col); q[0] = c & 0xFF; q[1] = (c >> 8) & 0xFF; q[2] = (c >> 16) & 0xFF;
         }
     } else {
-        for (int trow = 0; trow < TILES_Y; trow++) for (int tcol = 0; tcol < TILES_X; tcol++) {
-            int base; uint64_t mixed_mask;
-            classify_tile_all(rs, trow * TILES_X + tcol, bg, base, mixed_mask);
-            g_stat[0]++; if (mixed_mask) { g_stat[1]++; g_stat[2] += __builtin_popcountll(mixed_mask); }
+        const int n_items = raster_total_items(rs);
+        std::vector<Item> all_items(n_items);
+        for (int i = 0; i < n_items; i++) all_items[i] = load_item(rs, i);
+        for (int tile = 0; tile < TILES_X * TILES_Y; tile++) {
+            // phase C: whole-tile classification against the full item list
+            float txc, tyc; tile_centre(tile, txc, tyc);
+            ClassState ts; ts.init(bg);
+            classify_items_array(rs, all_items.data(), n_items, txc, tyc, TILE_HX, TILE_HY, ts);
+            g_stat[0]++; if (ts.mixed) { g_stat[1]++; g_stat[2] += __builtin_popcountll(ts.mixed); }
+            // phase T: gather the undecided prims' items (slot order == what the lanes of a wave would hold)
+            std::vector<Item> items;
+            if (ts.mixed) {
+                int n_total = 0;
+                masked_item_index(rs, ts.mixed, 0, n_total);
+                for (int slot = 0; slot < n_total; slot++) { int nt; items.push_back(load_item(rs, masked_item_index(rs, ts.mixed, slot, nt))); }
+            }
+            const int tcol = tile % TILES_X, trow = tile / TILES_X;
             for (int ty = 0; ty < TILE_H; ty++) for (int tx = 0; tx < TILE_W; tx++) {
                 int X = tcol * TILE_W + tx, Y = trow * TILE_H + ty;
-                int c = base;
-                if (mixed_mask) { uint64_t pm = pixel_classify(rs, X, Y, mixed_mask, c); g_stat[3]++; if (pm) { g_stat[4]++; c = pixel_resolve(rs, X, Y, pm, c); } }
+                int c = ts.base;
+                if (ts.mixed) {
+                    ClassState st; st.init(ts.base);
+                    classify_items_array(rs, items.data(), (int)items.size(), 4.0f * X + 2.0f, (float)NATIVE_RES - 4.0f * Y - 2.0f, 1.5f, 1.5f, st);
+                    g_stat[3]++;
+                    c = st.base;
+                    if (st.mixed) { g_stat[4]++; c = pixel_resolve(rs, X, Y, st.mixed, c); }   // phase Q
+                }
                 uint8_t *q = out + 3 * (Y * LORES + X); q[0] = c & 0xFF; q[1] = (c >> 8) & 0xFF; q[2] = (c >> 16) & 0xFF;
             }
         }

@@ -1,7 +1,7 @@
 """GPU probe: k_raster launch time vs state / layout / view (development tool)."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np, torch, ctypes as C
 import magical_amd
 
 def timeit(env, out, view, layout, fill=None, n=20):
@@ -27,6 +27,16 @@ for s in range(60):
     if s in (0, 4, 19, 59):
         print('after %d steps: ego frame %.3f ms, ego stack4 %.3f ms, allo frame %.3f ms' % (
             s + 1, timeit(env, frame, 'ego', 'frame'), timeit(env, stack, 'ego', 'stack4'), timeit(env, frame, 'allo', 'frame')))
+clk = torch.zeros((N, 8), dtype=torch.int64, device='cuda:0')
+env._lib.mgx_engine_debug_raster_clocks(env._engine, C.c_void_p(clk.data_ptr()))
+env.render_frames(stack, view='ego', layout='stack4'); torch.cuda.synchronize()
+env._lib.mgx_engine_debug_raster_clocks(env._engine, None)
+c = clk.cpu().numpy().astype(np.float64)
+names = ['stage tmpl', 'setup (S)', 'tile classify (C)', 'pixel pass (T)', 'queue resolve (Q)']
+prev = 0
+for i, nme in enumerate(names):
+    print('  %-20s cumulative %.1f us (100 MHz wall clock)  delta mean %.1f us  max %.1f us' % (nme, c[:, i].mean() / 100, (c[:, i] - (c[:, i - 1] if i else 0)).mean() / 100, (c[:, i] - (c[:, i - 1] if i else 0)).max() / 100))
+print('  queued pixels per env: mean %.0f max %.0f' % (c[:, 5].mean(), c[:, 5].max()))
 # copy bandwidth reference
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): stack.copy_(stack + 0)
