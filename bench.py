@@ -108,7 +108,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    env.set_timing(True)
+    env.set_timing(8)       # HIP events around every 8th launch of each kernel inside the timed region
     last_score = torch.zeros(n, dtype=torch.float64, device=device)      # per-env result of the rollout
     n_eps = 0
     barrier()
@@ -129,7 +129,7 @@ def main():
         elapsed = float(t.item())
     step_ms = env.read_timing('step')
     rast_ms = env.read_timing('render')
-    env.set_timing(False)
+    env.set_timing(0)
 
     if rank == 0:
         value = n * world * K / elapsed

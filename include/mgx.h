@@ -119,8 +119,9 @@ int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t 
                       const uint8_t *fill_mask, void *stream);
 /* native-resolution (384x384x3, no box filter) render of ONE env, for tests against the oracle/images */
 int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_t *out, int view, void *stream);
-/* HIP-event timing: when enabled every step (which=0) / render (which=1) launch is bracketed by events on
- * the launch stream; timing_read synchronises those events and returns up to `max` most recent launch
+/* HIP-event timing: set_timing(e, n) with n > 0 brackets every n-th step (which=0) / render (which=1) launch with
+ * events on the launch stream (n = 1: every launch; event records serialise dispatch, so sampling keeps the
+ * measured region undisturbed); 0 switches it off; timing_read synchronises those events and returns up to `max` most recent launch
  * durations in ms (oldest first) and clears the log. */
 int mgx_engine_set_timing(mgx_engine *e, int enable);
 int mgx_engine_timing_read(mgx_engine *e, int which, float *ms, int max);

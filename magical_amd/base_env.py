@@ -312,8 +312,9 @@ class BaseEnv(abc.ABC):
         return views
 
     # ------------------------------------------------------------------ kernel timing (bench.py)
-    def set_timing(self, on):
-        nat.check(self._lib.mgx_engine_set_timing(self._engine, int(bool(on))))
+    def set_timing(self, every):
+        """Bracket every `every`-th kernel launch with HIP events (0 = off)."""
+        nat.check(self._lib.mgx_engine_set_timing(self._engine, int(every)))
 
     def read_timing(self, which, max_n=4096):
         buf = (C.c_float * max_n)()

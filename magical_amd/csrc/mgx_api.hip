@@ -39,7 +39,8 @@ struct mgx_engine {
     TmplDev tdev{};
     RasterDev rdev{};
     size_t lds_step = 0, lds_raster = 0;
-    bool timing = false;
+    int timing = 0;             // 0 = off, n = bracket every n-th launch of each kind with HIP events
+    int launch_count[2] = {0, 0};
     int dbg_iterations = -1;    // development probe: override the solver iteration count
     std::vector<hipEvent_t> ev[2];      // per kernel kind: start/stop pairs
     int ev_count[2] = {0, 0};
@@ -238,8 +239,9 @@ static int launch_step(mgx_engine *e, void *sp, void *sf, int32_t *si, const int
     return fail(MGX_ERR_ARG, "lanes_per_env must be 4, 8, 16, 32 or 64");
 }
 
+static bool timing_this_launch(const mgx_engine *e, int which) { return e->timing > 0 && e->launch_count[which] % e->timing == 0; }
 static int timing_begin(mgx_engine *e, int which, hipStream_t st) {
-    if (!e->timing) return MGX_OK;
+    if (!timing_this_launch(e, which)) return MGX_OK;
     if (e->ev[which].empty()) {
         e->ev[which].resize(2 * TIMING_RING);
         for (auto &ev : e->ev[which]) HIP_OK(hipEventCreate(&ev));
@@ -249,7 +251,8 @@ static int timing_begin(mgx_engine *e, int which, hipStream_t st) {
     return MGX_OK;
 }
 static int timing_end(mgx_engine *e, int which, hipStream_t st) {
-    if (!e->timing) return MGX_OK;
+    if (!timing_this_launch(e, which)) { e->launch_count[which]++; return MGX_OK; }
+    e->launch_count[which]++;
     int slot = e->ev_count[which] % TIMING_RING;
     HIP_OK(hipEventRecord(e->ev[which][2 * slot + 1], st));
     e->ev_count[which]++;
@@ -411,8 +414,9 @@ int mgx_engine_debug_raster_clocks(mgx_engine *e, void *buf) { if (e) e->rdev.db
 int mgx_engine_debug_iterations(mgx_engine *e, int it) { if (e) e->dbg_iterations = it; return MGX_OK; }
 int mgx_engine_set_timing(mgx_engine *e, int enable) {
     if (!e) return fail(MGX_ERR_ARG, "engine is NULL");
-    e->timing = enable != 0;
+    e->timing = enable < 0 ? 0 : enable;
     e->ev_count[0] = e->ev_count[1] = 0;
+    e->launch_count[0] = e->launch_count[1] = 0;
     return MGX_OK;
 }
 int mgx_engine_timing_read(mgx_engine *e, int which, float *ms, int max) {

@@ -231,6 +231,28 @@ MGX_HD double lineloop_alpha(const Raster &rs, int k, double x, double y) {
     return best;
 }
 
+// as lineloop_alpha, restricted to the segments in `segmask` (the others were excluded by the fp32 conservative test)
+MGX_HD double lineloop_alpha_masked(const Raster &rs, int k, double x, double y, uint32_t segmask) {
+    int vo = rs.prim_voff(k), stipple = rs.prim_stipple(k);
+    double hw = RD(prad, k), best = 0.0;
+    for (; segmask; segmask &= segmask - 1) {
+        const int i = __builtin_ctz(segmask);
+        double a = RD(ea, vo + i), b = RD(eb, vo + i);
+        double e = a * x + b * y + RD(ec, vo + i);
+        if (r_abs(e) >= hw) continue;
+        double ax = RD(svx, vo + i), ay = RD(svy, vo + i), len = RD(elen, vo + i);
+        double sl = r_clamp((x - ax) * b - (y - ay) * a, 0.0, len);
+        double qx = x - (ax + b * sl), qy = y - (ay - a * sl);
+        double alpha = r_clamp01(hw - sqrt(qx * qx + qy * qy));
+        if (alpha > 0.0 && stipple) {
+            int bit = ((int)rz_floor(RD(earc, vo + i) + sl)) & 15;
+            if (!((stipple >> bit) & 1)) alpha = 0.0;
+        }
+        if (alpha > best) best = alpha;
+    }
+    return best;
+}
+
 // one 384-grid sample, painter's order over the primitives in `mask` (bit k = prim k), starting from `base_rgb`
 MGX_HD int raster_sample(const Raster &rs, double x, double y, uint64_t mask, int base_rgb) {
     int r = base_rgb & 0xFF, g = (base_rgb >> 8) & 0xFF, b = (base_rgb >> 16) & 0xFF;
@@ -262,10 +284,11 @@ enum { IT_EDGE = 0, IT_NGON = 1, IT_SEG = 2 };
 constexpr int IT_LAST = 4;      // meta bit: last item of its primitive
 struct Item {
     float a, b, c;              // EDGE/SEG: normalised line a x + b y + c;  NGON: centre x, y, apothem
-    float g0, g1, g2, g3;       // SEG: start x, start y, length, half width;  NGON: g0 = circumradius
+    float g0, g1, g2, g3;       // EDGE: g0 / g1 = extent over a 4x4 block / a tile;  SEG: start x, y, length, half width;  NGON: g0 = circumradius
     int meta;                   // kind | IT_LAST | prim << 8
 };
 constexpr int TILE_W = 16, TILE_H = 4, TILES_X = LORES / TILE_W, TILES_Y = LORES / TILE_H;
+constexpr float TILE_HX = 2.0f * TILE_W - 0.5f, TILE_HY = 2.0f * TILE_H - 0.5f;
 
 MGX_HD int prim_item_count(const Raster &rs, int k) { return rs.prim_kind(k) == PR_NGON ? 1 : rs.prim_nv(k); }
 
@@ -285,8 +308,15 @@ MGX_HD void raster_setup_items(Raster &rs, int lane, int nl) {
         } else {
             for (int i = 0; i < nv; i++) {
                 it[i].a = (float)RD(ea, vo + i); it[i].b = (float)RD(eb, vo + i); it[i].c = (float)RD(ec, vo + i);
-                it[i].g0 = (float)RD(svx, vo + i); it[i].g1 = (float)RD(svy, vo + i); it[i].g2 = (float)RD(elen, vo + i);
-                it[i].g3 = kind == PR_LINELOOP ? (float)RD(prad, k) : 0.0f;
+                if (kind == PR_LINELOOP) {
+                    it[i].g0 = (float)RD(svx, vo + i); it[i].g1 = (float)RD(svy, vo + i); it[i].g2 = (float)RD(elen, vo + i);
+                    it[i].g3 = (float)RD(prad, k);
+                } else {
+                    // conservative half-extents of the edge function over a 4x4 sample block / over a whole tile
+                    float fa = r_abs(it[i].a), fb = r_abs(it[i].b);
+                    it[i].g0 = 1.5f * (fa + fb) + CLASS_EPS_F; it[i].g1 = TILE_HX * fa + TILE_HY * fb + CLASS_EPS_F;
+                    it[i].g2 = it[i].g3 = 0.0f;
+                }
                 it[i].meta = (kind == PR_POLY ? IT_EDGE : IT_SEG) | (i == nv - 1 ? IT_LAST : 0) | (k << 8);
             }
         }
@@ -312,54 +342,58 @@ MGX_HD int masked_item_index(const Raster &rs, uint64_t mask, int slot, int &n_t
     return found;
 }
 
-// per-lane classification state carried across item chunks
+// per-lane classification state carried across item chunks.  For the primitive being consumed, `lo` / `hi` collect
+//   lo = min over its items of (worst-case inside margin)   -> NONE  when lo < 0 (some edge excludes the whole block)
+//   hi = min over its items of (best-case  inside margin)   -> ALL   when hi > 0 (every edge contains the whole block)
+// (for line loops `lo` is the max touch margin: the block may be touched when lo >= 0).
 struct ClassState {
-    uint64_t mixed; int base; bool decided, none, partial, hit;
-    MGX_HD void init(int bg) { mixed = 0; base = bg; decided = false; none = false; partial = false; hit = false; }
+    uint64_t mixed; int base; int decided; float lo, hi;
+    MGX_HD void init(int bg) { mixed = 0; base = bg; decided = 0; lo = 1e30f; hi = 1e30f; }
 };
-// Consume one item for the sample block centred at (xc, yc) with half extents (hx, hy) (sample centres: a 4x4
-// block has hx = hy = 1.5).  ALL = every sample inside an opaque prim, NONE = no sample touched, MIXED = decide
-// per sample; conservative by CLASS_EPS_F.  `I` is wave-uniform on the device (readlane), so every branch on its
-// kind is a scalar branch.
-MGX_HD void classify_item(const Raster &rs, const Item &I, float xc, float yc, float hx, float hy, ClassState &st) {
+constexpr float BIG_F = 1e30f;
+// Consume one item for the sample block centred at (xc, yc): TILE = whole 16x4-pixel tile (half extents TILE_HX/HY),
+// otherwise one output pixel's 4x4 sample block (half extents 1.5).  ALL = every sample inside an opaque prim,
+// NONE = no sample touched, MIXED = decide per sample; conservative by CLASS_EPS_F.  `I` is wave-uniform on the
+// device (readlane), so the branches on its kind are scalar.
+template <bool TILE> MGX_HD void classify_item(const Raster &rs, const Item &I, float xc, float yc, ClassState &st) {
     const int kind = I.meta & 3;
+    const float hx = TILE ? TILE_HX : 1.5f, hy = TILE ? TILE_HY : 1.5f;
     if (kind == IT_EDGE) {
-        float e = I.a * xc + I.b * yc + I.c;
-        float ext = hx * r_abs(I.a) + hy * r_abs(I.b) + CLASS_EPS_F;
-        st.none |= e + ext < 0.0f;
-        st.partial |= e - ext < 0.0f;
+        const float e = I.a * xc + (I.b * yc + I.c), ext = TILE ? I.g1 : I.g0;
+        st.lo = r_min(st.lo, e + ext);
+        st.hi = r_min(st.hi, e - ext);
     } else if (kind == IT_NGON) {
-        float qx = r_abs(xc - I.a), qy = r_abs(yc - I.b);
-        float nx = r_max(qx - hx, 0.0f), ny = r_max(qy - hy, 0.0f);          // nearest point of the rect
-        float fx = qx + hx, fy = qy + hy;                                      // farthest corner
-        float apo = I.c - CLASS_EPS_F, rad = I.g0 + CLASS_EPS_F;
-        st.partial = !(apo > 0.0f && fx * fx + fy * fy < apo * apo);
-        st.none = nx * nx + ny * ny > rad * rad;
+        const float qx = r_abs(xc - I.a), qy = r_abs(yc - I.b);
+        const float nx = r_max(qx - hx, 0.0f), ny = r_max(qy - hy, 0.0f);        // nearest point of the rect
+        const float fx = qx + hx, fy = qy + hy;                                    // farthest corner
+        const float apo = I.c - CLASS_EPS_F, rad = I.g0 + CLASS_EPS_F;
+        st.lo = rad * rad - (nx * nx + ny * ny);
+        st.hi = apo > 0.0f ? apo * apo - (fx * fx + fy * fy) : -1.0f;
     } else {
-        float hw = I.g3 + CLASS_EPS_F;
-        float e = I.a * xc + I.b * yc + I.c;
-        bool off_line = r_abs(e) - (hx * r_abs(I.a) + hy * r_abs(I.b)) > hw;   // off the carrier line
-        float sl = (xc - I.g0) * I.b - (yc - I.g1) * I.a;                        // along the segment
-        float es = hx * r_abs(I.b) + hy * r_abs(I.a);
-        bool off_ends = sl + es < -hw || sl - es > I.g2 + hw;                   // beyond its ends
-        st.hit |= !(off_line || off_ends);
+        const float hw = I.g3 + CLASS_EPS_F;
+        const float e = I.a * xc + (I.b * yc + I.c);
+        const float sl = (xc - I.g0) * I.b - (yc - I.g1) * I.a;                    // along the segment
+        const float el = hx * r_abs(I.a) + hy * r_abs(I.b), es = hx * r_abs(I.b) + hy * r_abs(I.a);
+        // touch margin: >= 0 iff the block is within hw of the carrier line and not beyond the segment's ends
+        const float t = r_min(r_min(hw + el - r_abs(e), sl + es + hw), I.g2 + hw + es - sl);
+        st.lo = st.lo >= BIG_F ? t : r_max(st.lo, t);
     }
     if (I.meta & IT_LAST) {
         const int k = I.meta >> 8;
         if (!st.decided) {
-            if (kind == IT_SEG) { if (st.hit) st.mixed |= 1ull << k; }
-            else if (!st.none) {
-                if (st.partial) st.mixed |= 1ull << k;
-                else { st.base = rs.prim_rgb(k); st.decided = true; }      // topmost covering prim: everything below is hidden
+            if (kind == IT_SEG) { if (st.lo >= 0.0f) st.mixed |= 1ull << k; }
+            else if (!(st.lo < 0.0f)) {
+                if (st.hi > 0.0f) { st.base = rs.prim_rgb(k); st.decided = 1; }      // topmost covering prim hides the rest
+                else st.mixed |= 1ull << k;
             }
         }
-        st.none = false; st.partial = false; st.hit = false;
+        st.lo = BIG_F; st.hi = BIG_F;
     }
 }
 
 // host-side item source (the device uses registers + readlane, see mgx_raster.hip)
-MGX_HD void classify_items_array(const Raster &rs, const Item *items, int n, float xc, float yc, float hx, float hy, ClassState &st) {
-    for (int i = 0; i < n && !st.decided; i++) classify_item(rs, items[i], xc, yc, hx, hy, st);
+template <bool TILE> MGX_HD void classify_items_array(const Raster &rs, const Item *items, int n, float xc, float yc, ClassState &st) {
+    for (int i = 0; i < n && !st.decided; i++) classify_item<TILE>(rs, items[i], xc, yc, st);
 }
 
 MGX_HD void tile_centre(int tile, float &xc, float &yc) {
@@ -367,21 +401,148 @@ MGX_HD void tile_centre(int tile, float &xc, float &yc) {
     const int gx0 = 4 * TILE_W * tcol, gy1 = NATIVE_RES - 1 - 4 * TILE_H * trow, gy0 = gy1 - 4 * TILE_H + 1;
     xc = 0.5f * (gx0 + gx0 + 4 * TILE_W); yc = 0.5f * (gy0 + gy1 + 1);
 }
-constexpr float TILE_HX = 2.0f * TILE_W - 0.5f, TILE_HY = 2.0f * TILE_H - 0.5f;
-
-// exact 4x4-sample mean of an undecided pixel, one sample at a time (the device spreads the 16 samples over 16 lanes)
-MGX_HD int pixel_sample(const Raster &rs, int X, int Y, int s, uint64_t mixed, int base) {
-    return raster_sample(rs, 4.0 * X + (s & 3) + 0.5, (double)NATIVE_RES - 0.5 - 4.0 * Y - (s >> 2), mixed, base);
+// ---------------------------------------------------------------- resolving an undecided pixel (one lane per pixel)
+// 16-bit coverage of the 4x4 sample block whose top-left sample is (x0, y0); bit 4*j + i = sample (x0 + i, y0 - j).
+// fp32 first: a sample is decided in fp32 when |E| > CLASS_EPS_F, otherwise that one sample is re-evaluated in fp64
+// against the fp64 edge function -- the result equals the all-fp64 test.
+MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, int X, int Y) {
+    const int nv = rs.prim_nv(k), vo = rs.prim_voff(k), i0 = RI(pitem, k) & 0xFFFF;
+    const float x0 = 4.0f * X + 0.5f, y0 = (float)NATIVE_RES - 0.5f - 4.0f * Y;
+    const Item *items = reinterpret_cast<const Item *>(&RI(items, 0)) + i0;
+    uint32_t cov = 0xFFFFu;
+    for (int e = 0; e < nv && cov; e++) {
+        const float a = items[e].a, b = items[e].b;
+        float row = a * x0 + b * y0 + items[e].c;
+        // block spans x0..x0+3, y0-3..y0: worst / best corner value of this edge function
+        const float lo = row + r_min(0.0f, 3.0f * a) - r_max(0.0f, 3.0f * b);
+        if (lo >= CLASS_EPS_F) continue;                                   // whole block inside this edge
+        const float hi = row + r_max(0.0f, 3.0f * a) - r_min(0.0f, 3.0f * b);
+        if (hi < -CLASS_EPS_F) return 0u;                                  // whole block outside
+        uint32_t in = 0, amb = 0;
+        for (int j = 0; j < 4; j++) {
+            float v = row;
+            for (int i = 0; i < 4; i++) {
+                in |= (v >= CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
+                amb |= (r_abs(v) < CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
+                v += a;
+            }
+            row -= b;
+        }
+        while (amb) {                                                       // rare: exact fp64 for the ambiguous samples
+            int sidx = __builtin_ctz(amb);
+            amb &= amb - 1;
+            double x = 4.0 * X + (sidx & 3) + 0.5, y = (double)NATIVE_RES - 0.5 - 4.0 * Y - (sidx >> 2);
+            if (RD(ea, vo + e) * x + RD(eb, vo + e) * y + RD(ec, vo + e) >= 0.0) in |= 1u << sidx;
+        }
+        cov &= in;
+    }
+    return cov;
 }
-// cv2 INTER_AREA integer-factor path: saturate_cast<uchar>(sum * (1/16)) = round half to even
-MGX_HD int mean16(int sr, int sg, int sb) {
+MGX_HD uint32_t ngon_coverage16(const Raster &rs, int k, int X, int Y) {
+    const Item &it = reinterpret_cast<const Item *>(&RI(items, 0))[RI(pitem, k) & 0xFFFF];
+    const float x0 = 4.0f * X + 0.5f - it.a, y0 = (float)NATIVE_RES - 0.5f - 4.0f * Y - it.b;
+    const float apo = it.c - CLASS_EPS_F, rad = it.g0 + CLASS_EPS_F, apo2 = apo > 0.0f ? apo * apo : -1.0f, rad2 = rad * rad;
+    uint32_t cov = 0;
+    for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 4; i++) {
+            float qx = x0 + i, qy = y0 - j, d2 = qx * qx + qy * qy;
+            bool in = d2 <= apo2;
+            if (!in && d2 <= rad2)   // annulus between in- and circum-circle (plus fp32 margin): exact fp64 sector test
+                in = ngon_contains(rs, k, 4.0 * X + i + 0.5, (double)NATIVE_RES - 0.5 - 4.0 * Y - j);
+            cov |= (in ? 1u : 0u) << (4 * j + i);
+        }
+    return cov;
+}
+// samples of the block that a line loop may touch (alpha > 0 possible), fp32 conservative
+MGX_HD uint32_t lineloop_touch16(const Raster &rs, int k, int X, int Y, uint32_t &segmask) {
+    segmask = 0;
+    const int nv = rs.prim_nv(k), i0 = RI(pitem, k) & 0xFFFF;
+    const float x0 = 4.0f * X + 0.5f, y0 = (float)NATIVE_RES - 0.5f - 4.0f * Y;
+    const Item *items = reinterpret_cast<const Item *>(&RI(items, 0)) + i0;
+    uint32_t touch = 0;
+    for (int e = 0; e < nv; e++) {
+        const float a = items[e].a, b = items[e].b, hw = items[e].g3 + CLASS_EPS_F;
+        float row = a * x0 + b * y0 + items[e].c;
+        const float lo = row + r_min(0.0f, 3.0f * a) - r_max(0.0f, 3.0f * b), hi = row + r_max(0.0f, 3.0f * a) - r_min(0.0f, 3.0f * b);
+        if (lo > hw || hi < -hw) continue;                                  // block entirely off the carrier line
+        segmask |= 1u << e;
+        for (int j = 0; j < 4; j++) {
+            float v = row;
+            for (int i = 0; i < 4; i++) { touch |= (r_abs(v) <= hw ? 1u : 0u) << (4 * j + i); v += a; }
+            row -= b;
+        }
+    }
+    return touch;
+}
+
+// exact 4x4-sample mean of an undecided pixel.  Opaque prims (front to back) claim samples through coverage masks;
+// at a translucent line loop the still-unclaimed samples it may touch are blended individually in fp64 (painter's
+// order over everything from the line down), the others keep going through masks.
+MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int base) {
+    uint32_t remaining = 0xFFFFu;
+    int sr = 0, sg = 0, sb = 0;
+    uint64_t m = mixed;
+    while (m && remaining) {
+        const int k = 63 - __builtin_clzll(m);
+        m &= ~(1ull << k);
+        const int kind = rs.prim_kind(k);
+        uint32_t cov;
+        if (kind == PR_LINELOOP) {
+            uint32_t segmask;
+            cov = lineloop_touch16(rs, k, X, Y, segmask) & remaining;
+            if (cov) {
+                // colour under the line for each touched sample: coverage masks of the opaque prims below it
+                // (front to back); a second line loop in that stack falls back to the generic per-sample painter
+                constexpr int MAXL = 4;
+                uint32_t lcov[MAXL]; int lcol[MAXL]; int nlow = 0; bool generic = false;
+                const uint64_t lower = mixed & ((1ull << k) - 1ull);
+                for (uint64_t lm = lower; lm;) {
+                    const int kk = 63 - __builtin_clzll(lm);
+                    lm &= ~(1ull << kk);
+                    const int kd = rs.prim_kind(kk);
+                    if (kd == PR_LINELOOP || nlow == MAXL) { generic = true; break; }
+                    lcov[nlow] = kd == PR_POLY ? poly_coverage16(rs, kk, X, Y) : ngon_coverage16(rs, kk, X, Y);
+                    lcol[nlow] = rs.prim_rgb(kk);
+                    nlow++;
+                }
+                const int col = rs.prim_rgb(k);
+                const double lr = (double)(col & 0xFF), lg = (double)((col >> 8) & 0xFF), lb = (double)((col >> 16) & 0xFF);
+                for (uint32_t t = cov; t; t &= t - 1) {
+                    const int sidx = __builtin_ctz(t);
+                    const double x = 4.0 * X + (sidx & 3) + 0.5, y = (double)NATIVE_RES - 0.5 - 4.0 * Y - (sidx >> 2);
+                    int c;
+                    if (generic) {
+                        c = raster_sample(rs, x, y, mixed & ((2ull << k) - 1ull), base);
+                    } else {
+                        c = base;
+                        for (int q = nlow - 1; q >= 0; q--) if ((lcov[q] >> sidx) & 1u) c = lcol[q];     // back to front
+                        const double a = lineloop_alpha_masked(rs, k, x, y, segmask);
+                        if (a > 0.0) {
+                            const int r = (int)rz_floor(a * lr + (1.0 - a) * (double)(c & 0xFF) + 0.5);
+                            const int g = (int)rz_floor(a * lg + (1.0 - a) * (double)((c >> 8) & 0xFF) + 0.5);
+                            const int b = (int)rz_floor(a * lb + (1.0 - a) * (double)((c >> 16) & 0xFF) + 0.5);
+                            c = r | (g << 8) | (b << 16);
+                        }
+                    }
+                    sr += c & 0xFF; sg += (c >> 8) & 0xFF; sb += (c >> 16) & 0xFF;
+                }
+            }
+        } else {
+            cov = (kind == PR_POLY ? poly_coverage16(rs, k, X, Y) : ngon_coverage16(rs, k, X, Y)) & remaining;
+            if (cov) {
+                const int n = __builtin_popcount(cov), col = rs.prim_rgb(k);
+                sr += n * (col & 0xFF); sg += n * ((col >> 8) & 0xFF); sb += n * ((col >> 16) & 0xFF);
+            }
+        }
+        remaining &= ~cov;
+    }
+    if (remaining) {
+        const int n = __builtin_popcount(remaining);
+        sr += n * (base & 0xFF); sg += n * ((base >> 8) & 0xFF); sb += n * ((base >> 16) & 0xFF);
+    }
+    // cv2 INTER_AREA integer-factor path: saturate_cast<uchar>(sum * (1/16)) = round half to even
     int r = (sr + 7 + ((sr >> 4) & 1)) >> 4, g = (sg + 7 + ((sg >> 4) & 1)) >> 4, b = (sb + 7 + ((sb >> 4) & 1)) >> 4;
     return r | (g << 8) | (b << 16);
-}
-MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int base) {
-    int sr = 0, sg = 0, sb = 0;
-    for (int s = 0; s < 16; s++) { int c = pixel_sample(rs, X, Y, s, mixed, base); sr += c & 0xFF; sg += (c >> 8) & 0xFF; sb += (c >> 16) & 0xFF; }
-    return mean16(sr, sg, sb);
 }
 
 }  // namespace mgx

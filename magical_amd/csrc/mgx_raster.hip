@@ -30,6 +30,28 @@ constexpr int N_TILES = TILES_X * TILES_Y;
 constexpr int QCAP = 2048;     // LDS queue of undecided pixels per env (overflow is resolved in place)
 
 // FlattenFrameStack shift of one pixel: 12 B read-modify-write (or 4 copies of the frame after a reset)
+struct OldPx { uint32_t o0, o1, o2; };
+__device__ __forceinline__ OldPx load_stack4(const uint8_t *frame, int X, int Y) {
+    const uint32_t *px = reinterpret_cast<const uint32_t *>(frame + (long)(Y * LORES + X) * 12);
+    OldPx o; o.o0 = px[0]; o.o1 = px[1]; o.o2 = px[2];
+    return o;
+}
+// same shift with the old pixel already in registers (loaded a tile ahead so its latency hides behind classification)
+__device__ __forceinline__ void store_stack4_pre(uint8_t *frame, int X, int Y, int c, bool fill, const OldPx &o) {
+    uint32_t *px = reinterpret_cast<uint32_t *>(frame + (long)(Y * LORES + X) * 12);
+    const uint32_t r = c & 0xFF, g = (c >> 8) & 0xFF, b = (c >> 16) & 0xFF;
+    uint32_t d0, d1, d2;
+    if (fill) {
+        d0 = r | (g << 8) | (b << 16) | (r << 24);
+        d1 = g | (b << 8) | (r << 16) | (g << 24);
+        d2 = b | (r << 8) | (g << 16) | (b << 24);
+    } else {
+        d0 = (o.o0 >> 24) | (o.o1 << 8);
+        d1 = (o.o1 >> 24) | (o.o2 << 8);
+        d2 = (o.o2 >> 24) | ((uint32_t)c << 8);
+    }
+    px[0] = d0; px[1] = d1; px[2] = d2;
+}
 __device__ __forceinline__ void store_stack4(uint8_t *frame, int X, int Y, int c, bool fill) {
     uint32_t *px = reinterpret_cast<uint32_t *>(frame + (long)(Y * LORES + X) * 12);
     const uint32_t r = c & 0xFF, g = (c >> 8) & 0xFF, b = (c >> 16) & 0xFF;
@@ -67,18 +89,19 @@ struct RegItems {
         return r;
     }
 };
-// consume items [0, n) held one per lane; stops early once every lane of the wave is decided
-__device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegItems &src, int n, float xc, float yc, float hx, float hy,
+// consume items [0, n) held one per lane; stops at a primitive boundary once every lane of the wave is decided
+template <bool TILE>
+__device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegItems &src, int n, float xc, float yc,
                                                     ClassState &st, bool active) {
     for (int i = 0; i < n; i++) {
-        if (__all(st.decided || !active)) break;
         const Item I = src.get(i);
-        classify_item(rs, I, xc, yc, hx, hy, st);
+        classify_item<TILE>(rs, I, xc, yc, st);
+        if ((I.meta & IT_LAST) && __all(st.decided || !active)) break;
     }
 }
 
 template <typename P, int LAYOUT>
-__global__ __launch_bounds__(256) void k_raster(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(256, 3) void k_raster(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
                                                 long env_stride, int view, const uint8_t *__restrict__ fill_mask, int n_envs) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
@@ -123,7 +146,8 @@ __global__ __launch_bounds__(256) void k_raster(RasterDev t, const P *__restrict
                 const int idx = c0 + lane;
                 src.my = load_item(rs, idx < n_items ? idx : 0);
                 const int n = n_items - c0 < 64 ? n_items - c0 : 64;
-                classify_items_regs(rs, src, n, xc, yc, TILE_HX, TILE_HY, st, active);
+                classify_items_regs<true>(rs, src, n, xc, yc, st, active);
+                if (__all(st.decided || !active)) break;
             }
             if (active) { tile_base[tile] = st.base; tile_mixed[tile] = st.mixed; }
         }
@@ -135,13 +159,20 @@ __global__ __launch_bounds__(256) void k_raster(RasterDev t, const P *__restrict
     const int tx = lane & (TILE_W - 1), ty = lane >> 4;
     const bool fill = LAYOUT == 1 && fill_mask != nullptr && fill_mask[env] != 0;
     uint8_t *frame = out + env * env_stride;
+    OldPx next_px{0, 0, 0};
+    if (LAYOUT == 1 && !fill) next_px = load_stack4(frame, (wave % TILES_X) * TILE_W + tx, (wave / TILES_X) * TILE_H + ty);
     for (int tile = wave; tile < N_TILES; tile += 4) {
         const int tcol = tile % TILES_X, trow = tile / TILES_X;
         const int X = tcol * TILE_W + tx, Y = trow * TILE_H + ty;
         const uint64_t tmixed = tile_mixed[tile];
         int c = tile_base[tile];
+        // STACK4: the old pixel of this tile was fetched one tile ago; fetch the next tile's now
+        const OldPx cur_px = next_px;
+        if (LAYOUT == 1 && !fill && tile + 4 < N_TILES) {
+            const int nt = tile + 4;
+            next_px = load_stack4(frame, (nt % TILES_X) * TILE_W + tx, (nt / TILES_X) * TILE_H + ty);
+        }
         if (tmixed == 0) {
-            // decided for the whole tile: packed stores
             if (LAYOUT == 0) {
                 // 16 pixels x 3 B = 12 dwords per tile row: lanes tx < 12 each assemble one dword
                 const int d = tx < 12 ? tx : 0;
@@ -150,12 +181,12 @@ __global__ __launch_bounds__(256) void k_raster(RasterDev t, const P *__restrict
                 uint32_t w = o == 0 ? (c0 | (c1 << 24)) : (o == 1 ? ((c0 >> 8) | (c1 << 16)) : ((c0 >> 16) | (c1 << 8)));
                 if (tx < 12) reinterpret_cast<uint32_t *>(frame + (long)(Y * LORES + tcol * TILE_W) * 3)[d] = w;
             } else {
-                store_stack4(frame, X, Y, c, fill);
+                store_stack4_pre(frame, X, Y, c, fill, cur_px);
             }
             continue;
         }
-        // undecided tile: gather the items of its undecided prims (front to back), one per lane, and classify
-        // every pixel's 4x4 sample block against them
+        // gather the items of the tile's undecided prims (front to back), one per lane, and classify every
+        // pixel's 4x4 sample block against them
         ClassState st; st.init(c);
         const float xc = 4.0f * X + 2.0f, yc = (float)NATIVE_RES - 4.0f * Y - 2.0f;
         int n_total = 0;
@@ -164,12 +195,12 @@ __global__ __launch_bounds__(256) void k_raster(RasterDev t, const P *__restrict
             const int idx = masked_item_index(rs, tmixed, c0 + lane, n_total);
             src.my = load_item(rs, idx >= 0 ? idx : 0);
             const int n = n_total - c0 < 64 ? n_total - c0 : 64;
-            classify_items_regs(rs, src, n, xc, yc, 1.5f, 1.5f, st, true);
+            classify_items_regs<false>(rs, src, n, xc, yc, st, true);
             if (c0 + 64 >= n_total) break;
         }
         c = st.base;
         if (st.mixed == 0) {
-            if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
+            if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4_pre(frame, X, Y, c, fill, cur_px);
         } else {
             // undecided pixel: queue it for phase Q so that finished lanes do not wait for it
             int slot = atomicAdd(q_count, 1);
@@ -177,30 +208,19 @@ __global__ __launch_bounds__(256) void k_raster(RasterDev t, const P *__restrict
                 q_mask[slot] = st.mixed; q_pix[slot] = X | (Y << 8); q_base[slot] = c;
             } else {
                 c = pixel_resolve(rs, X, Y, st.mixed, c);
-                if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
+                if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4_pre(frame, X, Y, c, fill, cur_px);
             }
         }
     }
     __syncthreads();
     CLK(3)
-    // phase Q: 16 lanes per queued pixel, one exact fp64 sample each, reduced with cross-lane shuffles
+    // phase Q: the queue is dense, so every lane resolves one undecided pixel (fp32 coverage masks, fp64 only for
+    // ambiguous samples and line blending)
     const int nq = *q_count < QCAP ? *q_count : QCAP;
-    const int sub = tid & 15;
-    for (int q0 = 0; q0 < nq; q0 += 16) {
-        const int q = q0 + (tid >> 4);
-        int sr = 0, sg = 0, sb = 0, X = 0, Y = 0;
-        if (q < nq) {
-            X = q_pix[q] & 0xFF; Y = q_pix[q] >> 8;
-            const int cs = pixel_sample(rs, X, Y, sub, q_mask[q], q_base[q]);
-            sr = cs & 0xFF; sg = (cs >> 8) & 0xFF; sb = (cs >> 16) & 0xFF;
-        }
-        int rg = sr | (sg << 16);
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) { rg += __shfl_xor(rg, m, 16); sb += __shfl_xor(sb, m, 16); }
-        if (q < nq && sub == 0) {
-            const int c = mean16(rg & 0xFFFF, rg >> 16, sb);
-            if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
-        }
+    for (int i = tid; i < nq; i += 256) {
+        const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;
+        const int c = pixel_resolve(rs, X, Y, q_mask[i], q_base[i]);
+        if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
     }
     __syncthreads();
     CLK(4)

@@ -109,7 +109,7 @@ static void emu_raster(const World &w, const P *sp, int n_envs, int env, int vie
             // phase C: whole-tile classification against the full item list
             float txc, tyc; tile_centre(tile, txc, tyc);
             ClassState ts; ts.init(bg);
-            classify_items_array(rs, all_items.data(), n_items, txc, tyc, TILE_HX, TILE_HY, ts);
+            classify_items_array<true>(rs, all_items.data(), n_items, txc, tyc, ts);
             g_stat[0]++; if (ts.mixed) { g_stat[1]++; g_stat[2] += __builtin_popcountll(ts.mixed); }
             // phase T: gather the undecided prims' items (slot order == what the lanes of a wave would hold)
             std::vector<Item> items;
@@ -124,7 +124,7 @@ static void emu_raster(const World &w, const P *sp, int n_envs, int env, int vie
                 int c = ts.base;
                 if (ts.mixed) {
                     ClassState st; st.init(ts.base);
-                    classify_items_array(rs, items.data(), (int)items.size(), 4.0f * X + 2.0f, (float)NATIVE_RES - 4.0f * Y - 2.0f, 1.5f, 1.5f, st);
+                    classify_items_array<false>(rs, items.data(), (int)items.size(), 4.0f * X + 2.0f, (float)NATIVE_RES - 4.0f * Y - 2.0f, st);
                     g_stat[3]++;
                     c = st.base;
                     if (st.mixed) { g_stat[4]++; c = pixel_resolve(rs, X, Y, st.mixed, c); }   // phase Q
