@@ -78,6 +78,13 @@ struct Raster {
 
 MGX_HD double rz_floor(double x) { return floor(x); }
 
+#ifdef MGX_RASTER_STATS     // host emulation only (tests/emu): operation counts of the resolve path
+inline long g_rstat[16];
+#define MGX_RSTAT(i, n) g_rstat[i] += (n)
+#else
+#define MGX_RSTAT(i, n)
+#endif
+
 // ---- setup phase 1: body poses from the pose blob (lane per body)
 template <typename P>
 MGX_HD void raster_setup_bodies(Raster &rs, const P *sp, long stride, long env, int lane, int nl) {
@@ -442,15 +449,19 @@ MGX_HD uint32_t ngon_coverage16(const Raster &rs, int k, int X, int Y) {
     const Item &it = reinterpret_cast<const Item *>(&RI(items, 0))[RI(pitem, k) & 0xFFFF];
     const float x0 = 4.0f * X + 0.5f - it.a, y0 = (float)NATIVE_RES - 0.5f - 4.0f * Y - it.b;
     const float apo = it.c - CLASS_EPS_F, rad = it.g0 + CLASS_EPS_F, apo2 = apo > 0.0f ? apo * apo : -1.0f, rad2 = rad * rad;
-    uint32_t cov = 0;
+    uint32_t cov = 0, ann = 0;
     for (int j = 0; j < 4; j++)
         for (int i = 0; i < 4; i++) {
             float qx = x0 + i, qy = y0 - j, d2 = qx * qx + qy * qy;
-            bool in = d2 <= apo2;
-            if (!in && d2 <= rad2)   // annulus between in- and circum-circle (plus fp32 margin): exact fp64 sector test
-                in = ngon_contains(rs, k, 4.0 * X + i + 0.5, (double)NATIVE_RES - 0.5 - 4.0 * Y - j);
-            cov |= (in ? 1u : 0u) << (4 * j + i);
+            cov |= (d2 <= apo2 ? 1u : 0u) << (4 * j + i);
+            ann |= (d2 > apo2 && d2 <= rad2 ? 1u : 0u) << (4 * j + i);
         }
+    // annulus between in- and circum-circle (plus fp32 margin): exact fp64 sector test, one sample at a time so that
+    // the (long) test is instantiated once
+    for (; ann; ann &= ann - 1) {
+        const int sidx = __builtin_ctz(ann);
+        if (ngon_contains(rs, k, 4.0 * X + (sidx & 3) + 0.5, (double)NATIVE_RES - 0.5 - 4.0 * Y - (sidx >> 2))) cov |= 1u << sidx;
+    }
     return cov;
 }
 // samples of the block that a line loop may touch (alpha > 0 possible), fp32 conservative
@@ -475,6 +486,46 @@ MGX_HD uint32_t lineloop_touch16(const Raster &rs, int k, int X, int Y, uint32_t
     return touch;
 }
 
+// fp32 alpha of all 16 samples of the block for the segments in `segmask`, in block-local coordinates: the fp64 edge
+// and arclength functions are evaluated once at sample (0, 0) and stepped in fp32, so the absolute error of alpha
+// stays below ALPHA_ERR_F (terms are O(1) wherever alpha can be non-zero).  Samples whose stipple bit cannot be
+// decided in fp32 are flagged in `amb` and must be redone with lineloop_alpha_masked.
+constexpr float ALPHA_ERR_F = 4e-6f;
+constexpr float STIPPLE_TOL_F = 1e-3f;
+MGX_HD void lineloop_alpha16(const Raster &rs, int k, int X, int Y, uint32_t segmask, float (&alpha)[16], uint32_t &amb) {
+    const int vo = rs.prim_voff(k), stipple = rs.prim_stipple(k);
+    const float hw = (float)RD(prad, k);
+    const double x0 = 4.0 * X + 0.5, y0 = (double)NATIVE_RES - 0.5 - 4.0 * Y;
+#pragma unroll
+    for (int q = 0; q < 16; q++) alpha[q] = 0.0f;
+    for (; segmask; segmask &= segmask - 1) {
+        const int i = __builtin_ctz(segmask);
+        const double a = RD(ea, vo + i), b = RD(eb, vo + i), ax = RD(svx, vo + i), ay = RD(svy, vo + i), len = RD(elen, vo + i);
+        const double E0 = a * x0 + b * y0 + RD(ec, vo + i), S0 = (x0 - ax) * b - (y0 - ay) * a;
+        const float af = (float)a, bf = (float)b, e0 = (float)E0, s0 = (float)S0, s1 = (float)(S0 - len), lenf = (float)len;
+        float u0 = 0.0f;
+        if (stipple) { const double arc = RD(earc, vo + i); u0 = (float)(arc - 16.0 * rz_floor(arc * 0.0625)); }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+                const float fi = (float)ii, fj = (float)j;
+                const float e = e0 + (af * fi - bf * fj);
+                const float ds = bf * fi + af * fj;
+                const float s = s0 + ds, sb = s1 + ds;                         // arclength from the start / beyond the end
+                const float t = r_max(r_max(-s, sb), 0.0f);
+                float al = r_clamp01(hw - sqrtf(e * e + t * t));
+                if (stipple) {
+                    const float u = u0 + r_clamp(s, 0.0f, lenf), fl = floorf(u);
+                    if (al > 0.0f && (u - fl < STIPPLE_TOL_F || fl + 1.0f - u < STIPPLE_TOL_F)) amb |= 1u << (4 * j + ii);
+                    if (!((stipple >> (((int)fl) & 15)) & 1)) al = 0.0f;
+                }
+                alpha[4 * j + ii] = r_max(alpha[4 * j + ii], al);
+            }
+        }
+    }
+}
+
 // exact 4x4-sample mean of an undecided pixel.  Opaque prims (front to back) claim samples through coverage masks;
 // at a translucent line loop the still-unclaimed samples it may touch are blended individually in fp64 (painter's
 // order over everything from the line down), the others keep going through masks.
@@ -482,6 +533,7 @@ MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int bas
     uint32_t remaining = 0xFFFFu;
     int sr = 0, sg = 0, sb = 0;
     uint64_t m = mixed;
+    MGX_RSTAT(0, 1); MGX_RSTAT(1, __builtin_popcountll(mixed));
     while (m && remaining) {
         const int k = 63 - __builtin_clzll(m);
         m &= ~(1ull << k);
@@ -490,7 +542,9 @@ MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int bas
         if (kind == PR_LINELOOP) {
             uint32_t segmask;
             cov = lineloop_touch16(rs, k, X, Y, segmask) & remaining;
+            MGX_RSTAT(2, 1);
             if (cov) {
+                MGX_RSTAT(3, 1); MGX_RSTAT(4, __builtin_popcount(cov)); MGX_RSTAT(5, __builtin_popcount(segmask));
                 // colour under the line for each touched sample: coverage masks of the opaque prims below it
                 // (front to back); a second line loop in that stack falls back to the generic per-sample painter
                 constexpr int MAXL = 4;
@@ -507,7 +561,32 @@ MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int bas
                 }
                 const int col = rs.prim_rgb(k);
                 const double lr = (double)(col & 0xFF), lg = (double)((col >> 8) & 0xFF), lb = (double)((col >> 16) & 0xFF);
-                for (uint32_t t = cov; t; t &= t - 1) {
+                uint32_t exact = cov;                      // samples that still need the exact fp64 painter
+                if (!generic) {
+                    // fp32 first: alpha of all 16 samples, then the blend; a sample whose rounded channel value could
+                    // flip within the fp32 error bound is left to the exact path
+                    float alpha[16]; uint32_t amb = 0;
+                    lineloop_alpha16(rs, k, X, Y, segmask, alpha, amb);
+                    const float lrf = (float)(col & 0xFF), lgf = (float)((col >> 8) & 0xFF), lbf = (float)((col >> 16) & 0xFF);
+                    constexpr float TAU = 255.0f * ALPHA_ERR_F + 5e-4f;
+                    exact = amb & cov;
+#pragma unroll
+                    for (int sidx = 0; sidx < 16; sidx++) {
+                        if (!((cov >> sidx) & 1u) || ((amb >> sidx) & 1u)) continue;
+                        int c = base;
+#pragma unroll
+                        for (int q = MAXL - 1; q >= 0; q--) if (q < nlow && ((lcov[q] >> sidx) & 1u)) c = lcol[q];   // back to front
+                        const float a = alpha[sidx];
+                        const float cr = (float)(c & 0xFF), cg = (float)((c >> 8) & 0xFF), cb = (float)((c >> 16) & 0xFF);
+                        const float vr = cr + a * (lrf - cr) + 0.5f, vg = cg + a * (lgf - cg) + 0.5f, vb = cb + a * (lbf - cb) + 0.5f;
+                        const float fr = floorf(vr), fg = floorf(vg), fb = floorf(vb);
+                        const float dr = r_abs(vr - fr - 0.5f), dg = r_abs(vg - fg - 0.5f), db = r_abs(vb - fb - 0.5f);
+                        if (r_max(r_max(dr, dg), db) > 0.5f - TAU) { exact |= 1u << sidx; continue; }
+                        sr += (int)fr; sg += (int)fg; sb += (int)fb;
+                    }
+                }
+                MGX_RSTAT(6, __builtin_popcount(exact)); MGX_RSTAT(7, nlow); MGX_RSTAT(8, generic ? 1 : 0);
+                for (uint32_t t = exact; t; t &= t - 1) {
                     const int sidx = __builtin_ctz(t);
                     const double x = 4.0 * X + (sidx & 3) + 0.5, y = (double)NATIVE_RES - 0.5 - 4.0 * Y - (sidx >> 2);
                     int c;
@@ -529,6 +608,7 @@ MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int bas
             }
         } else {
             cov = (kind == PR_POLY ? poly_coverage16(rs, k, X, Y) : ngon_coverage16(rs, k, X, Y)) & remaining;
+            MGX_RSTAT(9, 1);
             if (cov) {
                 const int n = __builtin_popcount(cov), col = rs.prim_rgb(k);
                 sr += n * (col & 0xFF); sg += n * ((col >> 8) & 0xFF); sb += n * ((col >> 16) & 0xFF);

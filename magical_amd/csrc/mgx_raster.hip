@@ -23,11 +23,17 @@ struct RasterDev {
     int scratch_d;           // doubles of per-env scratch
     int bg_rgb;
     int off_tiles;           // word offset (inside the scratch area) of the per-tile / queue region, 8-byte aligned
-    unsigned long long *dbg_clk;   // development probe: per-block phase clocks [n_envs][8] (NULL = off)
+    unsigned long long *dbg_clk;   // development probe: per-block phase clocks [n_envs][16] (NULL = off)
+    int dbg_stop;                  // development probe: return after phase k (0 = run everything)
+    int qcap;                      // queue entries in use (<= QCAP; tests shrink it to exercise the overflow rounds)
 };
 
 constexpr int N_TILES = TILES_X * TILES_Y;
-constexpr int QCAP = 2048;     // LDS queue of undecided pixels per env (overflow is resolved in place)
+constexpr int QCAP = 1024;     // LDS queue of undecided pixels per env; what does not fit waits in a bitmap for another round
+constexpr int OVF_WORDS = LORES * LORES / 32;
+#ifndef MGX_STACK_GROUP
+#define MGX_STACK_GROUP 4      // tiles whose old pixels are fetched ahead, per wavefront (STACK4 layout)
+#endif
 
 // FlattenFrameStack shift of one pixel: 12 B read-modify-write (or 4 copies of the frame after a reset)
 struct OldPx { uint32_t o0, o1, o2; };
@@ -101,12 +107,21 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
 }
 
 template <typename P, int LAYOUT>
-__global__ __launch_bounds__(256, 3) void k_raster(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(256, 4) void k_raster(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
                                                 long env_stride, int view, const uint8_t *__restrict__ fill_mask, int n_envs) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
     unsigned long long clk0 = wall_clock64();
-#define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 8 + (i)] = wall_clock64() - clk0;
+#ifdef MGX_RASTER_PROBE
+#define PROBE(...) __VA_ARGS__
+#else
+#define PROBE(...)
+#endif
+#ifdef MGX_RASTER_PROBE   // development build: also allows truncating the kernel after phase i (tools/raster_phase_probe.py)
+#define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + (i)] = wall_clock64() - clk0; if ((i) > 0 && t.dbg_stop == (i)) return;
+#else
+#define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + (i)] = wall_clock64() - clk0;
+#endif
     for (int i = tid; i < t.n_words; i += 256) lds[i] = t.words[i];
     __syncthreads();
     CLK(0)
@@ -121,8 +136,10 @@ __global__ __launch_bounds__(256, 3) void k_raster(RasterDev t, const P *__restr
     uint64_t *q_mask = reinterpret_cast<uint64_t *>(tile_base + N_TILES);
     int32_t *q_pix = reinterpret_cast<int32_t *>(q_mask + QCAP);
     int32_t *q_base = q_pix + QCAP;
-    int32_t *q_count = q_base + QCAP;
-    if (tid == 0) *q_count = 0;
+    int32_t *q_count = q_base + QCAP;              // [0] entries pushed, [1] "some pixel did not fit" flag
+    uint32_t *q_ovf = reinterpret_cast<uint32_t *>(q_count + 2);   // bitmap of the pixels that did not fit
+    if (tid == 0) { q_count[0] = 0; q_count[1] = 0; }
+    for (int i = tid; i < OVF_WORDS; i += 256) q_ovf[i] = 0;
     // phase S: screen-space setup (lane per body, lane per primitive, lane per primitive again for the item list)
     raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
     __syncthreads();
@@ -159,32 +176,21 @@ __global__ __launch_bounds__(256, 3) void k_raster(RasterDev t, const P *__restr
     const int tx = lane & (TILE_W - 1), ty = lane >> 4;
     const bool fill = LAYOUT == 1 && fill_mask != nullptr && fill_mask[env] != 0;
     uint8_t *frame = out + env * env_stride;
-    OldPx next_px{0, 0, 0};
-    if (LAYOUT == 1 && !fill) next_px = load_stack4(frame, (wave % TILES_X) * TILE_W + tx, (wave / TILES_X) * TILE_H + ty);
-    for (int tile = wave; tile < N_TILES; tile += 4) {
-        const int tcol = tile % TILES_X, trow = tile / TILES_X;
-        const int X = tcol * TILE_W + tx, Y = trow * TILE_H + ty;
+    // wave w walks tiles w, w + 4, ... (pairing horizontally adjacent tiles to complete 128 B lines back to back was
+    // measured slower and produced more write-back traffic)
+    auto seq_tile = [&](int i) { return wave + 4 * i; };
+    constexpr int N_SEQ = N_TILES / 4;
+    static_assert(N_TILES % 4 == 0, "tiles per wave");
+    const int qcap = t.qcap;
+    PROBE(unsigned long long pr_gather = 0, pr_class = 0, pr_items = 0, pr_tiles = 0; const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();)
+    // classify the pixels of one tile: returns the colour; `queued` when the pixel must wait for phase Q
+    auto do_tile = [&](int tile, int X, int Y, bool &queued) -> int {
         const uint64_t tmixed = tile_mixed[tile];
         int c = tile_base[tile];
-        // STACK4: the old pixel of this tile was fetched one tile ago; fetch the next tile's now
-        const OldPx cur_px = next_px;
-        if (LAYOUT == 1 && !fill && tile + 4 < N_TILES) {
-            const int nt = tile + 4;
-            next_px = load_stack4(frame, (nt % TILES_X) * TILE_W + tx, (nt / TILES_X) * TILE_H + ty);
-        }
-        if (tmixed == 0) {
-            if (LAYOUT == 0) {
-                // 16 pixels x 3 B = 12 dwords per tile row: lanes tx < 12 each assemble one dword
-                const int d = tx < 12 ? tx : 0;
-                const int p0 = (4 * d) / 3, o = (4 * d) % 3;
-                const uint32_t c0 = (uint32_t)__shfl(c, (ty << 4) + p0), c1 = (uint32_t)__shfl(c, (ty << 4) + p0 + 1);
-                uint32_t w = o == 0 ? (c0 | (c1 << 24)) : (o == 1 ? ((c0 >> 8) | (c1 << 16)) : ((c0 >> 16) | (c1 << 8)));
-                if (tx < 12) reinterpret_cast<uint32_t *>(frame + (long)(Y * LORES + tcol * TILE_W) * 3)[d] = w;
-            } else {
-                store_stack4_pre(frame, X, Y, c, fill, cur_px);
-            }
-            continue;
-        }
+        queued = false;
+        if (tmixed == 0) return c;
+        PROBE(if (t.dbg_stop == 9) return c;)     // probe: pure streaming, no per-pixel classification
+        PROBE(const unsigned long long pt0 = __builtin_amdgcn_s_memtime();)
         // gather the items of the tile's undecided prims (front to back), one per lane, and classify every
         // pixel's 4x4 sample block against them
         ClassState st; st.init(c);
@@ -195,36 +201,125 @@ __global__ __launch_bounds__(256, 3) void k_raster(RasterDev t, const P *__restr
             const int idx = masked_item_index(rs, tmixed, c0 + lane, n_total);
             src.my = load_item(rs, idx >= 0 ? idx : 0);
             const int n = n_total - c0 < 64 ? n_total - c0 : 64;
+            PROBE(const unsigned long long pt1 = __builtin_amdgcn_s_memtime(); pr_gather += pt1 - pt0;)
             classify_items_regs<false>(rs, src, n, xc, yc, st, true);
+            PROBE(pr_class += __builtin_amdgcn_s_memtime() - pt1; pr_items += n;)
             if (c0 + 64 >= n_total) break;
         }
-        c = st.base;
-        if (st.mixed == 0) {
-            if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4_pre(frame, X, Y, c, fill, cur_px);
-        } else {
+        PROBE(pr_tiles++;)
+        if (st.mixed != 0) {
             // undecided pixel: queue it for phase Q so that finished lanes do not wait for it
-            int slot = atomicAdd(q_count, 1);
-            if (slot < QCAP) {
-                q_mask[slot] = st.mixed; q_pix[slot] = X | (Y << 8); q_base[slot] = c;
+            queued = true;
+            const int slot = atomicAdd(&q_count[0], 1);
+            if (slot < qcap) {
+                q_mask[slot] = st.mixed; q_pix[slot] = X | (Y << 8); q_base[slot] = st.base;
             } else {
-                c = pixel_resolve(rs, X, Y, st.mixed, c);
-                if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4_pre(frame, X, Y, c, fill, cur_px);
+                const int p = Y * LORES + X;
+                atomicOr(&q_ovf[p >> 5], 1u << (p & 31));
+                q_count[1] = 1;
+            }
+        }
+        return st.base;
+    };
+    if (LAYOUT == 0) {
+        for (int seq = 0; seq < N_SEQ; seq++) {
+            const int tile = seq_tile(seq);
+            const int tcol = tile % TILES_X, trow = tile / TILES_X;
+            const int X = tcol * TILE_W + tx, Y = trow * TILE_H + ty;
+            if (tile_mixed[tile] == 0) {
+                // 16 pixels x 3 B = 12 dwords per tile row: lanes tx < 12 each assemble one dword
+                const int c = tile_base[tile];
+                const int d = tx < 12 ? tx : 0;
+                const int p0 = (4 * d) / 3, o = (4 * d) % 3;
+                const uint32_t c0 = (uint32_t)__shfl(c, (ty << 4) + p0), c1 = (uint32_t)__shfl(c, (ty << 4) + p0 + 1);
+                uint32_t w = o == 0 ? (c0 | (c1 << 24)) : (o == 1 ? ((c0 >> 8) | (c1 << 16)) : ((c0 >> 16) | (c1 << 8)));
+                if (tx < 12) reinterpret_cast<uint32_t *>(frame + (long)(Y * LORES + tcol * TILE_W) * 3)[d] = w;
+                continue;
+            }
+            bool queued;
+            const int c = do_tile(tile, X, Y, queued);
+            if (!queued) store_frame_px(frame, X, Y, c);
+        }
+    } else {
+        // STACK4 shifts 12 B per pixel in place.  The old pixels are fetched a whole group of G tiles ahead (G x 768 B
+        // in flight per wavefront) so that the read latency is covered by the previous group's classification.
+        constexpr int G = MGX_STACK_GROUP;
+        static_assert(N_SEQ % G == 0, "tile groups");
+        OldPx nxt[G];
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            nxt[u] = OldPx{0, 0, 0};
+            const int tile = seq_tile(u);
+            if (!fill) nxt[u] = load_stack4(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty);
+        }
+        for (int g = 0; g < N_SEQ; g += G) {
+            OldPx cur[G];
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                cur[u] = nxt[u];
+                const int tile = seq_tile(g + G + u);
+                if (!fill && g + G < N_SEQ) nxt[u] = load_stack4(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty);
+            }
+            int col[G];
+#pragma unroll
+            for (int v = 0; v < G; v++) col[v] = 0;
+            uint32_t qbits = 0;
+#pragma unroll 1
+            for (int u = 0; u < G; u++) {
+                const int tile = seq_tile(g + u);
+                bool queued;
+                const int c = do_tile(tile, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty, queued);
+                if (queued) qbits |= 1u << u;
+#pragma unroll
+                for (int v = 0; v < G; v++) col[v] = u == v ? c : col[v];
+            }
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const int tile = seq_tile(g + u);
+                if (!((qbits >> u) & 1u))
+                    store_stack4_pre(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty, col[u], fill, cur[u]);
             }
         }
     }
+    PROBE(if (t.dbg_clk && tid == 0) { unsigned long long *d = t.dbg_clk + blockIdx.x * 16; d[6] = pr_gather; d[7] = pr_class;
+                d[8] = __builtin_amdgcn_s_memtime() - pr_t0; d[9] = pr_tiles; d[10] = pr_items; })
     __syncthreads();
     CLK(3)
     // phase Q: the queue is dense, so every lane resolves one undecided pixel (fp32 coverage masks, fp64 only for
-    // ambiguous samples and line blending)
-    const int nq = *q_count < QCAP ? *q_count : QCAP;
-    for (int i = tid; i < nq; i += 256) {
-        const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;
-        const int c = pixel_resolve(rs, X, Y, q_mask[i], q_base[i]);
-        if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
+    // ambiguous samples and line blending).  Pixels that did not fit the queue are re-queued from the bitmap with
+    // their tile's prim set (a superset of the pixel's, same result) for another round.
+    int nq_total = 0;
+    for (;;) {
+        const int nq = q_count[0] < qcap ? q_count[0] : qcap;
+        const bool more = q_count[1] != 0;
+        nq_total += nq;
+        for (int i = tid; i < nq; i += 256) {
+            const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;
+            const int c = pixel_resolve(rs, X, Y, q_mask[i], q_base[i]);
+            if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
+        }
+        __syncthreads();
+        if (!more) break;
+        if (tid == 0) { q_count[0] = 0; q_count[1] = 0; }
+        __syncthreads();
+        for (int w = tid; w < OVF_WORDS; w += 256) {
+            uint32_t bits = q_ovf[w];
+            while (bits) {
+                const int b = __ffs(bits) - 1;
+                const int slot = atomicAdd(&q_count[0], 1);
+                if (slot >= qcap) { q_count[1] = 1; break; }
+                const int p = w * 32 + b, X = p % LORES, Y = p / LORES;
+                const int tile = (Y / TILE_H) * TILES_X + X / TILE_W;
+                q_mask[slot] = tile_mixed[tile]; q_pix[slot] = X | (Y << 8); q_base[slot] = tile_base[tile];
+                bits &= bits - 1;
+            }
+            q_ovf[w] = bits;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     CLK(4)
-    if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 8 + 5] = nq;
+    const int nq = nq_total;
+    if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + 5] = nq;
 #undef CLK
 }
 

@@ -40,7 +40,11 @@ __global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *_
 
     constexpr int EPB = 64 / L;
     const int env_local = tid / L, lane = tid % L, nl = L;
-    long env = (long)blockIdx.x * EPB + env_local;
+    // consecutive workgroups land on different XCDs (round robin over the 8 L2s); give each XCD a contiguous env
+    // range so that the [row][env] lines shared by neighbouring workgroups are fetched into one L2 only
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
+    long env = (long)wg * EPB + env_local;
     const bool valid = env < n_envs;
     if (!valid) env = n_envs - 1;   // tail lanes shadow the last env (no stores) so barriers stay uniform
     uint32_t *slab = lds + t.lds_tmpl_words + env_local * t.env_stride_words;

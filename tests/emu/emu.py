@@ -17,7 +17,7 @@ MODES = {'f32': 0, 'mixed': 1, 'f64': 2}
 def build():
     newest = max(os.path.getmtime(p) for p in _SRCS)
     if not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
-        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-ffp-contract=off', '-shared', '-o', _SO,
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-ffp-contract=off', '-DMGX_RASTER_STATS', '-shared', '-o', _SO,
                                _SRCS[0], _SRCS[1]])
     return _SO
 

@@ -160,6 +160,7 @@ int emu_n_state(void *p) { return ((EmuHandle *)p)->emu[0]->h.n_state; }
 int emu_state_row(void *p, int row) { EmuHandle *h = (EmuHandle *)p; TmplOff o(h->emu[0]->h); return h->emu[0]->ti[o.state_map + row]; }
 int emu_n_bodies(void *p) { return ((EmuHandle *)p)->emu[0]->h.n_bodies; }
 int emu_contacts(void *p, int mode, double *out, int max_rows) { return ((EmuHandle *)p)->emu[mode]->contacts(out, max_rows); }
+void emu_rstats(long *out) { for (int i = 0; i < 16; i++) { out[i] = mgx::g_rstat[i]; mgx::g_rstat[i] = 0; } }
 void emu_stats(long *out) { for (int i = 0; i < 8; i++) { out[i] = g_stat[i]; g_stat[i] = 0; } }
 void emu_render(void *p, int mode, const void *sp, int env, int view, int native, uint8_t *out) {
     EmuHandle *h = (EmuHandle *)p;

@@ -159,6 +159,38 @@ def test_render_matches_oracle_bit_exact(task):
     env.close()
 
 
+@pytest.mark.parametrize('task', ['ClusterColour', 'MatchRegions'])
+def test_render_queue_overflow_rounds(task):
+    """The rasteriser's LDS queue of undecided pixels overflows into extra rounds; shrinking it to 64 / 1 entries
+    must not change a single byte of either layout."""
+    import torch
+    n, t = 3, 9
+    tape = _tape(23, t, n)
+    env = _make(f'{task}-Demo-v0', n)
+    env.reset()
+    for s in range(t):
+        env.step(tape[s])
+    frames, stacks = [], []
+    for qcap in (1 << 20, 64, 1):
+        env._lib.mgx_engine_debug_raster_qcap(env._engine, qcap)
+        for view in ('ego', 'allo'):
+            frame = torch.zeros((n, 96, 96, 3), dtype=torch.uint8, device='cuda:0')
+            env.render_frames(frame, view=view, layout='frame')
+            frames.append(frame.cpu().numpy())
+        stack = torch.arange(n * 96 * 96 * 12, device='cuda:0').remainder(251).to(torch.uint8).reshape(n, 96, 96, 12)
+        old = stack.cpu().numpy().copy()
+        env.render_frames(stack, view='ego', layout='stack4')
+        got = stack.cpu().numpy()
+        assert np.array_equal(got[..., :9], old[..., 3:])
+        stacks.append(got)
+    env._lib.mgx_engine_debug_raster_qcap(env._engine, 1 << 20)
+    for k in (2, 4):
+        assert np.array_equal(frames[k], frames[0]) and np.array_equal(frames[k + 1], frames[1])
+    assert np.array_equal(stacks[1], stacks[0]) and np.array_equal(stacks[2], stacks[0])
+    assert np.array_equal(stacks[0][..., 9:], frames[0])
+    env.close()
+
+
 def test_lores4e_stack_and_autoreset():
     """FlattenFrameStack semantics on device: reset fills 4 copies, step shifts by one frame, auto-reset refills;
     compared with the oracle's LoRes4E pipeline for the first steps."""

@@ -1,0 +1,31 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes per kernel (development tool).
+
+usage: python tools/pmc_summary.py <fetch_dir> <write_dir> > profiles/rNN_pmc_traffic.json
+
+rocprofv3 reports both counters in KiB.  WRITE_SIZE is exact for 16 B/lane streaming stores (the 452 984 832 B fill
+of the observation tensor in the same run reads 442 368.0); FETCH_SIZE on gfx950 tallies 128 B read requests at
+64 B (MI355X_MICROARCH.md, "HBM"), so fetch bytes are doubled.
+"""
+import collections, csv, glob, json, statistics, sys
+
+def per_kernel(d):
+    f = glob.glob(d + '/**/*_counter_collection.csv', recursive=True)[0]
+    out = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name']
+        k = 'k_raster' if 'k_raster' in k else 'k_step' if 'k_step' in k else 'fill_u8' if 'FillFunctor<unsigned char>' in k else None
+        if k:
+            out[k].append(float(r['Counter_Value']) * 1024.0)
+    return out
+
+fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+res = {}
+for k in ('k_raster', 'k_step'):
+    fr, wr = statistics.median(fetch[k]), statistics.median(write[k])
+    res[k] = {'launches_fetch_pass': len(fetch[k]), 'launches_write_pass': len(write[k]),
+              'FETCH_SIZE_raw_bytes_median': fr, 'FETCH_SIZE_x2_bytes': 2 * fr, 'WRITE_SIZE_bytes_median': wr,
+              'hbm_traffic_bytes_per_launch': 2 * fr + wr}
+if 'fill_u8' in write:
+    res['calibration'] = {'kernel': 'at::native FillFunctor<unsigned char> over the [N,96,96,12] u8 tensor',
+                          'WRITE_SIZE_bytes': max(write['fill_u8'])}
+print(json.dumps(res, indent=1))

@@ -27,7 +27,7 @@ for s in range(60):
     if s in (0, 4, 19, 59):
         print('after %d steps: ego frame %.3f ms, ego stack4 %.3f ms, allo frame %.3f ms' % (
             s + 1, timeit(env, frame, 'ego', 'frame'), timeit(env, stack, 'ego', 'stack4'), timeit(env, frame, 'allo', 'frame')))
-clk = torch.zeros((N, 8), dtype=torch.int64, device='cuda:0')
+clk = torch.zeros((N, 16), dtype=torch.int64, device='cuda:0')
 env._lib.mgx_engine_debug_raster_clocks(env._engine, C.c_void_p(clk.data_ptr()))
 env.render_frames(stack, view='ego', layout='stack4'); torch.cuda.synchronize()
 env._lib.mgx_engine_debug_raster_clocks(env._engine, None)
@@ -37,6 +37,9 @@ prev = 0
 for i, nme in enumerate(names):
     print('  %-20s cumulative %.1f us (100 MHz wall clock)  delta mean %.1f us  max %.1f us' % (nme, c[:, i].mean() / 100, (c[:, i] - (c[:, i - 1] if i else 0)).mean() / 100, (c[:, i] - (c[:, i - 1] if i else 0)).max() / 100))
 print('  queued pixels per env: mean %.0f max %.0f' % (c[:, 5].mean(), c[:, 5].max()))
+if c[:, 8].max() > 0:   # MGX_RASTER_PROBE build: wave 0 of each block, shader cycles
+    print('  wave 0 phase T: total %.0f cyc; gather %.0f cyc, classify %.0f cyc, mixed tiles %.1f, items %.0f' % (
+        c[:, 8].mean(), c[:, 6].mean(), c[:, 7].mean(), c[:, 9].mean(), c[:, 10].mean()))
 # copy bandwidth reference
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): stack.copy_(stack + 0)
