@@ -307,8 +307,8 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
         e->rdev.lds_tmpl_words = total; e->rdev.scratch_d = ro.n_d; e->rdev.bg_rgb = BG_RGB;
         int off_tiles = even(2 * ro.n_d + ro.n_i);
         e->rdev.off_tiles = off_tiles;
-        // per-tile (u64 mask + i32 base) + queue (u64 mask + 2 x i32) + counter and flag + overflow bitmap
-        int extra = N_TILES * 3 + QCAP * 4 + 2 + OVF_WORDS;
+        // per-tile (u64 mask + i32 base) + queue (u64 mask + 2 x i32) + counters + overflow bitmap + phase E records (u64 sums, u16 entry)
+        int extra = N_TILES * 3 + QCAP * 4 + 4 + OVF_WORDS + QCAP * 2 + QCAP / 2;
         e->rdev.qcap = QCAP;
         e->lds_raster = (size_t)(total + off_tiles + extra) * 4;
     }
@@ -414,6 +414,7 @@ int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_
 int mgx_engine_debug_raster_qcap(mgx_engine *e, int n) { if (e) e->rdev.qcap = n < 1 ? 1 : (n > QCAP ? QCAP : n); return MGX_OK; }
 int mgx_engine_debug_raster_stop(mgx_engine *e, int phase) { if (e) e->rdev.dbg_stop = phase; return MGX_OK; }
 int mgx_engine_debug_raster_clocks(mgx_engine *e, void *buf) { if (e) e->rdev.dbg_clk = (unsigned long long *)buf; return MGX_OK; }
+int mgx_engine_debug_step_clocks(mgx_engine *e, void *buf) { if (e) e->tdev.dbg_clk = (unsigned long long *)buf; return MGX_OK; }
 int mgx_engine_debug_iterations(mgx_engine *e, int it) { if (e) e->dbg_iterations = it; return MGX_OK; }
 int mgx_engine_set_timing(mgx_engine *e, int enable) {
     if (!e) return fail(MGX_ERR_ARG, "engine is NULL");

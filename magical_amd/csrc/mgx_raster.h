@@ -412,8 +412,8 @@ MGX_HD void tile_centre(int tile, float &xc, float &yc) {
 // 16-bit coverage of the 4x4 sample block whose top-left sample is (x0, y0); bit 4*j + i = sample (x0 + i, y0 - j).
 // fp32 first: a sample is decided in fp32 when |E| > CLASS_EPS_F, otherwise that one sample is re-evaluated in fp64
 // against the fp64 edge function -- the result equals the all-fp64 test.
-MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, int X, int Y) {
-    const int nv = rs.prim_nv(k), vo = rs.prim_voff(k), i0 = RI(pitem, k) & 0xFFFF;
+MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, int X, int Y, uint32_t &unc) {
+    const int nv = rs.prim_nv(k), i0 = RI(pitem, k) & 0xFFFF;
     const float x0 = 4.0f * X + 0.5f, y0 = (float)NATIVE_RES - 0.5f - 4.0f * Y;
     const Item *items = reinterpret_cast<const Item *>(&RI(items, 0)) + i0;
     uint32_t cov = 0xFFFFu;
@@ -435,17 +435,16 @@ MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, int X, int Y) {
             }
             row -= b;
         }
-        while (amb) {                                                       // rare: exact fp64 for the ambiguous samples
-            int sidx = __builtin_ctz(amb);
-            amb &= amb - 1;
-            double x = 4.0 * X + (sidx & 3) + 0.5, y = (double)NATIVE_RES - 0.5 - 4.0 * Y - (sidx >> 2);
-            if (RD(ea, vo + e) * x + RD(eb, vo + e) * y + RD(ec, vo + e) >= 0.0) in |= 1u << sidx;
-        }
+        unc |= amb & cov;                                                  // samples too close to call in fp32
         cov &= in;
     }
     return cov;
 }
-MGX_HD uint32_t ngon_coverage16(const Raster &rs, int k, int X, int Y) {
+// regular n-gon (circles): inside the in-circle / outside the circum-circle is decided by the radius; in the thin annulus
+// between them the sample is tested against the edges of its angular sector and of both neighbours (robust against an
+// off-by-one sector from the fp32 angle; the largest of the three equals the polygon's support function there)
+constexpr float NGON_TOL_F = 2e-4f;
+MGX_HD uint32_t ngon_coverage16(const Raster &rs, int k, int X, int Y, uint32_t &unc) {
     const Item &it = reinterpret_cast<const Item *>(&RI(items, 0))[RI(pitem, k) & 0xFFFF];
     const float x0 = 4.0f * X + 0.5f - it.a, y0 = (float)NATIVE_RES - 0.5f - 4.0f * Y - it.b;
     const float apo = it.c - CLASS_EPS_F, rad = it.g0 + CLASS_EPS_F, apo2 = apo > 0.0f ? apo * apo : -1.0f, rad2 = rad * rad;
@@ -456,11 +455,24 @@ MGX_HD uint32_t ngon_coverage16(const Raster &rs, int k, int X, int Y) {
             cov |= (d2 <= apo2 ? 1u : 0u) << (4 * j + i);
             ann |= (d2 > apo2 && d2 <= rad2 ? 1u : 0u) << (4 * j + i);
         }
-    // annulus between in- and circum-circle (plus fp32 margin): exact fp64 sector test, one sample at a time so that
-    // the (long) test is instantiated once
-    for (; ann; ann &= ann - 1) {
-        const int sidx = __builtin_ctz(ann);
-        if (ngon_contains(rs, k, 4.0 * X + (sidx & 3) + 0.5, (double)NATIVE_RES - 0.5 - 4.0 * Y - (sidx >> 2))) cov |= 1u << sidx;
+    if (ann) {
+        const int n = rs.prim_nv(k);
+        const float step = 6.283185307179586f / (float)n, phi = (float)RD(pphi, k);
+        float ss, cs;
+        r_sincos<float>(step, ss, cs);
+        for (; ann; ann &= ann - 1) {
+            const int sidx = __builtin_ctz(ann);
+            const float qx = x0 + (float)(sidx & 3), qy = y0 - (float)(sidx >> 2);
+            const float kk = floorf((atan2f(qy, qx) - phi) / step);
+            float s, c;
+            r_sincos<float>(phi + (kk + 0.5f) * step, s, c);
+            const float d0 = qx * c + qy * s;                                      // this sector's edge
+            const float dp = qx * (c * cs - s * ss) + qy * (s * cs + c * ss);      // next sector
+            const float dm = qx * (c * cs + s * ss) + qy * (s * cs - c * ss);      // previous sector
+            const float d = r_max(d0, r_max(dp, dm)) - it.c;
+            if (r_abs(d) < NGON_TOL_F) unc |= 1u << sidx;
+            if (d <= 0.0f) cov |= 1u << sidx;
+        }
     }
     return cov;
 }
@@ -526,11 +538,14 @@ MGX_HD void lineloop_alpha16(const Raster &rs, int k, int X, int Y, uint32_t seg
     }
 }
 
-// exact 4x4-sample mean of an undecided pixel.  Opaque prims (front to back) claim samples through coverage masks;
-// at a translucent line loop the still-unclaimed samples it may touch are blended individually in fp64 (painter's
-// order over everything from the line down), the others keep going through masks.
-MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int base) {
-    uint32_t remaining = 0xFFFFu;
+// Sum of the 4x4 samples of an undecided pixel, fp32 only.  Opaque prims (front to back) claim samples through
+// coverage masks; at a translucent line loop the still-unclaimed samples it may touch are blended over the colour of
+// the opaque prims below it.  Samples are independent of each other, so whenever a decision for one sample cannot be
+// guaranteed to agree with the fp64 painter (within the fp32 margin of an edge, a blended channel within TAU of a
+// rounding boundary, an undecidable stipple bit, two line loops on top of each other) that sample is left out of the
+// sums and reported in `uncertain`, to be added with pixel_add_exact.  sums = r | g << 12 | b << 24 (each <= 4080).
+MGX_HD uint64_t pixel_resolve_fast(const Raster &rs, int X, int Y, uint64_t mixed, int base, uint32_t &uncertain) {
+    uint32_t remaining = 0xFFFFu, unc = 0;
     int sr = 0, sg = 0, sb = 0;
     uint64_t m = mixed;
     MGX_RSTAT(0, 1); MGX_RSTAT(1, __builtin_popcountll(mixed));
@@ -545,74 +560,57 @@ MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int bas
             MGX_RSTAT(2, 1);
             if (cov) {
                 MGX_RSTAT(3, 1); MGX_RSTAT(4, __builtin_popcount(cov)); MGX_RSTAT(5, __builtin_popcount(segmask));
-                // colour under the line for each touched sample: coverage masks of the opaque prims below it
-                // (front to back); a second line loop in that stack falls back to the generic per-sample painter
+                // colour under the line for each touched sample: coverage masks of the opaque prims below it (front to back)
                 constexpr int MAXL = 4;
-                uint32_t lcov[MAXL]; int lcol[MAXL]; int nlow = 0; bool generic = false;
+                uint32_t lcov[MAXL]; int lcol[MAXL]; int nlow = 0;
+                uint32_t lunc = 0;
                 const uint64_t lower = mixed & ((1ull << k) - 1ull);
                 for (uint64_t lm = lower; lm;) {
                     const int kk = 63 - __builtin_clzll(lm);
                     lm &= ~(1ull << kk);
                     const int kd = rs.prim_kind(kk);
-                    if (kd == PR_LINELOOP || nlow == MAXL) { generic = true; break; }
-                    lcov[nlow] = kd == PR_POLY ? poly_coverage16(rs, kk, X, Y) : ngon_coverage16(rs, kk, X, Y);
+                    if (kd == PR_LINELOOP || nlow == MAXL) { lunc = 0xFFFFu; break; }
+                    lcov[nlow] = kd == PR_POLY ? poly_coverage16(rs, kk, X, Y, lunc) : ngon_coverage16(rs, kk, X, Y, lunc);
                     lcol[nlow] = rs.prim_rgb(kk);
                     nlow++;
                 }
                 const int col = rs.prim_rgb(k);
-                const double lr = (double)(col & 0xFF), lg = (double)((col >> 8) & 0xFF), lb = (double)((col >> 16) & 0xFF);
-                uint32_t exact = cov;                      // samples that still need the exact fp64 painter
-                if (!generic) {
-                    // fp32 first: alpha of all 16 samples, then the blend; a sample whose rounded channel value could
-                    // flip within the fp32 error bound is left to the exact path
-                    float alpha[16]; uint32_t amb = 0;
-                    lineloop_alpha16(rs, k, X, Y, segmask, alpha, amb);
-                    const float lrf = (float)(col & 0xFF), lgf = (float)((col >> 8) & 0xFF), lbf = (float)((col >> 16) & 0xFF);
-                    constexpr float TAU = 255.0f * ALPHA_ERR_F + 5e-4f;
-                    exact = amb & cov;
+                float alpha[16];
+                lineloop_alpha16(rs, k, X, Y, segmask, alpha, lunc);
+                const float lrf = (float)(col & 0xFF), lgf = (float)((col >> 8) & 0xFF), lbf = (float)((col >> 16) & 0xFF);
+                constexpr float TAU = 255.0f * ALPHA_ERR_F + 5e-4f;
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-                    for (int sidx = 0; sidx < 16; sidx++) {
-                        if (!((cov >> sidx) & 1u) || ((amb >> sidx) & 1u)) continue;
-                        int c = base;
+#endif
+                for (int sidx = 0; sidx < 16; sidx++) {
+                    if (!(((cov & ~lunc) >> sidx) & 1u)) continue;
+                    int c = base;
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-                        for (int q = MAXL - 1; q >= 0; q--) if (q < nlow && ((lcov[q] >> sidx) & 1u)) c = lcol[q];   // back to front
-                        const float a = alpha[sidx];
-                        const float cr = (float)(c & 0xFF), cg = (float)((c >> 8) & 0xFF), cb = (float)((c >> 16) & 0xFF);
-                        const float vr = cr + a * (lrf - cr) + 0.5f, vg = cg + a * (lgf - cg) + 0.5f, vb = cb + a * (lbf - cb) + 0.5f;
-                        const float fr = floorf(vr), fg = floorf(vg), fb = floorf(vb);
-                        const float dr = r_abs(vr - fr - 0.5f), dg = r_abs(vg - fg - 0.5f), db = r_abs(vb - fb - 0.5f);
-                        if (r_max(r_max(dr, dg), db) > 0.5f - TAU) { exact |= 1u << sidx; continue; }
-                        sr += (int)fr; sg += (int)fg; sb += (int)fb;
-                    }
+#endif
+                    for (int q = MAXL - 1; q >= 0; q--) if (q < nlow && ((lcov[q] >> sidx) & 1u)) c = lcol[q];   // back to front
+                    const float a = alpha[sidx];
+                    const float cr = (float)(c & 0xFF), cg = (float)((c >> 8) & 0xFF), cb = (float)((c >> 16) & 0xFF);
+                    const float vr = cr + a * (lrf - cr) + 0.5f, vg = cg + a * (lgf - cg) + 0.5f, vb = cb + a * (lbf - cb) + 0.5f;
+                    const float fr = floorf(vr), fg = floorf(vg), fb = floorf(vb);
+                    const float dr = r_abs(vr - fr - 0.5f), dg = r_abs(vg - fg - 0.5f), db = r_abs(vb - fb - 0.5f);
+                    if (r_max(r_max(dr, dg), db) > 0.5f - TAU) { lunc |= 1u << sidx; continue; }
+                    sr += (int)fr; sg += (int)fg; sb += (int)fb;
                 }
-                MGX_RSTAT(6, __builtin_popcount(exact)); MGX_RSTAT(7, nlow); MGX_RSTAT(8, generic ? 1 : 0);
-                for (uint32_t t = exact; t; t &= t - 1) {
-                    const int sidx = __builtin_ctz(t);
-                    const double x = 4.0 * X + (sidx & 3) + 0.5, y = (double)NATIVE_RES - 0.5 - 4.0 * Y - (sidx >> 2);
-                    int c;
-                    if (generic) {
-                        c = raster_sample(rs, x, y, mixed & ((2ull << k) - 1ull), base);
-                    } else {
-                        c = base;
-                        for (int q = nlow - 1; q >= 0; q--) if ((lcov[q] >> sidx) & 1u) c = lcol[q];     // back to front
-                        const double a = lineloop_alpha_masked(rs, k, x, y, segmask);
-                        if (a > 0.0) {
-                            const int r = (int)rz_floor(a * lr + (1.0 - a) * (double)(c & 0xFF) + 0.5);
-                            const int g = (int)rz_floor(a * lg + (1.0 - a) * (double)((c >> 8) & 0xFF) + 0.5);
-                            const int b = (int)rz_floor(a * lb + (1.0 - a) * (double)((c >> 16) & 0xFF) + 0.5);
-                            c = r | (g << 8) | (b << 16);
-                        }
-                    }
-                    sr += c & 0xFF; sg += (c >> 8) & 0xFF; sb += (c >> 16) & 0xFF;
-                }
+                unc |= lunc & cov;
             }
         } else {
-            cov = (kind == PR_POLY ? poly_coverage16(rs, k, X, Y) : ngon_coverage16(rs, k, X, Y)) & remaining;
+            uint32_t punc = 0;
+            cov = (kind == PR_POLY ? poly_coverage16(rs, k, X, Y, punc) : ngon_coverage16(rs, k, X, Y, punc)) & remaining;
             MGX_RSTAT(9, 1);
+            punc &= remaining;
+            unc |= punc;
+            cov = (cov & ~punc);
             if (cov) {
                 const int n = __builtin_popcount(cov), col = rs.prim_rgb(k);
                 sr += n * (col & 0xFF); sg += n * ((col >> 8) & 0xFF); sb += n * ((col >> 16) & 0xFF);
             }
+            cov |= punc;
         }
         remaining &= ~cov;
     }
@@ -620,9 +618,31 @@ MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int bas
         const int n = __builtin_popcount(remaining);
         sr += n * (base & 0xFF); sg += n * ((base >> 8) & 0xFF); sb += n * ((base >> 16) & 0xFF);
     }
-    // cv2 INTER_AREA integer-factor path: saturate_cast<uchar>(sum * (1/16)) = round half to even
-    int r = (sr + 7 + ((sr >> 4) & 1)) >> 4, g = (sg + 7 + ((sg >> 4) & 1)) >> 4, b = (sb + 7 + ((sb >> 4) & 1)) >> 4;
+    MGX_RSTAT(6, unc ? 1 : 0); MGX_RSTAT(7, __builtin_popcount(unc));
+    uncertain = unc;
+    return (uint64_t)sr | ((uint64_t)sg << 12) | ((uint64_t)sb << 24);
+}
+// cv2 INTER_AREA integer-factor path: saturate_cast<uchar>(sum * (1/16)) = round half to even
+MGX_HD int pixel_finish(uint64_t sums) {
+    const int sr = (int)(sums & 0xFFF), sg = (int)((sums >> 12) & 0xFFF), sb = (int)((sums >> 24) & 0xFFF);
+    const int r = (sr + 7 + ((sr >> 4) & 1)) >> 4, g = (sg + 7 + ((sg >> 4) & 1)) >> 4, b = (sb + 7 + ((sb >> 4) & 1)) >> 4;
     return r | (g << 8) | (b << 16);
+}
+// add the samples in `uncertain` with the fp64 painter (what k_raster_native and the oracle do for every sample)
+MGX_HD uint64_t pixel_add_exact(const Raster &rs, int X, int Y, uint64_t mixed, int base, uint64_t sums, uint32_t uncertain) {
+    for (; uncertain; uncertain &= uncertain - 1) {
+        const int sidx = __builtin_ctz(uncertain);
+        const double x = 4.0 * X + (sidx & 3) + 0.5, y = (double)NATIVE_RES - 0.5 - 4.0 * Y - (sidx >> 2);
+        const int c = raster_sample(rs, x, y, mixed, base);
+        sums += (uint64_t)(c & 0xFF) | ((uint64_t)((c >> 8) & 0xFF) << 12) | ((uint64_t)((c >> 16) & 0xFF) << 24);
+    }
+    return sums;
+}
+MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int base) {
+    uint32_t unc;
+    uint64_t sums = pixel_resolve_fast(rs, X, Y, mixed, base, unc);
+    if (unc) sums = pixel_add_exact(rs, X, Y, mixed, base, sums, unc);
+    return pixel_finish(sums);
 }
 
 }  // namespace mgx

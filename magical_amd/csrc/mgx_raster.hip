@@ -31,6 +31,9 @@ struct RasterDev {
 constexpr int N_TILES = TILES_X * TILES_Y;
 constexpr int QCAP = 1024;     // LDS queue of undecided pixels per env; what does not fit waits in a bitmap for another round
 constexpr int OVF_WORDS = LORES * LORES / 32;
+#ifndef MGX_RASTER_WAVES
+#define MGX_RASTER_WAVES 4      // workgroups per CU the register allocation is capped for (= waves per SIMD)
+#endif
 #ifndef MGX_STACK_GROUP
 #define MGX_STACK_GROUP 4      // tiles whose old pixels are fetched ahead, per wavefront (STACK4 layout)
 #endif
@@ -107,7 +110,7 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
 }
 
 template <typename P, int LAYOUT>
-__global__ __launch_bounds__(256, 4) void k_raster(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
                                                 long env_stride, int view, const uint8_t *__restrict__ fill_mask, int n_envs) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
@@ -136,9 +139,11 @@ __global__ __launch_bounds__(256, 4) void k_raster(RasterDev t, const P *__restr
     uint64_t *q_mask = reinterpret_cast<uint64_t *>(tile_base + N_TILES);
     int32_t *q_pix = reinterpret_cast<int32_t *>(q_mask + QCAP);
     int32_t *q_base = q_pix + QCAP;
-    int32_t *q_count = q_base + QCAP;              // [0] entries pushed, [1] "some pixel did not fit" flag
-    uint32_t *q_ovf = reinterpret_cast<uint32_t *>(q_count + 2);   // bitmap of the pixels that did not fit
-    if (tid == 0) { q_count[0] = 0; q_count[1] = 0; }
+    int32_t *q_count = q_base + QCAP;              // [0] entries pushed, [1] "some pixel did not fit" flag, [2] entries for phase E
+    uint32_t *q_ovf = reinterpret_cast<uint32_t *>(q_count + 4);   // bitmap of the pixels that did not fit
+    uint64_t *e_sums = reinterpret_cast<uint64_t *>(q_ovf + OVF_WORDS);   // phase E: partial sums | uncertain samples << 40
+    uint16_t *e_list = reinterpret_cast<uint16_t *>(e_sums + QCAP);       // phase E: queue entry of each record
+    if (tid == 0) { q_count[0] = 0; q_count[1] = 0; q_count[2] = 0; }
     for (int i = tid; i < OVF_WORDS; i += 256) q_ovf[i] = 0;
     // phase S: screen-space setup (lane per body, lane per primitive, lane per primitive again for the item list)
     raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
@@ -295,12 +300,29 @@ __global__ __launch_bounds__(256, 4) void k_raster(RasterDev t, const P *__restr
         nq_total += nq;
         for (int i = tid; i < nq; i += 256) {
             const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;
-            const int c = pixel_resolve(rs, X, Y, q_mask[i], q_base[i]);
+            uint32_t unc;
+            const uint64_t sums = pixel_resolve_fast(rs, X, Y, q_mask[i], q_base[i], unc);
+            if (unc) {      // phase E adds the samples that need the fp64 painter
+                const int j = atomicAdd(&q_count[2], 1);
+                e_list[j] = (uint16_t)i; e_sums[j] = sums | ((uint64_t)unc << 40);
+                continue;
+            }
+            const int c = pixel_finish(sums);
+            if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
+        }
+        __syncthreads();
+        // phase E: the few samples whose fp32 result could not be guaranteed, with the fp64 painter
+        const int ne = q_count[2];
+        for (int j = tid; j < ne; j += 256) {
+            const int i = e_list[j];
+            const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;
+            const uint64_t rec = e_sums[j];
+            const int c = pixel_finish(pixel_add_exact(rs, X, Y, q_mask[i], q_base[i], rec & 0xFFFFFFFFFFull, (uint32_t)(rec >> 40)));
             if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
         }
         __syncthreads();
         if (!more) break;
-        if (tid == 0) { q_count[0] = 0; q_count[1] = 0; }
+        if (tid == 0) { q_count[0] = 0; q_count[1] = 0; q_count[2] = 0; }
         __syncthreads();
         for (int w = tid; w < OVF_WORDS; w += 256) {
             uint32_t bits = q_ovf[w];
@@ -325,7 +347,7 @@ __global__ __launch_bounds__(256, 4) void k_raster(RasterDev t, const P *__restr
 
 // 384x384x3 point-sampled frame of ONE env (no box filter): parity tests against the oracle / reference PNGs
 template <typename P>
-__global__ __launch_bounds__(256) void k_raster_native(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster_native(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
                                                        int view, long env, int n_envs) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;

@@ -23,8 +23,19 @@ struct TmplDev {
     int env_stride_words;      // per-env LDS stride in 32-bit words (multiple of 2)
     int env_off_r, env_off_i;  // word offsets of the R and int regions inside an env's slab (P region first)
     int lds_tmpl_words;        // words reserved for the template at the start of LDS (multiple of 2)
+    unsigned long long *dbg_clk;   // development probe (MGX_STEP_PROBE builds): per-workgroup phase cycles [blocks][32]
 };
 
+#ifdef MGX_STEP_PROBE
+constexpr bool probe_prefix(const char *s, const char *p) { return *p == 0 ? true : (*s == *p && probe_prefix(s + 1, p + 1)); }
+constexpr int probe_phase_id(const char *s) {
+    const char *names[] = {"ph_init_work", "ph_load_state", "ph_integrate", "ph_shapes", "ph_broad_count", "ph_broad_write", "ph_narrow",
+                           "ph_arbiters_joints", "solve_begin", "solve_warm_contacts", "solve_warm_joints", "solve_iter_publish",
+                           "solve_iter_contacts", "solve_iter_joints", "solve_end", "ph_cache_commit"};
+    for (int i = 0; i < 16; i++) if (probe_prefix(s, names[i])) return i;
+    return 19;
+}
+#endif
 template <typename R, typename P, int L>
 __global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
                                              const int32_t *__restrict__ actions, uint8_t *__restrict__ done,
@@ -53,7 +64,14 @@ __global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *_
     const long stride = n_envs;
     SolveCtx<R> ctx;
 
+#ifdef MGX_STEP_PROBE
+    // development build: shader cycles per phase, accumulated over the launch (tools/step_phase_probe.py)
+    unsigned long long pacc[20] = {0};
+#define SYNC(stmt) { constexpr int pid_ = probe_phase_id(#stmt); const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); \
+                     stmt; __syncthreads(); pacc[pid_] += __builtin_amdgcn_s_memtime() - t0_; }
+#else
 #define SYNC(stmt) stmt; __syncthreads();
+#endif
     SYNC(ph_init_work(e, lane, nl))
     SYNC(ph_load_state(e, sp, sf, si, stride, env, lane, nl))
     ph_refresh_trig(e, lane, nl);
@@ -71,6 +89,9 @@ __global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *_
     }
     __syncthreads();
     if (valid) ph_store_state(e, sp, sf, si, stride, env, lane, nl);
+#ifdef MGX_STEP_PROBE
+    if (t.dbg_clk && tid == 0) for (int i = 0; i < 20; i++) t.dbg_clk[(long)blockIdx.x * 32 + i] = pacc[i];
+#endif
 #undef SYNC
 }
 
