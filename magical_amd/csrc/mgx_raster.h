@@ -289,6 +289,8 @@ MGX_HD int raster_sample(const Raster &rs, double x, double y, uint64_t mask, in
 // broadcasts: the item fields become scalar operands, the loop is wave-uniform and touches no LDS.
 enum { IT_EDGE = 0, IT_NGON = 1, IT_SEG = 2 };
 constexpr int IT_LAST = 4;      // meta bit: last item of its primitive
+// meta = kind | IT_LAST | (items left in the prim, this one included) << 3 | prim << 12
+constexpr int IT_REM_SHIFT = 3, IT_REM_MASK = 0x1FF, IT_K_SHIFT = 12;
 struct Item {
     float a, b, c;              // EDGE/SEG: normalised line a x + b y + c;  NGON: centre x, y, apothem
     float g0, g1, g2, g3;       // EDGE: g0 / g1 = extent over a 4x4 block / a tile;  SEG: start x, y, length, half width;  NGON: g0 = circumradius
@@ -311,7 +313,7 @@ MGX_HD void raster_setup_items(Raster &rs, int lane, int nl) {
         if (kind == PR_NGON) {
             it[0].a = (float)RD(pcx, k); it[0].b = (float)RD(pcy, k); it[0].c = (float)RD(papo, k); it[0].g0 = (float)RD(prad, k);
             it[0].g1 = it[0].g2 = it[0].g3 = 0.0f;
-            it[0].meta = IT_NGON | IT_LAST | (k << 8);
+            it[0].meta = IT_NGON | IT_LAST | (1 << IT_REM_SHIFT) | (k << IT_K_SHIFT);
         } else {
             for (int i = 0; i < nv; i++) {
                 it[i].a = (float)RD(ea, vo + i); it[i].b = (float)RD(eb, vo + i); it[i].c = (float)RD(ec, vo + i);
@@ -319,12 +321,15 @@ MGX_HD void raster_setup_items(Raster &rs, int lane, int nl) {
                     it[i].g0 = (float)RD(svx, vo + i); it[i].g1 = (float)RD(svy, vo + i); it[i].g2 = (float)RD(elen, vo + i);
                     it[i].g3 = (float)RD(prad, k);
                 } else {
-                    // conservative half-extents of the edge function over a 4x4 sample block / over a whole tile
+                    // edge function divided by its conservative half-extent over a 4x4 sample block (g0..g2: the block is
+                    // entirely inside / outside this edge when the scaled value at its centre is > 1 / < -1), and the
+                    // reciprocal half-extent over a whole tile (g3)
                     float fa = r_abs(it[i].a), fb = r_abs(it[i].b);
-                    it[i].g0 = 1.5f * (fa + fb) + CLASS_EPS_F; it[i].g1 = TILE_HX * fa + TILE_HY * fb + CLASS_EPS_F;
-                    it[i].g2 = it[i].g3 = 0.0f;
+                    float ip = 1.0f / (1.5f * (fa + fb) + CLASS_EPS_F);
+                    it[i].g0 = it[i].a * ip; it[i].g1 = it[i].b * ip; it[i].g2 = it[i].c * ip;
+                    it[i].g3 = 1.0f / (TILE_HX * fa + TILE_HY * fb + CLASS_EPS_F);
                 }
-                it[i].meta = (kind == PR_POLY ? IT_EDGE : IT_SEG) | (i == nv - 1 ? IT_LAST : 0) | (k << 8);
+                it[i].meta = (kind == PR_POLY ? IT_EDGE : IT_SEG) | (i == nv - 1 ? IT_LAST : 0) | ((nv - i) << IT_REM_SHIFT) | (k << IT_K_SHIFT);
             }
         }
     }
@@ -349,13 +354,13 @@ MGX_HD int masked_item_index(const Raster &rs, uint64_t mask, int slot, int &n_t
     return found;
 }
 
-// per-lane classification state carried across item chunks.  For the primitive being consumed, `lo` / `hi` collect
-//   lo = min over its items of (worst-case inside margin)   -> NONE  when lo < 0 (some edge excludes the whole block)
-//   hi = min over its items of (best-case  inside margin)   -> ALL   when hi > 0 (every edge contains the whole block)
-// (for line loops `lo` is the max touch margin: the block may be touched when lo >= 0).
+// per-lane classification state carried across item chunks.  For the polygon being consumed `lo` is the minimum over
+// its edges of the edge function at the block centre divided by the edge's conservative half-extent over the block:
+//   lo < -1 -> NONE (some edge excludes the whole block),  lo > +1 -> ALL (every edge contains the whole block)
+// (n-gons report -2 / 0 / +2 on the same scale; for line loops `lo` is the max touch margin: touched when lo >= 0).
 struct ClassState {
-    uint64_t mixed; int base; int decided; float lo, hi;
-    MGX_HD void init(int bg) { mixed = 0; base = bg; decided = 0; lo = 1e30f; hi = 1e30f; }
+    uint64_t mixed; int base; int decided; float lo;
+    MGX_HD void init(int bg) { mixed = 0; base = bg; decided = 0; lo = 1e30f; }
 };
 constexpr float BIG_F = 1e30f;
 // Consume one item for the sample block centred at (xc, yc): TILE = whole 16x4-pixel tile (half extents TILE_HX/HY),
@@ -366,16 +371,17 @@ template <bool TILE> MGX_HD void classify_item(const Raster &rs, const Item &I, 
     const int kind = I.meta & 3;
     const float hx = TILE ? TILE_HX : 1.5f, hy = TILE ? TILE_HY : 1.5f;
     if (kind == IT_EDGE) {
-        const float e = I.a * xc + (I.b * yc + I.c), ext = TILE ? I.g1 : I.g0;
-        st.lo = r_min(st.lo, e + ext);
-        st.hi = r_min(st.hi, e - ext);
+        // scaled edge function: the block is outside this edge below -1, inside above +1; `lo` keeps the minimum
+        const float e = TILE ? (I.a * xc + (I.b * yc + I.c)) * I.g3 : I.g0 * xc + (I.g1 * yc + I.g2);
+        st.lo = r_min(st.lo, e);
     } else if (kind == IT_NGON) {
         const float qx = r_abs(xc - I.a), qy = r_abs(yc - I.b);
         const float nx = r_max(qx - hx, 0.0f), ny = r_max(qy - hy, 0.0f);        // nearest point of the rect
         const float fx = qx + hx, fy = qy + hy;                                    // farthest corner
         const float apo = I.c - CLASS_EPS_F, rad = I.g0 + CLASS_EPS_F;
-        st.lo = rad * rad - (nx * nx + ny * ny);
-        st.hi = apo > 0.0f ? apo * apo - (fx * fx + fy * fy) : -1.0f;
+        const float lo = rad * rad - (nx * nx + ny * ny);
+        const float hi = apo > 0.0f ? apo * apo - (fx * fx + fy * fy) : -1.0f;
+        st.lo = lo < 0.0f ? -2.0f : (hi > 0.0f ? 2.0f : 0.0f);                    // same scale as the edges
     } else {
         const float hw = I.g3 + CLASS_EPS_F;
         const float e = I.a * xc + (I.b * yc + I.c);
@@ -386,15 +392,15 @@ template <bool TILE> MGX_HD void classify_item(const Raster &rs, const Item &I, 
         st.lo = st.lo >= BIG_F ? t : r_max(st.lo, t);
     }
     if (I.meta & IT_LAST) {
-        const int k = I.meta >> 8;
+        const int k = I.meta >> IT_K_SHIFT;
         if (!st.decided) {
             if (kind == IT_SEG) { if (st.lo >= 0.0f) st.mixed |= 1ull << k; }
-            else if (!(st.lo < 0.0f)) {
-                if (st.hi > 0.0f) { st.base = rs.prim_rgb(k); st.decided = 1; }      // topmost covering prim hides the rest
+            else if (!(st.lo < -1.0f)) {
+                if (st.lo > 1.0f) { st.base = rs.prim_rgb(k); st.decided = 1; }     // topmost covering prim hides the rest
                 else st.mixed |= 1ull << k;
             }
         }
-        st.lo = BIG_F; st.hi = BIG_F;
+        st.lo = BIG_F;
     }
 }
 

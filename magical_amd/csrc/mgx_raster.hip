@@ -98,14 +98,63 @@ struct RegItems {
         return r;
     }
 };
-// consume items [0, n) held one per lane; stops at a primitive boundary once every lane of the wave is decided
+// consume items [0, n) held one per lane; stops at a primitive boundary once every lane of the wave is decided.
+// Same arithmetic as classify_item, organised as runs of one primitive's items so that the polygon-edge loop is
+// branch-free (3 broadcasts + 2 fma + 1 min per edge) and the per-primitive verdict is computed without divergence.
 template <bool TILE>
 __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegItems &src, int n, float xc, float yc,
                                                     ClassState &st, bool active) {
-    for (int i = 0; i < n; i++) {
-        const Item I = src.get(i);
-        classify_item<TILE>(rs, I, xc, yc, st);
-        if ((I.meta & IT_LAST) && __all(st.decided || !active)) break;
+    auto bc = [&](float v, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); };
+    const float hx = TILE ? TILE_HX : 1.5f, hy = TILE ? TILE_HY : 1.5f;
+    int i = 0;
+    while (i < n) {
+        const int meta = __builtin_amdgcn_readlane(src.my.meta, i);
+        const int kind = meta & 3, rem = (meta >> IT_REM_SHIFT) & IT_REM_MASK, k = meta >> IT_K_SHIFT;
+        const int run = rem < n - i ? rem : n - i;
+        const int rgb = rs.prim_rgb(k);                 // uniform LDS read, issued before the run so that it is free
+        float lo = st.lo;
+        if (kind == IT_EDGE) {
+            for (int j = i; j < i + run; j++) {
+                const float e = TILE ? (bc(src.my.a, j) * xc + (bc(src.my.b, j) * yc + bc(src.my.c, j))) * bc(src.my.g3, j)
+                                     : bc(src.my.g0, j) * xc + (bc(src.my.g1, j) * yc + bc(src.my.g2, j));
+                lo = r_min(lo, e);
+            }
+        } else if (kind == IT_NGON) {
+            const float qx = r_abs(xc - bc(src.my.a, i)), qy = r_abs(yc - bc(src.my.b, i));
+            const float nx = r_max(qx - hx, 0.0f), ny = r_max(qy - hy, 0.0f);
+            const float fx = qx + hx, fy = qy + hy;
+            const float apo = bc(src.my.c, i) - CLASS_EPS_F, rad = bc(src.my.g0, i) + CLASS_EPS_F;
+            const float l = rad * rad - (nx * nx + ny * ny);
+            const float h = apo > 0.0f ? apo * apo - (fx * fx + fy * fy) : -1.0f;
+            lo = l < 0.0f ? -2.0f : (h > 0.0f ? 2.0f : 0.0f);
+        } else {
+            for (int j = i; j < i + run; j++) {
+                const float a = bc(src.my.a, j), b = bc(src.my.b, j);
+                const float hw = bc(src.my.g3, j) + CLASS_EPS_F;
+                const float e = a * xc + (b * yc + bc(src.my.c, j));
+                const float sl = (xc - bc(src.my.g0, j)) * b - (yc - bc(src.my.g1, j)) * a;
+                const float el = hx * r_abs(a) + hy * r_abs(b), es = hx * r_abs(b) + hy * r_abs(a);
+                const float t = r_min(r_min(hw + el - r_abs(e), sl + es + hw), bc(src.my.g2, j) + hw + es - sl);
+                lo = lo >= BIG_F ? t : r_max(lo, t);
+            }
+        }
+        i += run;
+        if (run == rem) {
+            // the primitive is complete: verdict for this lane's block
+            const bool open = !st.decided;
+            const bool touch = kind == IT_SEG ? lo >= 0.0f : !(lo < -1.0f);
+            const bool all = kind != IT_SEG && lo > 1.0f;
+            const bool mix = open && touch && !all, cover = open && touch && all;
+            const uint64_t bit = 1ull << k;
+            st.mixed |= mix ? bit : 0ull;
+            st.base = cover ? rgb : st.base;
+            st.decided |= cover ? 1 : 0;
+            lo = BIG_F;
+            st.lo = lo;
+            if (__all(st.decided || !active)) break;
+        } else {
+            st.lo = lo;                                  // the primitive continues in the next 64-item chunk
+        }
     }
 }
 
