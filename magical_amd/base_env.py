@@ -122,6 +122,8 @@ class BaseEnv(abc.ABC):
             self._entities.append(ent)
 
     # ------------------------------------------------------------------ engine construction
+    _warm = False
+
     def _build(self):
         import torch
         L = self._lib
@@ -186,6 +188,11 @@ class BaseEnv(abc.ABC):
         nat.check(self._lib.mgx_engine_reset(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
                                              self.state_i.data_ptr(), None, self._stream()))
         self._steps[:] = 0
+        if not self._warm:
+            # the first pose read-back loads torch's gather / copy kernels (tens of ms, once per process); pay for it
+            # here rather than in the middle of the first rollout
+            self.get_poses(np.arange(self.n_envs))
+            self._warm = True
         return self._observe(fill_all=True)
 
     def step(self, actions):

@@ -308,8 +308,8 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
         int off_tiles = even(2 * ro.n_d + ro.n_i);
         e->rdev.off_tiles = off_tiles;
         // per-tile (u64 mask + i32 base) + queue (u64 mask + 2 x i32) + counters + overflow bitmap + phase E records (u64 sums, u16 entry)
-        int extra = N_TILES * 3 + QCAP * 4 + 4 + OVF_WORDS + QCAP * 2 + QCAP / 2;
-        e->rdev.qcap = QCAP;
+        int extra = N_TILES * 3 + QCAP * 4 + 4 + OVF_WORDS + ECAP * 2 + ECAP / 2;
+        e->rdev.qcap = QCAP; e->rdev.ecap = ECAP;
         e->lds_raster = (size_t)(total + off_tiles + extra) * 4;
     }
     *out = e;
@@ -411,6 +411,7 @@ int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_
     HIP_OK(hipGetLastError());
     return MGX_OK;
 }
+int mgx_engine_debug_raster_ecap(mgx_engine *e, int n) { if (e) e->rdev.ecap = n < 1 ? 1 : (n > ECAP ? ECAP : n); return MGX_OK; }
 int mgx_engine_debug_raster_qcap(mgx_engine *e, int n) { if (e) e->rdev.qcap = n < 1 ? 1 : (n > QCAP ? QCAP : n); return MGX_OK; }
 int mgx_engine_debug_raster_stop(mgx_engine *e, int phase) { if (e) e->rdev.dbg_stop = phase; return MGX_OK; }
 int mgx_engine_debug_raster_clocks(mgx_engine *e, void *buf) { if (e) e->rdev.dbg_clk = (unsigned long long *)buf; return MGX_OK; }

@@ -26,11 +26,13 @@ struct RasterDev {
     unsigned long long *dbg_clk;   // development probe: per-block phase clocks [n_envs][16] (NULL = off)
     int dbg_stop;                  // development probe: return after phase k (0 = run everything)
     int qcap;                      // queue entries in use (<= QCAP; tests shrink it to exercise the overflow rounds)
+    int ecap;                      // phase E records in use (<= ECAP; likewise)
 };
 
 constexpr int N_TILES = TILES_X * TILES_Y;
 constexpr int QCAP = 1024;     // LDS queue of undecided pixels per env; what does not fit waits in a bitmap for another round
 constexpr int OVF_WORDS = LORES * LORES / 32;
+constexpr int ECAP = 256;      // phase E records per round (uncertain pixels beyond that wait in the bitmap like queue overflow)
 #ifndef MGX_RASTER_WAVES
 #define MGX_RASTER_WAVES 4      // workgroups per CU the register allocation is capped for (= waves per SIMD)
 #endif
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, c
     int32_t *q_count = q_base + QCAP;              // [0] entries pushed, [1] "some pixel did not fit" flag, [2] entries for phase E
     uint32_t *q_ovf = reinterpret_cast<uint32_t *>(q_count + 4);   // bitmap of the pixels that did not fit
     uint64_t *e_sums = reinterpret_cast<uint64_t *>(q_ovf + OVF_WORDS);   // phase E: partial sums | uncertain samples << 40
-    uint16_t *e_list = reinterpret_cast<uint16_t *>(e_sums + QCAP);       // phase E: queue entry of each record
+    uint16_t *e_list = reinterpret_cast<uint16_t *>(e_sums + ECAP);       // phase E: queue entry of each record
     if (tid == 0) { q_count[0] = 0; q_count[1] = 0; q_count[2] = 0; }
     for (int i = tid; i < OVF_WORDS; i += 256) q_ovf[i] = 0;
     // phase S: screen-space setup (lane per body, lane per primitive, lane per primitive again for the item list)
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, c
     auto seq_tile = [&](int i) { return wave + 4 * i; };
     constexpr int N_SEQ = N_TILES / 4;
     static_assert(N_TILES % 4 == 0, "tiles per wave");
-    const int qcap = t.qcap;
+    const int qcap = t.qcap, ecap = t.ecap;
     PROBE(unsigned long long pr_gather = 0, pr_class = 0, pr_items = 0, pr_tiles = 0; const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();)
     // classify the pixels of one tile: returns the colour; `queued` when the pixel must wait for phase Q
     auto do_tile = [&](int tile, int X, int Y, bool &queued) -> int {
@@ -345,7 +347,6 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, c
     int nq_total = 0;
     for (;;) {
         const int nq = q_count[0] < qcap ? q_count[0] : qcap;
-        const bool more = q_count[1] != 0;
         nq_total += nq;
         for (int i = tid; i < nq; i += 256) {
             const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;
@@ -353,7 +354,13 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, c
             const uint64_t sums = pixel_resolve_fast(rs, X, Y, q_mask[i], q_base[i], unc);
             if (unc) {      // phase E adds the samples that need the fp64 painter
                 const int j = atomicAdd(&q_count[2], 1);
-                e_list[j] = (uint16_t)i; e_sums[j] = sums | ((uint64_t)unc << 40);
+                if (j < ecap) {
+                    e_list[j] = (uint16_t)i; e_sums[j] = sums | ((uint64_t)unc << 40);
+                } else {    // no record left this round: back to the bitmap
+                    const int p = Y * LORES + X;
+                    atomicOr(&q_ovf[p >> 5], 1u << (p & 31));
+                    q_count[1] = 1;
+                }
                 continue;
             }
             const int c = pixel_finish(sums);
@@ -361,7 +368,8 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, c
         }
         __syncthreads();
         // phase E: the few samples whose fp32 result could not be guaranteed, with the fp64 painter
-        const int ne = q_count[2];
+        const bool more = q_count[1] != 0;          // some pixel found no queue slot / no phase E record: another round
+        const int ne = q_count[2] < ecap ? q_count[2] : ecap;
         for (int j = tid; j < ne; j += 256) {
             const int i = e_list[j];
             const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;

@@ -161,8 +161,8 @@ def test_render_matches_oracle_bit_exact(task):
 
 @pytest.mark.parametrize('task', ['ClusterColour', 'MatchRegions'])
 def test_render_queue_overflow_rounds(task):
-    """The rasteriser's LDS queue of undecided pixels overflows into extra rounds; shrinking it to 64 / 1 entries
-    must not change a single byte of either layout."""
+    """The rasteriser's LDS queue of undecided pixels overflows into extra rounds; shrinking it (or the list of
+    uncertain pixels) to 64 / 1 entries must not change a single byte of either layout."""
     import torch
     n, t = 3, 9
     tape = _tape(23, t, n)
@@ -171,8 +171,9 @@ def test_render_queue_overflow_rounds(task):
     for s in range(t):
         env.step(tape[s])
     frames, stacks = [], []
-    for qcap in (1 << 20, 64, 1):
+    for qcap, ecap in ((1 << 20, 1 << 20), (64, 1 << 20), (1, 1 << 20), (1 << 20, 1)):
         env._lib.mgx_engine_debug_raster_qcap(env._engine, qcap)
+        env._lib.mgx_engine_debug_raster_ecap(env._engine, ecap)
         for view in ('ego', 'allo'):
             frame = torch.zeros((n, 96, 96, 3), dtype=torch.uint8, device='cuda:0')
             env.render_frames(frame, view=view, layout='frame')
@@ -184,9 +185,10 @@ def test_render_queue_overflow_rounds(task):
         assert np.array_equal(got[..., :9], old[..., 3:])
         stacks.append(got)
     env._lib.mgx_engine_debug_raster_qcap(env._engine, 1 << 20)
-    for k in (2, 4):
+    env._lib.mgx_engine_debug_raster_ecap(env._engine, 1 << 20)
+    for k in (2, 4, 6):
         assert np.array_equal(frames[k], frames[0]) and np.array_equal(frames[k + 1], frames[1])
-    assert np.array_equal(stacks[1], stacks[0]) and np.array_equal(stacks[2], stacks[0])
+    assert all(np.array_equal(st, stacks[0]) for st in stacks[1:])
     assert np.array_equal(stacks[0][..., 9:], frames[0])
     env.close()
 
