@@ -144,6 +144,17 @@ def main():
         kernels = {'k_step': (float(step_ms.mean()), step_bytes), 'k_raster': (float(rast_ms.mean()), rast_bytes)}
         dom = max(kernels, key=lambda k: kernels[k][0])
         ach = kernels[dom][1] / (kernels[dom][0] * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters: rocprofv3 cannot run inside this process, so the figure is the
+        # committed summary of the separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command
+        # (profiles/, produced by tools/pmc_summary.py; FETCH_SIZE doubled per MI355X_MICROARCH.md); default workload only
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_mtc_lores4e.json')
+        if args.task == TASK and n == N_ENVS and args.dtype == 'f32' and os.path.exists(pmc):
+            try:
+                traffic = float(json.load(open(pmc))[dom]['hbm_traffic_bytes_per_launch'])
+                traffic_src = 'profiles/r01_pmc_traffic_mtc_lores4e.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, median per launch)'
+            except Exception:
+                pass
         out = {
             'metric': 'env-steps/sec (incl. 96x96 LoRes4E render) at N_envs=4096', 'value': value, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True,
@@ -155,7 +166,7 @@ def main():
                        'mean_eval_score': float(all_scores.mean().item()),
                        'arith': 'fp32 velocities/impulses/contacts + fp64 poses; fp64 rasteriser' if args.dtype == 'f32' else args.dtype},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'avg_launch_ms': kernels[dom][0], 'algorithmic_bytes_per_launch': kernels[dom][1],
                          'other_kernels': {k: {'avg_launch_ms': v[0], 'algorithmic_bytes_per_launch': v[1],
                                                'achieved_GBs': v[1] / (v[0] * 1e-3) / 1e9} for k, v in kernels.items() if k != dom}},
