@@ -44,6 +44,10 @@ enum mgx_view { MGX_VIEW_EGO = 0, MGX_VIEW_ALLO = 1 };
 enum mgx_obs_layout {
     MGX_OBS_FRAME = 0,   /* u8[N][96][96][3]: just the new frame (caller owns any ring) */
     MGX_OBS_STACK4 = 1,  /* u8[N][96][96][12]: FlattenFrameStack semantics, oldest first; shifted in place */
+    /* the two halves of LoRes3EA = FlattenFrameStack({'allo': 1, 'ego': 3}) (benchmarks/__init__.py:219-251), both on
+     * the same u8[N][96][96][12] tensor, one launch per view: */
+    MGX_OBS_STACK3_HI = 2,  /* channels 3..11: depth-3 stack of this view, shifted in place; channels 0..2 untouched */
+    MGX_OBS_SLOT_LO = 3,    /* channels 0..2 <- this view's new frame; channels 3..11 untouched */
 };
 
 const char *mgx_last_error(void);

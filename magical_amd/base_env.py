@@ -298,7 +298,7 @@ class BaseEnv(abc.ABC):
 
     def render_frames(self, out, view='ego', layout='frame', fill_mask=None):
         """Rasterise every env into `out` (torch.uint8 on the engine device): [N,96,96,3] or [N,96,96,12]."""
-        lay = nat.OBS_FRAME if layout == 'frame' else nat.OBS_STACK4
+        lay = {'frame': nat.OBS_FRAME, 'stack4': nat.OBS_STACK4, 'stack3_hi': nat.OBS_STACK3_HI, 'slot_lo': nat.OBS_SLOT_LO}[layout]
         assert out.is_contiguous() and out.device == self.device and out.shape[0] == self.n_envs
         nat.check(self._lib.mgx_engine_render(self._engine, self.state_p.data_ptr(), out.data_ptr(), out.stride(0),
                                               nat.VIEW_EGO if view == 'ego' else nat.VIEW_ALLO, lay,

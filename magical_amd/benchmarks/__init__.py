@@ -13,7 +13,8 @@ Observation layouts (torch tensors on the engine's device):
   ...-LoRes4E-v0                 u8[N, 96, 96, 12]     4 ego frames, oldest first (benchmarks/__init__.py:252-256)
   ...-LoRes4A-v0                 u8[N, 96, 96, 12]     4 allo frames
   ...-LoResCHW4E-v0              u8[N, 12, 96, 96]     channels-first view of LoRes4E
-  ...-LoRes3EA-v0 / -LoResStack  registered, not built yet
+  ...-LoRes3EA-v0                u8[N, 96, 96, 12]     [allo_t, ego_t-2, ego_t-1, ego_t] (:242-245)
+  ...-LoResStack-v0              {'allo': u8[N, 96, 96, 12], 'ego': u8[N, 96, 96, 12]}  4 frames each (:257-261)
 """
 import collections
 import importlib
@@ -90,7 +91,7 @@ _ENV_TABLE = [
 ]
 
 AVAILABLE_PREPROCESSORS = ['LoRes3EA', 'LoRes4E', 'LoRes4A', 'LoResStack', 'LoResCHW4E']   # :242-274
-_BUILT_PREPROCESSORS = ('LoRes4E', 'LoRes4A', 'LoResCHW4E')
+_BUILT_PREPROCESSORS = ('LoRes3EA', 'LoRes4E', 'LoRes4A', 'LoResStack', 'LoResCHW4E')
 
 _ENV_NAME_RE = re.compile(
     r'^(?P<name_prefix>[^-]+)(?P<demo_test_spec>-(Demo|Test[^-]*))'

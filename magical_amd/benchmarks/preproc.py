@@ -1,33 +1,48 @@
 """Observation preprocessors: the batched mirror of the wrapper stacks in
-magical/benchmarks/__init__.py:208-274 (FlattenFrameStack + ResizeObservation + ChannelsFirst).
+magical/benchmarks/__init__.py:208-274 (FlattenFrameStack / EagerDictFrameStack + Resize*Observation + ChannelsFirst).
 
 In the reference these are gym.Wrappers around one env; here they are a mixin that changes what
-`_observe()` asks the rasteriser for.  The 4-frame stack lives in ONE torch.uint8 tensor
-[N, 96, 96, 12] that the raster kernel shifts in place (oldest frame first, newest last).
+`_observe()` asks the rasteriser for.  A 4-frame stack lives in ONE torch.uint8 tensor
+[N, 96, 96, 12] that the raster kernel shifts in place (oldest frame first, newest last):
+
+    LoRes4E / LoRes4A   4 ego / allo frames                                   (:246-256)
+    LoResCHW4E          LoRes4E moved to channels-first (a view, no copy)     (:262-268)
+    LoRes3EA            [allo_t, ego_t-2, ego_t-1, ego_t]                      (:242-245)
+    LoResStack          {'allo': 4 allo frames, 'ego': 4 ego frames}           (:257-261)
 """
 
 
 def wrap_preproc(env_cls, preproc):
     if preproc is None:
         return env_cls
-    view = {'LoRes4E': 'ego', 'LoRes4A': 'allo', 'LoResCHW4E': 'ego'}[preproc]
-    chw = preproc == 'LoResCHW4E'
+    if preproc not in ('LoRes4E', 'LoRes4A', 'LoResCHW4E', 'LoRes3EA', 'LoResStack'):
+        raise KeyError(preproc)
 
-    class _LoRes4(env_cls):
-        obs_view = view
-        channels_first = chw
+    class _LoRes(env_cls):
+        preproc_name = preproc
 
         def _build(self):
             import torch
             super()._build()
-            self._stack = torch.zeros((self.n_envs, 96, 96, 12), dtype=torch.uint8, device=self.device)
+            mk = lambda: torch.zeros((self.n_envs, 96, 96, 12), dtype=torch.uint8, device=self.device)
+            self._stack = mk()
+            self._stack_allo = mk() if preproc == 'LoResStack' else None
+            self._ones = torch.ones(self.n_envs, dtype=torch.uint8, device=self.device)
 
         def _observe(self, fill_all=False, fill_mask=None):
-            import torch
             if fill_all:
-                fill_mask = torch.ones(self.n_envs, dtype=torch.uint8, device=self.device)
-            self.render_frames(self._stack, view=self.obs_view, layout='stack4', fill_mask=fill_mask)
-            return self._stack.permute(0, 3, 1, 2) if self.channels_first else self._stack
+                fill_mask = self._ones
+            if preproc == 'LoRes3EA':
+                # both halves update the same 12-byte pixels; the launches are ordered by the stream
+                self.render_frames(self._stack, view='allo', layout='slot_lo', fill_mask=fill_mask)
+                self.render_frames(self._stack, view='ego', layout='stack3_hi', fill_mask=fill_mask)
+                return self._stack
+            if preproc == 'LoResStack':
+                self.render_frames(self._stack_allo, view='allo', layout='stack4', fill_mask=fill_mask)
+                self.render_frames(self._stack, view='ego', layout='stack4', fill_mask=fill_mask)
+                return {'allo': self._stack_allo, 'ego': self._stack}
+            self.render_frames(self._stack, view='allo' if preproc == 'LoRes4A' else 'ego', layout='stack4', fill_mask=fill_mask)
+            return self._stack.permute(0, 3, 1, 2) if preproc == 'LoResCHW4E' else self._stack
 
-    _LoRes4.__name__ = f'{env_cls.__name__}{preproc}'
-    return _LoRes4
+    _LoRes.__name__ = f'{env_cls.__name__}{preproc}'
+    return _LoRes

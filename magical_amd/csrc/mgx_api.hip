@@ -369,15 +369,14 @@ int mgx_engine_substeps(mgx_engine *e, void *state_p, void *state_f, int32_t *st
 template <typename P>
 static int launch_raster(mgx_engine *e, const void *sp, uint8_t *out, int64_t env_stride, int view, int layout, const uint8_t *fill, hipStream_t st) {
     size_t lds = e->lds_raster;
-    if (layout == MGX_OBS_FRAME) {
-        auto kern = k_raster<P, 0>;
+    auto go = [&](auto kern) -> int {
         if (lds > 65536) HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, fill, e->n_envs);
-    } else {
-        auto kern = k_raster<P, 1>;
-        if (lds > 65536) HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, fill, e->n_envs);
-    }
+        return MGX_OK;
+    };
+    int rc = layout == MGX_OBS_FRAME ? go(k_raster<P, 0>) : layout == MGX_OBS_STACK4 ? go(k_raster<P, 1>)
+           : layout == MGX_OBS_STACK3_HI ? go(k_raster<P, 2>) : go(k_raster<P, 3>);
+    if (rc) return rc;
     HIP_OK(hipGetLastError());
     return MGX_OK;
 }
@@ -387,7 +386,7 @@ int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t 
                       const uint8_t *fill_mask, void *stream) {
     if (!e || !state_p || !out) return fail(MGX_ERR_ARG, "NULL argument");
     if (view != MGX_VIEW_EGO && view != MGX_VIEW_ALLO) return fail(MGX_ERR_ARG, "bad view");
-    if (layout != MGX_OBS_FRAME && layout != MGX_OBS_STACK4) return fail(MGX_ERR_ARG, "bad layout");
+    if (layout < MGX_OBS_FRAME || layout > MGX_OBS_SLOT_LO) return fail(MGX_ERR_ARG, "bad layout");
     int64_t need = (int64_t)LORES * LORES * (layout == MGX_OBS_FRAME ? 3 : 12);
     if (env_stride < need || (env_stride & 3)) return fail(MGX_ERR_ARG, "env_stride too small or not a multiple of 4");
     if (e->h.n_prims > 64) return fail(MGX_ERR_CAPACITY, "draw list longer than 64 primitives");

@@ -40,44 +40,41 @@ constexpr int ECAP = 256;      // phase E records per round (uncertain pixels be
 #define MGX_STACK_GROUP 4      // tiles whose old pixels are fetched ahead, per wavefront (STACK4 layout)
 #endif
 
-// FlattenFrameStack shift of one pixel: 12 B read-modify-write (or 4 copies of the frame after a reset)
+// Output layouts (include/mgx.h mgx_obs_layout).  The three stacked ones address a 12 B pixel of u8[N][96][96][12]:
+//   1 STACK4   FlattenFrameStack of one view, depth 4: bytes 0..8 <- bytes 3..11, bytes 9..11 <- new frame
+//   2 STACK3HI depth 3 in bytes 3..11 (the 3 ego frames of LoRes3EA): bytes 3..8 <- bytes 6..11, bytes 9..11 <- new
+//   3 SLOT0    bytes 0..2 <- new frame, the rest untouched (the allo frame of LoRes3EA)
+// after a reset (`fill`) every frame of the stack is the new one.
+constexpr int LAY_FRAME = 0, LAY_STACK4 = 1, LAY_STACK3HI = 2, LAY_SLOT0 = 3;
 struct OldPx { uint32_t o0, o1, o2; };
-__device__ __forceinline__ OldPx load_stack4(const uint8_t *frame, int X, int Y) {
+template <int LAYOUT> __device__ __forceinline__ bool layout_needs_old(bool fill) { return LAYOUT == LAY_STACK4 ? !fill : true; }
+template <int LAYOUT> __device__ __forceinline__ OldPx load_old(const uint8_t *frame, int X, int Y) {
     const uint32_t *px = reinterpret_cast<const uint32_t *>(frame + (long)(Y * LORES + X) * 12);
-    OldPx o; o.o0 = px[0]; o.o1 = px[1]; o.o2 = px[2];
+    OldPx o; o.o0 = px[0];
+    if (LAYOUT == LAY_SLOT0) { o.o1 = 0; o.o2 = 0; } else { o.o1 = px[1]; o.o2 = px[2]; }
     return o;
 }
-// same shift with the old pixel already in registers (loaded a tile ahead so its latency hides behind classification)
-__device__ __forceinline__ void store_stack4_pre(uint8_t *frame, int X, int Y, int c, bool fill, const OldPx &o) {
+// the pixel update with the old pixel already in registers (loaded a tile ahead so its latency hides behind classification)
+template <int LAYOUT> __device__ __forceinline__ void store_pre(uint8_t *frame, int X, int Y, int c, bool fill, const OldPx &o) {
     uint32_t *px = reinterpret_cast<uint32_t *>(frame + (long)(Y * LORES + X) * 12);
     const uint32_t r = c & 0xFF, g = (c >> 8) & 0xFF, b = (c >> 16) & 0xFF;
+    if (LAYOUT == LAY_SLOT0) { px[0] = (o.o0 & 0xFF000000u) | ((uint32_t)c & 0xFFFFFFu); return; }
     uint32_t d0, d1, d2;
     if (fill) {
-        d0 = r | (g << 8) | (b << 16) | (r << 24);
+        d0 = LAYOUT == LAY_STACK4 ? (r | (g << 8) | (b << 16) | (r << 24)) : ((o.o0 & 0xFFFFFFu) | (r << 24));
         d1 = g | (b << 8) | (r << 16) | (g << 24);
         d2 = b | (r << 8) | (g << 16) | (b << 24);
     } else {
-        d0 = (o.o0 >> 24) | (o.o1 << 8);
+        d0 = LAYOUT == LAY_STACK4 ? ((o.o0 >> 24) | (o.o1 << 8)) : ((o.o0 & 0xFFFFFFu) | ((o.o1 >> 16) << 24));
         d1 = (o.o1 >> 24) | (o.o2 << 8);
         d2 = (o.o2 >> 24) | ((uint32_t)c << 8);
     }
     px[0] = d0; px[1] = d1; px[2] = d2;
 }
-__device__ __forceinline__ void store_stack4(uint8_t *frame, int X, int Y, int c, bool fill) {
-    uint32_t *px = reinterpret_cast<uint32_t *>(frame + (long)(Y * LORES + X) * 12);
-    const uint32_t r = c & 0xFF, g = (c >> 8) & 0xFF, b = (c >> 16) & 0xFF;
-    uint32_t d0, d1, d2;
-    if (fill) {
-        d0 = r | (g << 8) | (b << 16) | (r << 24);
-        d1 = g | (b << 8) | (r << 16) | (g << 24);
-        d2 = b | (r << 8) | (g << 16) | (b << 24);
-    } else {
-        const uint32_t o0 = px[0], o1 = px[1], o2 = px[2];
-        d0 = (o0 >> 24) | (o1 << 8);
-        d1 = (o1 >> 24) | (o2 << 8);
-        d2 = (o2 >> 24) | ((uint32_t)c << 8);
-    }
-    px[0] = d0; px[1] = d1; px[2] = d2;
+template <int LAYOUT> __device__ __forceinline__ void store_rmw(uint8_t *frame, int X, int Y, int c, bool fill) {
+    OldPx o{0, 0, 0};
+    if (layout_needs_old<LAYOUT>(fill)) o = load_old<LAYOUT>(frame, X, Y);
+    store_pre<LAYOUT>(frame, X, Y, c, fill, o);
 }
 __device__ __forceinline__ void store_frame_px(uint8_t *frame, int X, int Y, int c) {
     uint8_t *q = frame + (long)(Y * LORES + X) * 3;
@@ -230,7 +227,8 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, c
 
     // phase T: each wavefront walks its tiles, one lane per output pixel
     const int tx = lane & (TILE_W - 1), ty = lane >> 4;
-    const bool fill = LAYOUT == 1 && fill_mask != nullptr && fill_mask[env] != 0;
+    const bool fill = LAYOUT != LAY_FRAME && fill_mask != nullptr && fill_mask[env] != 0;
+    const bool need_old = layout_needs_old<LAYOUT>(fill);
     uint8_t *frame = out + env * env_stride;
     // wave w walks tiles w, w + 4, ... (pairing horizontally adjacent tiles to complete 128 B lines back to back was
     // measured slower and produced more write-back traffic)
@@ -277,7 +275,7 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, c
         }
         return st.base;
     };
-    if (LAYOUT == 0) {
+    if (LAYOUT == LAY_FRAME) {
         for (int seq = 0; seq < N_SEQ; seq++) {
             const int tile = seq_tile(seq);
             const int tcol = tile % TILES_X, trow = tile / TILES_X;
@@ -306,7 +304,7 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, c
         for (int u = 0; u < G; u++) {
             nxt[u] = OldPx{0, 0, 0};
             const int tile = seq_tile(u);
-            if (!fill) nxt[u] = load_stack4(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty);
+            if (need_old) nxt[u] = load_old<LAYOUT>(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty);
         }
         for (int g = 0; g < N_SEQ; g += G) {
             OldPx cur[G];
@@ -314,7 +312,7 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, c
             for (int u = 0; u < G; u++) {
                 cur[u] = nxt[u];
                 const int tile = seq_tile(g + G + u);
-                if (!fill && g + G < N_SEQ) nxt[u] = load_stack4(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty);
+                if (need_old && g + G < N_SEQ) nxt[u] = load_old<LAYOUT>(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty);
             }
             int col[G];
 #pragma unroll
@@ -333,7 +331,7 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, c
             for (int u = 0; u < G; u++) {
                 const int tile = seq_tile(g + u);
                 if (!((qbits >> u) & 1u))
-                    store_stack4_pre(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty, col[u], fill, cur[u]);
+                    store_pre<LAYOUT>(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty, col[u], fill, cur[u]);
             }
         }
     }
@@ -364,7 +362,7 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, c
                 continue;
             }
             const int c = pixel_finish(sums);
-            if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
+            if (LAYOUT == LAY_FRAME) store_frame_px(frame, X, Y, c); else store_rmw<LAYOUT>(frame, X, Y, c, fill);
         }
         __syncthreads();
         // phase E: the few samples whose fp32 result could not be guaranteed, with the fp64 painter
@@ -375,7 +373,7 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, c
             const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;
             const uint64_t rec = e_sums[j];
             const int c = pixel_finish(pixel_add_exact(rs, X, Y, q_mask[i], q_base[i], rec & 0xFFFFFFFFFFull, (uint32_t)(rec >> 40)));
-            if (LAYOUT == 0) store_frame_px(frame, X, Y, c); else store_stack4(frame, X, Y, c, fill);
+            if (LAYOUT == LAY_FRAME) store_frame_px(frame, X, Y, c); else store_rmw<LAYOUT>(frame, X, Y, c, fill);
         }
         __syncthreads();
         if (!more) break;

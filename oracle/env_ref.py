@@ -127,3 +127,59 @@ class LoRes4ERef:
     def _obs(self):
         stacked = np.concatenate(list(self.frames), axis=-1)
         return area_downsample(stacked, DEFAULT_RES // 96)
+
+
+class LoRes3EARef:
+    """FlattenFrameStack(OrderedDict(allo=1, ego=3)) then ResizeObservation(96)
+    (benchmarks/__init__.py:219-251, :80-136): channels = [allo_t, ego_t-2, ego_t-1, ego_t]."""
+
+    def __init__(self, env):
+        self.env = env
+        self.allo = collections.deque(maxlen=1)
+        self.ego = collections.deque(maxlen=3)
+
+    def reset(self):
+        self.env.reset()
+        self.allo.append(self.env.render('allo'))
+        ego = self.env.render('ego')
+        for _ in range(3):
+            self.ego.append(ego)
+        return self._obs()
+
+    def step(self, action):
+        rew, done, info = self.env.step(action)
+        self.allo.append(self.env.render('allo'))
+        self.ego.append(self.env.render('ego'))
+        return self._obs(), rew, done, info
+
+    def _obs(self):
+        stacked = np.concatenate(list(self.allo) + list(self.ego), axis=-1)
+        return area_downsample(stacked, DEFAULT_RES // 96)
+
+
+class LoResStackRef:
+    """ResizeDictObservation(96) then EagerDictFrameStack(4) (benchmarks/__init__.py:46-77,139-169,204-215):
+    obs = {'allo': u8[96,96,12], 'ego': u8[96,96,12]}, oldest frame first in each."""
+
+    def __init__(self, env):
+        self.env = env
+        self.frames = collections.deque(maxlen=4)
+
+    def _frame(self):
+        f = DEFAULT_RES // 96
+        return {'allo': area_downsample(self.env.render('allo'), f), 'ego': area_downsample(self.env.render('ego'), f)}
+
+    def reset(self):
+        self.env.reset()
+        frame = self._frame()
+        for _ in range(4):
+            self.frames.append(frame)
+        return self._obs()
+
+    def step(self, action):
+        rew, done, info = self.env.step(action)
+        self.frames.append(self._frame())
+        return self._obs(), rew, done, info
+
+    def _obs(self):
+        return {k: np.concatenate([fr[k] for fr in self.frames], axis=-1) for k in ('allo', 'ego')}

@@ -193,6 +193,48 @@ def test_render_queue_overflow_rounds(task):
     env.close()
 
 
+@pytest.mark.parametrize('preproc', ['LoRes3EA', 'LoResStack', 'LoRes4A', 'LoResCHW4E'])
+def test_other_preprocessors_match_oracle(preproc):
+    """The remaining wrapper stacks of benchmarks/__init__.py:242-268 on device, byte for byte against the oracle's
+    restatement of the same wrappers, across an auto-reset."""
+    from oracle.env_ref import LoRes3EARef, LoRes4ERef, LoResStackRef, RefEnv
+    n, steps, ep = 2, 7, 5
+    task = 'MatchRegions'
+    env = _make(f'{task}-Demo-{preproc}-v0', n, dtype='f64', max_episode_steps=ep)
+
+    class LoRes4ARef(LoRes4ERef):          # FlattenFrameStack(allo=4, ego=0): the same pipeline on the other view
+        def reset(self):
+            self.env.reset(); fr = self.env.render('allo'); [self.frames.append(fr) for _ in range(4)]; return self._obs()
+
+        def step(self, a):
+            r = self.env.step(a); self.frames.append(self.env.render('allo')); return (self._obs(),) + tuple(r)
+
+    mk = {'LoRes3EA': LoRes3EARef, 'LoResStack': LoResStackRef, 'LoRes4A': LoRes4ARef, 'LoResCHW4E': LoRes4ERef}[preproc]
+    refs = [mk(RefEnv(task, max_episode_steps=ep)) for _ in range(n)]
+
+    def same(got, want, k):
+        if preproc == 'LoResStack':
+            return all(np.array_equal(got[v][k].cpu().numpy(), want[v]) for v in ('allo', 'ego'))
+        g = got[k].cpu().numpy()
+        return np.array_equal(np.moveaxis(g, 0, -1) if preproc == 'LoResCHW4E' else g, want)
+
+    obs = env.reset()
+    first = [r.reset() for r in refs]
+    for k in range(n):
+        assert same(obs, first[k], k)
+    tape = _tape(29, steps, n)
+    for s in range(steps):
+        obs, rew, done, info = env.step(tape[s])
+        for k, r in enumerate(refs):
+            o, _, d, inf = r.step(tape[s, k])
+            assert d == done[k]
+            if d:      # auto-reset: the stack holds copies of the new episode's first frame
+                assert same(obs, r.reset(), k), (preproc, s, k)
+            else:
+                assert same(obs, o, k), (preproc, s, k)
+    env.close()
+
+
 def test_lores4e_stack_and_autoreset():
     """FlattenFrameStack semantics on device: reset fills 4 copies, step shifts by one frame, auto-reset refills;
     compared with the oracle's LoRes4E pipeline for the first steps."""
