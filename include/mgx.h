@@ -74,6 +74,10 @@ enum mgx_info_key {
     MGX_INFO_N_BODIES = 0, MGX_INFO_N_SHAPES, MGX_INFO_N_JOINTS, MGX_INFO_N_PAIRS, MGX_INFO_N_PRIMS,
     MGX_INFO_STATE_ROWS_P, MGX_INFO_STATE_ROWS_F, MGX_INFO_STATE_ROWS_I, MGX_INFO_ROBOT_BODY, MGX_INFO_N_ENTITIES,
     MGX_INFO_CACHE_SLOTS, MGX_INFO_MAX_CONTACTS, MGX_INFO_MAX_EPISODE_STEPS, MGX_INFO_N_JACC,
+    /* rand_dynamics (base_env.py:198-203, phys_vars.py): rows PHYSVAR_ROW .. +4 of the motion blob hold each env's
+     * five joint force limits as max impulse per substep = max_force x (1 / fps / phys_steps); mgx_engine_reset()
+     * writes the world's defaults, the host overwrites them for the envs it has sampled PhysicsVariables for */
+    MGX_INFO_PHYSVAR_ROW,
 };
 int mgx_world_info(const mgx_world *w, int key, int *out);
 /* body index of entity `ent` (shape body; -1 for goals) and its type/colour */

@@ -20,7 +20,7 @@ VIEW_EGO, VIEW_ALLO = 0, 1
 OBS_FRAME, OBS_STACK4, OBS_STACK3_HI, OBS_SLOT_LO = 0, 1, 2, 3
 INFO = {k: i for i, k in enumerate([
     'n_bodies', 'n_shapes', 'n_joints', 'n_pairs', 'n_prims', 'state_rows_p', 'state_rows_f', 'state_rows_i',
-    'robot_body', 'n_entities', 'cache_slots', 'max_contacts', 'max_episode_steps', 'n_jacc'])}
+    'robot_body', 'n_entities', 'cache_slots', 'max_contacts', 'max_episode_steps', 'n_jacc', 'physvar_row'])}
 
 
 class MgxError(RuntimeError):

@@ -21,6 +21,7 @@ import numpy as np
 
 from . import _native as nat
 from . import entities as en
+from . import spaces
 
 
 class PhysicsVariables:
@@ -57,8 +58,6 @@ class BaseEnv(abc.ABC):
         if fps != 8 or phys_steps != 10 or phys_iter != 10:
             raise NotImplementedError('the engine is built for the registered rates: fps=8, 10 substeps, 10 iterations '
                                       '(benchmarks/__init__.py:401-404)')
-        if rand_dynamics:
-            raise NotImplementedError('rand_dynamics (Test* variants) is not built yet; Demo variants only')
         assert ego_view or allo_view, 'must use egocentric view or allocentric view (or both)'
         self.n_envs, self.fps, self.phys_steps, self.phys_iter = int(n_envs), fps, phys_steps, phys_iter
         self.res_hw, self.max_episode_steps = tuple(res_hw), max_episode_steps
@@ -71,6 +70,9 @@ class BaseEnv(abc.ABC):
         self._dtype = {'f32': nat.MGX_F32, 'f64': nat.MGX_F64, 'f32_pure': nat.MGX_F32_PURE}[dtype]
         self._lanes = lanes_per_env
         self.action_space_n = len(en.ACTION_NUMS_FLAGS_NAMES)
+        # per-env spaces, as a gym VecEnv reports them (base_env.py:97-109); `num_envs` envs run in lockstep
+        self.num_envs = self.n_envs
+        self.action_space = spaces.Discrete(self.action_space_n)
         self._lib = nat.lib()
         self._world = None
         self._engine = None
@@ -78,6 +80,7 @@ class BaseEnv(abc.ABC):
         self._robot = None
         self.seed()
         self._build()
+        self.observation_space = self._observation_space()
 
     # ------------------------------------------------------------------ reference protocol
     def action_to_flags(self, int_action):
@@ -87,9 +90,13 @@ class BaseEnv(abc.ABC):
         return en.FLAGS_TO_ACTION_ID[tuple(flags)]
 
     def seed(self, seed=None):
+        """base_env.py:133-140.  Every env of the batch has its own np.random.RandomState: env k is seeded with
+        `seed + k` (what gym's VectorEnv.seed(int) does), so env 0 draws exactly what the reference env seeded with
+        `seed` draws.  `self.rng` is env 0's."""
         if seed is None:
             seed = np.random.randint(0, (1 << 31) - 1)
-        self.rng = np.random.RandomState(seed=seed)
+        self.rngs = [np.random.RandomState(seed=(seed + k) % (1 << 32)) for k in range(self.n_envs)]
+        self.rng = self.rngs[0]
         return [seed]
 
     def _make_robot(self, init_pos, init_angle):
@@ -159,6 +166,7 @@ class BaseEnv(abc.ABC):
         self._done_dev = torch.zeros(self.n_envs, dtype=torch.uint8, device=self.device)
         self._reward = torch.zeros(self.n_envs, dtype=torch.float32, device=self.device)
         self._steps = np.zeros(self.n_envs, dtype=np.int64)
+        self.phys_vars = np.tile(np.asarray(PhysicsVariables.defaults(), dtype=np.float64), (self.n_envs, 1))   # per env
         # pose-blob row of (x, y, angle) per body, -1 where the body is not persistent
         n = nat.check(L.mgx_world_n_state_entries(w))
         self._pose_rows = -np.ones((self.n_bodies, 3), dtype=np.int64)
@@ -188,6 +196,8 @@ class BaseEnv(abc.ABC):
         nat.check(self._lib.mgx_engine_reset(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
                                              self.state_i.data_ptr(), None, self._stream()))
         self._steps[:] = 0
+        if self.rand_dynamics:
+            self._sample_phys_vars(np.arange(self.n_envs))
         if not self._warm:
             # the first pose read-back loads torch's gather / copy kernels (tens of ms, once per process); pay for it
             # here rather than in the middle of the first rollout
@@ -219,9 +229,30 @@ class BaseEnv(abc.ABC):
                 nat.check(self._lib.mgx_engine_reset(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
                                                      self.state_i.data_ptr(), self._done_dev.data_ptr(), self._stream()))
                 self._steps[idx] = 0
+                if self.rand_dynamics:
+                    self._sample_phys_vars(idx)
                 fill = self._done_dev
         obs = self._observe(fill_mask=fill)
         return obs, self._reward, done, {'eval_score': eval_score}
+
+    def _sample_phys_vars(self, env_idx):
+        """base_env.py:198-203: PhysicsVariables.sample(rng) for the envs being reset, five rng.uniform draws each in
+        declaration order (phys_vars.py:84-88), written into the envs' force-limit rows."""
+        vals = np.array([PhysicsVariables.sample(self.rngs[k]) for k in env_idx], dtype=np.float64)
+        self.set_phys_vars(vals, env_idx)
+
+    def set_phys_vars(self, values, env_idx=None):
+        """values: float64[M, 5] joint max forces (robot_pos, robot_rot, robot_finger, shape_trans, shape_rot) of the
+        envs `env_idx` (default: all).  Stored as max impulse per substep, like the template's own limits."""
+        import torch
+        values = np.asarray(values, dtype=np.float64).reshape(-1, 5)
+        idx = np.arange(self.n_envs) if env_idx is None else np.asarray(env_idx)
+        assert values.shape[0] == len(idx)
+        self.phys_vars[idx] = values
+        dt = 1.0 / self.fps / self.phys_steps
+        row = self._info('physvar_row')
+        imp = torch.as_tensor((values * dt).T.copy(), device=self.device).to(self.state_f.dtype)        # [5, M]
+        self.state_f[row:row + 5, torch.as_tensor(idx, device=self.device)] = imp
 
     def close(self):
         if self._engine is not None:
@@ -238,6 +269,11 @@ class BaseEnv(abc.ABC):
             pass
 
     # ------------------------------------------------------------------ observations
+    def _observation_space(self):
+        """Space of ONE env's observation.  Without a preprocessor that is this engine's state-only observation; the
+        reference's Dict{'allo','ego': Box(0,255,(384,384,3),u8)} (base_env.py:97-107) is what `render()` returns."""
+        return spaces.Box(-np.inf, np.inf, (self.n_bodies, 3), np.float32)
+
     def _observe(self, fill_all=False, fill_mask=None):
         """Default (no preprocessor): state-only observation f32[N, n_bodies, 3] = (x, y, angle)."""
         return self.get_poses_tensor()

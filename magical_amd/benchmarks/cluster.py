@@ -16,7 +16,7 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
     def __init__(self, rand_shape_colour=False, rand_shape_type=False, rand_layout_minor=False, rand_layout_full=False,
                  rand_shape_count=False, cluster_by=ClusterBy.COLOUR, **kwargs):
         if rand_shape_colour or rand_shape_type or rand_layout_minor or rand_layout_full or rand_shape_count:
-            raise NotImplementedError('only the Demo variant is built (Test* variants: SURVEY.md §8f)')
+            raise NotImplementedError('only the Demo and TestDynamics variants are built (the other Test* variants need per-env geometry: SURVEY.md §8f)')
         self.cluster_by = cluster_by
         super().__init__(**kwargs)
 

@@ -44,7 +44,7 @@ class MakeLineEnv(BaseEnv):
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
         if rand_colours or rand_shapes or rand_count or rand_layout_minor or rand_layout_full:
-            raise NotImplementedError('only the Demo variant is built (Test* variants: SURVEY.md §8f)')
+            raise NotImplementedError('only the Demo and TestDynamics variants are built (the other Test* variants need per-env geometry: SURVEY.md §8f)')
         super().__init__(**kwargs)
         self.inlier_dist = self.SHAPE_RAD * INLIER_RAD_MULT
         self.max_sep = self.SHAPE_RAD * MAX_SEP_RADS

@@ -12,7 +12,7 @@ class MatchRegionsEnv(BaseEnv):
     def __init__(self, rand_target_colour=False, rand_shape_type=False, rand_shape_count=False,
                  rand_layout_minor=False, rand_layout_full=False, **kwargs):
         if rand_target_colour or rand_shape_type or rand_shape_count or rand_layout_minor or rand_layout_full:
-            raise NotImplementedError('only the Demo variant is built (Test* variants: SURVEY.md §8f)')
+            raise NotImplementedError('only the Demo and TestDynamics variants are built (the other Test* variants need per-env geometry: SURVEY.md §8f)')
         super().__init__(**kwargs)
 
     def on_reset(self):   # match_regions.py:44-162

@@ -11,7 +11,7 @@ from ._scoring import row_norm
 class MoveToCornerEnv(BaseEnv):
     def __init__(self, rand_shape_colour=False, rand_shape_type=False, rand_poses=False, debug_reward=False, **kwargs):
         if rand_shape_colour or rand_shape_type or rand_poses or debug_reward:
-            raise NotImplementedError('only the Demo variant is built (Test* variants: SURVEY.md §8f)')
+            raise NotImplementedError('only the Demo and TestDynamics variants are built (the other Test* variants need per-env geometry: SURVEY.md §8f)')
         super().__init__(**kwargs)
 
     def on_reset(self):   # move_to_corner.py:31-54

@@ -12,7 +12,7 @@ DEFAULT_GOAL_XYHW = (-0.62, -0.17, 0.76, 0.75)
 class MoveToRegionEnv(BaseEnv):
     def __init__(self, rand_poses_minor=False, rand_poses_full=False, rand_goal_colour=False, **kwargs):
         if rand_poses_minor or rand_poses_full or rand_goal_colour:
-            raise NotImplementedError('only the Demo variant is built (Test* variants: SURVEY.md §8f)')
+            raise NotImplementedError('only the Demo and TestDynamics variants are built (the other Test* variants need per-env geometry: SURVEY.md §8f)')
         super().__init__(**kwargs)
 
     def on_reset(self):   # move_to_region.py:30-63

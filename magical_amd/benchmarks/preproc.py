@@ -29,6 +29,11 @@ def wrap_preproc(env_cls, preproc):
             self._stack_allo = mk() if preproc == 'LoResStack' else None
             self._ones = torch.ones(self.n_envs, dtype=torch.uint8, device=self.device)
 
+        def _observation_space(self):
+            from .. import spaces
+            box = spaces.Box(0, 255, (12, 96, 96) if preproc == 'LoResCHW4E' else (96, 96, 12), 'uint8')
+            return spaces.Dict([('allo', box), ('ego', box)]) if preproc == 'LoResStack' else box
+
         def _observe(self, fill_all=False, fill_mask=None):
             if fill_all:
                 fill_mask = self._ones

@@ -117,6 +117,7 @@ int mgx_world_info(const mgx_world *w, int key, int *out) {
         case MGX_INFO_MAX_CONTACTS: *out = h.max_contacts; break;
         case MGX_INFO_MAX_EPISODE_STEPS: *out = h.max_episode_steps; break;
         case MGX_INFO_N_JACC: *out = h.n_jacc; break;
+        case MGX_INFO_PHYSVAR_ROW: *out = state_row_physvar(h, 0); break;
         default: return fail(MGX_ERR_ARG, "unknown info key");
     }
     return MGX_OK;

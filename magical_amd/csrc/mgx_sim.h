@@ -554,7 +554,7 @@ template <typename R, typename P> MGX_HD void joint_apply_impulse(Env<R, P> &e, 
         R dx = E_R(jb0, j) - vrx, dy = E_R(jb1, j) - vry;
         R jx = dx * E_R(jk0, j) + dy * E_R(jk1, j), jy = dx * E_R(jk2, j) + dy * E_R(jk3, j);
         R ox = E_R(ja0, j), oy = E_R(ja1, j);
-        R nxv = ox + jx, nyv = oy + jy, lim = p[9];
+        R nxv = ox + jx, nyv = oy + jy, lim = E_R(jlim, j);
         R l2 = nxv * nxv + nyv * nyv;
         if (l2 > lim * lim) { R sc = lim / (r_sqrt(l2) + r_tiny<R>()); nxv *= sc; nyv *= sc; }
         E_R(ja0, j) = nxv; E_R(ja1, j) = nyv;
@@ -567,7 +567,7 @@ template <typename R, typename P> MGX_HD void joint_apply_impulse(Env<R, P> &e, 
         R ratio = p[5], ratio_inv = R(1) / ratio;
         R wa = E_R(w, a), wb = E_R(w, b);
         R wr = wb * ratio - wa;
-        R jmax = p[9];
+        R jmax = E_R(jlim, j);
         R jj = (E_R(jb0, j) - wr) * p[0];
         R jold = E_R(ja0, j);
         R jn = r_clamp(jold + jj, -jmax, jmax);
@@ -589,7 +589,7 @@ template <typename R, typename P> MGX_HD void joint_apply_impulse(Env<R, P> &e, 
         Vel<R> va = LOADV(a), vb = LOADV(b);
         R vrx = (vb.vx - r2y * vb.w) - (va.vx - r1y * va.w), vry = (vb.vy + r2x * vb.w) - (va.vy + r1x * va.w);
         R vrn = vrx * nx + vry * ny;
-        R jmax = p[9];
+        R jmax = E_R(jlim, j);
         R jn = (E_R(jb0, j) - vrn) * E_R(jk2, j);
         R jold = E_R(ja0, j);
         R jnew = r_clamp(jold + jn, -jmax, jmax);
@@ -604,7 +604,7 @@ template <typename R, typename P> MGX_HD void joint_apply_impulse(Env<R, P> &e, 
         if (bias == R(0)) return;
         R wa = E_R(w, a), wb = E_R(w, b);
         R wr = wb - wa;
-        R jmax = p[9];
+        R jmax = E_R(jlim, j);
         R jj = -(bias + wr) * p[0];
         R jold = E_R(ja0, j);
         R jn = bias < R(0) ? r_clamp(jold + jj, R(0), jmax) : r_clamp(jold + jj, -jmax, R(0));
@@ -614,7 +614,7 @@ template <typename R, typename P> MGX_HD void joint_apply_impulse(Env<R, P> &e, 
     case J_MOTOR: {
         R wa = E_R(w, a), wb = E_R(w, b);
         R wr = wb - wa + E_R(jrate, j);
-        R jmax = p[9];
+        R jmax = E_R(jlim, j);
         R jj = -wr * p[0];
         R jold = E_R(ja0, j);
         R jn = r_clamp(jold + jj, -jmax, jmax);
@@ -870,7 +870,7 @@ template <typename R, typename P> MGX_HD void solve_begin(Env<R, P> &e, SolveCtx
             const int kind = RI_KIND(j), jj = j0 + j;
             const R *p = &T_R(joint_p, jj * JOINT_PARAMS);
             R *f = c.f[j];
-            c.lim[j] = p[9];
+            c.lim[j] = E_R(jlim, jj);
             if (kind == J_PIVOT || kind == J_PIN) {
                 f[0] = E_R(jr1x, jj); f[1] = E_R(jr1y, jj); f[2] = E_R(jr2x, jj); f[3] = E_R(jr2y, jj);
                 if (kind == J_PIVOT) {
@@ -903,7 +903,7 @@ template <typename R, typename P> MGX_HD void solve_begin(Env<R, P> &e, SolveCtx
             c.bk[0] = E_R(jk0, jp); c.bk[1] = E_R(jk1, jp); c.bk[2] = E_R(jk2, jp); c.bk[3] = E_R(jk3, jp);
             c.bbias[0] = E_R(jb0, jp); c.bbias[1] = E_R(jb1, jp); c.bbias[2] = E_R(jb0, jg);
             c.bacc[0] = E_R(ja0, jp); c.bacc[1] = E_R(ja1, jp); c.bacc[2] = E_R(ja0, jg);
-            c.blim[0] = T_R(joint_p, jp * JOINT_PARAMS + 9); c.blim[1] = T_R(joint_p, jg * JOINT_PARAMS + 9);
+            c.blim[0] = E_R(jlim, jp); c.blim[1] = E_R(jlim, jg);
             c.bgear = T_R(joint_p, jg * JOINT_PARAMS);
         }
     }
@@ -1009,7 +1009,9 @@ template <typename R, typename P> MGX_HD void ph_cache_commit(Env<R, P> &e, int 
 // int blob       rows: 0 episode steps, 1 n_cache, 2 overflow count, 3.. cache headers
 // All blobs are [rows][N] (env index fastest) so lane<->env loads coalesce.
 MGX_HD int state_rows_p(const TmplHeader &h) { return h.n_state_p; }
-MGX_HD int state_rows_f(const TmplHeader &h) { return (h.n_state - h.n_state_p) + h.n_jacc + 4 * h.cache_slots; }
+// velocities | joint accumulators | contact cache impulses | the env's five force limits (max impulse per substep)
+MGX_HD int state_rows_f(const TmplHeader &h) { return (h.n_state - h.n_state_p) + h.n_jacc + 4 * h.cache_slots + N_PHYS_VARS; }
+MGX_HD int state_row_physvar(const TmplHeader &h, int k) { return (h.n_state - h.n_state_p) + h.n_jacc + 4 * h.cache_slots + k; }
 MGX_HD int state_rows_i(const TmplHeader &h) { return 3 + h.cache_slots; }
 
 template <typename R, typename P>
@@ -1042,7 +1044,9 @@ MGX_HD void ph_load_state(Env<R, P> &e, const P *sp, const R *sf, const int32_t 
         }
     }
     for (int j = lane; j < h.n_joints; j += nl) {
-        int kind = T_I(joint_kind, j), off = nvel + T_I(joint_acc, j);
+        int kind = T_I(joint_kind, j), off = nvel + T_I(joint_acc, j), pv = T_I(joint_pv, j);
+        // max impulse per substep: this env's PhysicsVariables (rand_dynamics) or the template's constant
+        E_R(jlim, j) = pv >= 0 ? sf[(long)state_row_physvar(h, pv) * stride + env] : T_R(joint_p, j * JOINT_PARAMS + 9);
         if (kind == J_SPRING) continue;
         E_R(ja0, j) = sf[(long)off * stride + env];
         if (kind == J_PIVOT) E_R(ja1, j) = sf[(long)(off + 1) * stride + env];
@@ -1098,7 +1102,7 @@ MGX_HD void ph_store_state(Env<R, P> &e, P *sp, R *sf, int32_t *si, long stride,
 // Bodies with a parent (finger roots) are placed with the SAME rounding sequence the pin-joint
 // preStep uses, so the zero-length PinJoint starts with delta == 0 exactly, as in the reference.
 template <typename R, typename P>
-MGX_HD void reset_env_state(const TmplHeader &h, const int32_t *ti, const P *tp, P *sp, R *sf, int32_t *si, long stride, long env) {
+MGX_HD void reset_env_state(const TmplHeader &h, const int32_t *ti, const R *tr, const P *tp, P *sp, R *sf, int32_t *si, long stride, long env) {
     TmplOff to(h);
     for (int k = 0; k < h.n_state; k++) {
         int m = ti[to.state_map + k], comp = m & 15, b = (m >> 4) & 0xFF, row = m >> 12;
@@ -1117,6 +1121,7 @@ MGX_HD void reset_env_state(const TmplHeader &h, const int32_t *ti, const P *tp,
     }
     int nvel = h.n_state - h.n_state_p;
     for (int k = 0; k < h.n_jacc + 4 * h.cache_slots; k++) sf[(long)(nvel + k) * stride + env] = R(0);
+    for (int k = 0; k < N_PHYS_VARS; k++) sf[(long)state_row_physvar(h, k) * stride + env] = tr[to.consts + C_PV0 + k];
     for (int k = 0; k < 3 + h.cache_slots; k++) si[(long)k * stride + env] = 0;
 }
 

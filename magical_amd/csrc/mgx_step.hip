@@ -104,11 +104,12 @@ __global__ __launch_bounds__(64) void k_reset(TmplDev t, P *__restrict__ sp, R *
     __syncthreads();
     const TmplHeader *h = reinterpret_cast<const TmplHeader *>(lds);
     const int32_t *ti = reinterpret_cast<const int32_t *>(lds + t.off_i);
+    const R *tr = reinterpret_cast<const R *>(lds + t.off_r);
     const P *tp = reinterpret_cast<const P *>(lds + t.off_p);
     long env = (long)blockIdx.x * 64 + threadIdx.x;
     if (env >= n_envs) return;
     if (mask && !mask[env]) return;
-    reset_env_state<R, P>(*h, ti, tp, sp, sf, si, (long)n_envs, env);
+    reset_env_state<R, P>(*h, ti, tr, tp, sp, sf, si, (long)n_envs, env);
 }
 
 }  // namespace mgx

@@ -32,6 +32,7 @@ constexpr int CAP_PAIRS = 448;
 constexpr int CAP_PRIMS = 64;    // rasteriser keeps per-tile primitive sets in one 64-bit ballot mask
 constexpr int CAP_PVERTS = 320;
 
+constexpr int N_PHYS_VARS = 5;    // robot_pos, robot_rot, finger, shape_trans, shape_rot joint max forces (phys_vars.py)
 constexpr int JOINT_PARAMS = 10;   // ax ay bx by p0 p1 p2 bias_rate max_bias max_impulse
 constexpr int PRIM_IWORDS = 6;     // kind, nverts, voff, xform|body<<8|eye_body<<16, rgb(packed), stipple
 constexpr int PRIM_RWORDS = 6;     // eye_base(2) eye_pre(2) line_halfwidth radius
@@ -48,14 +49,16 @@ struct TmplHeader {
 
 // indices into the consts block
 enum ConstIdx {
-    C_DT = 0, C_CONTACT_BIAS_RATE, C_SLOP, C_SPEED_FWD, C_SPEED_BACK, C_TURN, C_FINGER_OPEN, C_FINGER_CLOSED, C_N
+    C_DT = 0, C_CONTACT_BIAS_RATE, C_SLOP, C_SPEED_FWD, C_SPEED_BACK, C_TURN, C_FINGER_OPEN, C_FINGER_CLOSED,
+    C_PV0,                       // default max impulse (max_force x dt) of the five PhysicsVariables, base_env.py:49-57
+    C_N = C_PV0 + 5
 };
 
 // offsets into the template's int / real arrays
 struct TmplOff {
     // ints
     int body_type, body_parent, shape_kind, shape_body, shape_voff, shape_nv;
-    int joint_kind, joint_a, joint_b, joint_acc, pair, state_map, prim_i, body_prow, island_j, n_i;
+    int joint_kind, joint_a, joint_b, joint_acc, joint_pv, pair, state_map, prim_i, body_prow, island_j, n_i;
     // reals
     int body_minv, body_iinv, body_init, body_anchor, shape_r, shape_u, lvx, lvy, lnx, lny;
     int joint_p, prim_r, pvx, pvy, consts, n_r;
@@ -73,6 +76,7 @@ struct TmplOff {
         joint_a = o; o += h.n_joints;
         joint_b = o; o += h.n_joints;
         joint_acc = o; o += h.n_joints;
+        joint_pv = o; o += h.n_joints;        // which PhysicsVariable limits this joint's impulse (-1: the template's own value)
         pair = o; o += h.n_pairs;
         state_map = o; o += h.n_state;
         prim_i = o; o += h.n_prims * PRIM_IWORDS;
@@ -116,7 +120,7 @@ struct WorkOff {
     // world-space shape data
     int wx, wy, wnx, wny, bbl, bbb, bbr, bbt;
     // joints: anchors, effective mass (k00..k11 | n.x n.y imass -), bias(2), accumulators(2), motor rate / spring target
-    int jr1x, jr1y, jr2x, jr2y, jk0, jk1, jk2, jk3, jb0, jb1, ja0, ja1, jrate;
+    int jr1x, jr1y, jr2x, jr2y, jk0, jk1, jk2, jk3, jb0, jb1, ja0, ja1, jrate, jlim;
     // contact points
     int knx, kny, kr1x, kr1y, kr2x, kr2y, knm, ktm, kbias, kjb, kjn, kjt, kmu;
     // manifold scratch per overlapping pair: n(2) + 2 x (p1, p2)(4)
@@ -140,7 +144,7 @@ struct WorkOff {
         bbl = o; o += ns; bbb = o; o += ns; bbr = o; o += ns; bbt = o; o += ns;
         jr1x = o; o += nj; jr1y = o; o += nj; jr2x = o; o += nj; jr2y = o; o += nj;
         jk0 = o; o += nj; jk1 = o; o += nj; jk2 = o; o += nj; jk3 = o; o += nj;
-        jb0 = o; o += nj; jb1 = o; o += nj; ja0 = o; o += nj; ja1 = o; o += nj; jrate = o; o += nj;
+        jb0 = o; o += nj; jb1 = o; o += nj; ja0 = o; o += nj; ja1 = o; o += nj; jrate = o; o += nj; jlim = o; o += nj;
         knx = o; o += nk; kny = o; o += nk; kr1x = o; o += nk; kr1y = o; o += nk; kr2x = o; o += nk; kr2y = o; o += nk;
         knm = o; o += nk; ktm = o; o += nk; kbias = o; o += nk; kjb = o; o += nk; kjn = o; o += nk; kjt = o; o += nk;
         kmu = o; o += nk;

@@ -142,10 +142,10 @@ int World::finalize(int max_steps, std::string &err) {
             bodies.push_back({BODY_KINEMATIC, 0, 0, e.x, e.y, e.angle, -1, 0, 0, 0});
             robot_j0 = (int)joints.size();
             JointDef pj = joint(J_PIVOT, control_body, body);              // :255-258
-            pj.max_bias = 0; pj.max_force = pv[0];
+            pj.max_bias = 0; pj.max_force = pv[0]; pj.pv = 0;
             joints.push_back(pj);
             JointDef gj = joint(J_GEAR, control_body, body);               // :259-263
-            gj.p0 = 0.0; gj.p1 = 1.0; gj.error_bias = 0.0; gj.max_bias = 2.5; gj.max_force = pv[1];
+            gj.p0 = 0.0; gj.p1 = 1.0; gj.error_bias = 0.0; gj.max_bias = 2.5; gj.max_force = pv[1]; gj.pv = 1;
             joints.push_back(gj);
             int eye_bodies[2];
             for (int k = 0; k < 2; k++) {                                  // :267-277
@@ -188,7 +188,7 @@ int World::finalize(int max_steps, std::string &err) {
                 lim.p0 = lo; lim.p1 = hi; lim.error_bias = 0.0;
                 joints.push_back(lim);
                 JointDef mot = joint(J_MOTOR, body, fb);                   // :349-354
-                mot.max_bias = 0.0; mot.max_force = pv[2];
+                mot.max_bias = 0.0; mot.max_force = pv[2]; mot.pv = 2;
                 motor_joint[k] = (int)joints.size();
                 joints.push_back(mot);
             }
@@ -284,10 +284,10 @@ int World::finalize(int max_steps, std::string &err) {
             }
             island_j.push_back((int)joints.size());
             JointDef tj = joint(J_PIVOT, 0, body);                         // :703-707
-            tj.max_bias = 0; tj.max_force = pv[3];
+            tj.max_bias = 0; tj.max_force = pv[3]; tj.pv = 3;
             joints.push_back(tj);
             JointDef rj = joint(J_GEAR, 0, body);                          // :708-711
-            rj.p0 = 0.0; rj.p1 = 1.0; rj.max_bias = 0; rj.max_force = pv[4];
+            rj.p0 = 0.0; rj.p1 = 1.0; rj.max_bias = 0; rj.max_force = pv[4]; rj.pv = 4;
             joints.push_back(rj);
             if (circle) {
                 PrimDef o = prim(PR_NGON, dark, XF_BODY, body); o.ngon = 100; o.radius = size; prims.push_back(o);
@@ -429,6 +429,7 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
         const JointDef &J = joints[j];
         iw[o.joint_kind + j] = J.kind; iw[o.joint_a + j] = J.a; iw[o.joint_b + j] = J.b;
         iw[o.joint_acc + j] = joint_acc_off[j];
+        iw[o.joint_pv + j] = J.pv;
         double *p = &rw[o.joint_p + j * JOINT_PARAMS];
         double ia = bodies[J.a].i_inv, ib = bodies[J.b].i_inv;
         p[0] = J.ax; p[1] = J.ay; p[2] = J.bx; p[3] = J.by; p[4] = J.p0; p[5] = J.p1; p[6] = J.p2;
@@ -480,6 +481,7 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
     c[C_CONTACT_BIAS_RATE] = (1.0 - std::pow(std::pow(1.0 - 0.1, 60.0), dt)) / dt;   // collision_bias default
     c[C_SLOP] = COLLISION_SLOP;
     c[C_SPEED_FWD] = 4.0 * ROBOT_RAD; c[C_SPEED_BACK] = 3.0 * ROBOT_RAD; c[C_TURN] = 1.5;   // entities.py:439-451
+    for (int k = 0; k < N_PHYS_VARS; k++) c[C_PV0 + k] = phys_vars[k] * dt;                    // = p[9] of the joints they limit
     c[C_FINGER_OPEN] = PI / 8; c[C_FINGER_CLOSED] = 0.0;                                       // :227-228,452-457
 }
 

@@ -33,6 +33,7 @@ struct JointDef {
     int kind, a, b;
     double ax, ay, bx, by, p0, p1, p2;
     double error_bias, max_bias, max_force;
+    int pv = -1;            // index of the PhysicsVariable that is this joint's max_force (-1: constant)
 };
 struct PrimDef {
     int kind, xform, body, eye_body;

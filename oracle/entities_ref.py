@@ -59,12 +59,23 @@ def make_finger_vertices(upper_arm_len, forearm_len, thickness, side_sign):
 
 
 class PhysVars:
-    """base_env.py:49-57 defaults."""
+    """base_env.py:49-57: defaults, and the uniform ranges `rand_dynamics` samples from (phys_vars.py:84-108)."""
     robot_pos_joint_max_force = 3
     robot_rot_joint_max_force = 1
     robot_finger_max_force = 4
     shape_trans_joint_max_force = 1.5
     shape_rot_joint_max_force = 0.1
+    BOUNDS = (('robot_pos_joint_max_force', (2.2, 3.5)), ('robot_rot_joint_max_force', (0.7, 1.5)),
+              ('robot_finger_max_force', (2.5, 4.5)), ('shape_trans_joint_max_force', (1.0, 1.8)),
+              ('shape_rot_joint_max_force', (0.07, 0.15)))
+
+    @classmethod
+    def sample(cls, rng):
+        """PhysicsVariables.sample: one rng.uniform(lower, upper) per variable, in declaration order."""
+        pv = cls()
+        for name, (lo, hi) in cls.BOUNDS:
+            setattr(pv, name, rng.uniform(lo, hi))
+        return pv
 
 
 class RefWorld:

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import lib
-from .entities_ref import ArenaBoundaries, RefWorld
+from .entities_ref import PhysVars, ArenaBoundaries, RefWorld
 from .tasks_ref import TASKS
 
 DEFAULT_RES = 384      # benchmarks/__init__.py:23
@@ -19,17 +19,21 @@ PHYS_ITER = 10
 
 
 class RefEnv:
-    def __init__(self, task, max_episode_steps=None, gjk_warm=True):
+    def __init__(self, task, max_episode_steps=None, gjk_warm=True, rand_dynamics=False, seed=None):
         self.task_cls = TASKS[task]
         self.max_episode_steps = max_episode_steps or self.task_cls.ep_len
         self.L = lib()
         self.world = None
         self.task = None
         self.gjk_warm = gjk_warm
+        self.rand_dynamics = rand_dynamics
+        self.rng = np.random.RandomState(seed=seed)       # base_env.py:133-140
 
     # base_env.py:177-234
     def reset(self):
-        self.world = RefWorld(phys_iter=PHYS_ITER)
+        # base_env.py:198-203: the physics variables are drawn before anything else touches the rng
+        pv = PhysVars.sample(self.rng) if self.rand_dynamics else None
+        self.world = RefWorld(phys_vars=pv, phys_iter=PHYS_ITER)
         self.L.ref_set_gjk_warm(self.world.h, 1 if self.gjk_warm else 0)
         self.arena = self.world.add(ArenaBoundaries())
         self.task = self.task_cls(self.world)

@@ -42,7 +42,7 @@ template <typename R, typename P> struct Emu : EmuBase {
     Env<R, P> env() { return Env<R, P>(&h, ti.data(), tr.data(), tp.data(), wr.data(), wp.data(), wi.data()); }
     void reset(void *sp, void *sf, int32_t *si, const uint8_t *mask) override {
         for (int e = 0; e < n_envs; e++)
-            if (!mask || mask[e]) reset_env_state<R, P>(h, ti.data(), tp.data(), (P *)sp, (R *)sf, si, n_envs, e);
+            if (!mask || mask[e]) reset_env_state<R, P>(h, ti.data(), tr.data(), tp.data(), (P *)sp, (R *)sf, si, n_envs, e);
     }
     void run(void *sp_, void *sf_, int32_t *si, const int32_t *actions, int n_sub, int nl, bool count_step, uint8_t *done) override {
         P *sp = (P *)sp_; R *sf = (R *)sf_;

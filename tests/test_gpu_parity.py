@@ -29,6 +29,10 @@ def test_native_library_is_loaded():
     assert L.mgx_version() == 1
     env = _make('MoveToCorner-Demo-v0', 64)
     assert env.lanes_per_env in (4, 8, 16, 32, 64)
+    assert env.action_space.n == 18 and env.num_envs == 64 and env.observation_space.shape == (env.n_bodies, 3)
+    env.close()
+    env = _make('MoveToCorner-Demo-LoResStack-v0', 2)
+    assert env.observation_space['ego'].shape == (96, 96, 12) and env.observation_space['allo'].dtype == np.uint8
     env.close()
 
 
@@ -233,6 +237,52 @@ def test_other_preprocessors_match_oracle(preproc):
             else:
                 assert same(obs, o, k), (preproc, s, k)
     env.close()
+
+
+@pytest.mark.parametrize('task', ['MoveToCorner', 'ClusterShape'])
+def test_rand_dynamics_matches_oracle(task):
+    """*-TestDynamics-v0 (base_env.py:198-203): every env draws its own PhysicsVariables from its own RandomState at
+    each reset (env k seeded with seed + k); the fp64 engine with those per-env force limits tracks an oracle env built
+    with the same draws, across an auto-reset, and differs from the default dynamics."""
+    from oracle.env_ref import RefEnv
+    n, ep, seed = 3, 4, 1234
+    env = _make(f'{task}-TestDynamics-v0', n, dtype='f64', max_episode_steps=ep)
+    assert env.rand_dynamics
+    env.seed(seed)
+    env.reset()
+    refs = [RefEnv(task, max_episode_steps=ep, rand_dynamics=True, seed=seed + k) for k in range(n)]
+    for r in refs:
+        r.reset()
+    want = np.array([[getattr(r.world.phys_vars, nm) for nm, _ in type(r.world.phys_vars).BOUNDS] for r in refs])
+    assert np.array_equal(env.phys_vars, want)                     # same draws, bit for bit
+    assert len(np.unique(want[:, 0])) == n
+    tape = _tape(31, 2 * ep, n)
+    idx = ref_body_index(refs[0])
+    mask = comparable_mask(refs[0])
+    for s in range(2 * ep):
+        _, _, done, _ = env.step(tape[s])
+        for k, r in enumerate(refs):
+            _, d, _ = r.step(tape[s, k])
+            assert d == done[k]
+            if d:
+                r.reset()
+        if done.all():
+            want = np.array([[getattr(r.world.phys_vars, nm) for nm, _ in type(r.world.phys_vars).BOUNDS] for r in refs])
+            assert np.array_equal(env.phys_vars, want)             # second draw of each env's stream
+            continue
+        got = env.get_bodies()
+        for k, r in enumerate(refs):
+            err = np.abs(got[k, 1:, :3] - r.bodies()[idx][:, :3])[mask[:, :3]].max()
+            assert err < (1e-8 if s % ep == 0 else 5e-3), (task, s, k, err)
+    # the limits matter: default dynamics give different poses after one step
+    dflt = _make(f'{task}-Demo-v0', n, dtype='f64', max_episode_steps=ep)
+    dflt.reset()
+    env.seed(seed); env.reset()
+    a = np.full(n, 4, dtype=np.int32)        # UpLeftOpen
+    for _ in range(3):
+        env.step(a); dflt.step(a)
+    assert np.abs(env.get_bodies()[:, 1:, :3] - dflt.get_bodies()[:, 1:, :3]).max() > 1e-4
+    env.close(); dflt.close()
 
 
 def test_lores4e_stack_and_autoreset():

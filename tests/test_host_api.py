@@ -122,3 +122,17 @@ def test_palette_table_matches_colorsys():
     assert table('BASE') == [to_u8(COLOURS_RGB[c]) for c in order]
     assert table('DARK') == [to_u8(darken_rgb(COLOURS_RGB[c])) for c in order]
     assert table('LIGHT2') == [to_u8(lighten_rgb(COLOURS_RGB[c], 2)) for c in order]
+
+
+def test_spaces_standins():
+    """The gym.spaces stand-ins carry what the reference's users read from them (base_env.py:97-109)."""
+    from magical_amd import spaces
+    a = spaces.Discrete(18)
+    assert a.n == 18 and a.contains(17) and not a.contains(18) and 0 <= a.sample(np.random.RandomState(0)) < 18
+    b = spaces.Box(0, 255, (96, 96, 12), 'uint8')
+    assert b.shape == (96, 96, 12) and b.dtype == np.uint8 and b.low.min() == 0 and b.high.max() == 255
+    assert b.contains(np.zeros((96, 96, 12), dtype=np.uint8)) and not b.contains(np.zeros((96, 96, 3), dtype=np.uint8))
+    d = spaces.Dict([('allo', b), ('ego', b)])
+    assert list(d.spaces) == ['allo', 'ego'] and d['ego'] == b
+    assert d.contains(d.sample(np.random.RandomState(1)))
+    assert spaces.to_gym(a) is a or type(spaces.to_gym(a)).__name__ == 'Discrete'
