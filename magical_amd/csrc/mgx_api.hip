@@ -2,6 +2,7 @@
 // kernel launches.  Device state blobs and output tensors are owned by the caller (PyTorch);
 // the engine owns only its small constant template buffers and timing events.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cstdio>
 #include <cstring>
@@ -38,6 +39,7 @@ struct mgx_engine {
     uint32_t *d_step = nullptr, *d_raster = nullptr;
     TmplDev tdev{};
     RasterDev rdev{};
+    int raster_waves = 4;       // k_raster variant: workgroups per CU its register cap is set for (3, 4 or 5)
     size_t lds_step = 0, lds_raster = 0;
     int timing = 0;             // 0 = off, n = bracket every n-th launch of each kind with HIP events
     int launch_count[2] = {0, 0};
@@ -312,6 +314,9 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
         int extra = N_TILES * 3 + QCAP * 4 + 4 + OVF_WORDS + ECAP * 2 + ECAP / 2;
         e->rdev.qcap = QCAP; e->rdev.ecap = ECAP;
         e->lds_raster = (size_t)(total + off_tiles + extra) * 4;
+        // as many workgroups per CU as LDS allows (512 B allocation slack), between 3 and 5
+        int fit = (int)((size_t)MAX_LDS_BYTES / (e->lds_raster + 512));
+        e->raster_waves = fit >= 5 ? 5 : (fit == 4 ? 4 : 3);
     }
     *out = e;
     return MGX_OK;
@@ -375,8 +380,13 @@ static int launch_raster(mgx_engine *e, const void *sp, uint8_t *out, int64_t en
         hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, fill, e->n_envs);
         return MGX_OK;
     };
-    int rc = layout == MGX_OBS_FRAME ? go(k_raster<P, 0>) : layout == MGX_OBS_STACK4 ? go(k_raster<P, 1>)
-           : layout == MGX_OBS_STACK3_HI ? go(k_raster<P, 2>) : go(k_raster<P, 3>);
+    auto by_layout = [&](auto waves) -> int {
+        constexpr int W = decltype(waves)::value;
+        return layout == MGX_OBS_FRAME ? go(k_raster<P, 0, W>) : layout == MGX_OBS_STACK4 ? go(k_raster<P, 1, W>)
+             : layout == MGX_OBS_STACK3_HI ? go(k_raster<P, 2, W>) : go(k_raster<P, 3, W>);
+    };
+    int rc = e->raster_waves >= 5 ? by_layout(std::integral_constant<int, 5>{})
+           : e->raster_waves == 4 ? by_layout(std::integral_constant<int, 4>{}) : by_layout(std::integral_constant<int, 3>{});
     if (rc) return rc;
     HIP_OK(hipGetLastError());
     return MGX_OK;

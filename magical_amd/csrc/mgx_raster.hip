@@ -33,8 +33,10 @@ constexpr int N_TILES = TILES_X * TILES_Y;
 constexpr int QCAP = 1024;     // LDS queue of undecided pixels per env; what does not fit waits in a bitmap for another round
 constexpr int OVF_WORDS = LORES * LORES / 32;
 constexpr int ECAP = 256;      // phase E records per round (uncertain pixels beyond that wait in the bitmap like queue overflow)
+// k_raster is instantiated for 3, 4 and 5 workgroups per CU (= waves per SIMD: VGPR caps 168 / 128 / 96); the host picks
+// the one the world's LDS footprint allows, so that LDS-bound worlds are not squeezed into fewer registers for nothing
 #ifndef MGX_RASTER_WAVES
-#define MGX_RASTER_WAVES 4      // workgroups per CU the register allocation is capped for (= waves per SIMD)
+#define MGX_RASTER_WAVES 4      // k_raster_native only
 #endif
 #ifndef MGX_STACK_GROUP
 #define MGX_STACK_GROUP 4      // tiles whose old pixels are fetched ahead, per wavefront (STACK4 layout)
@@ -157,8 +159,8 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
     }
 }
 
-template <typename P, int LAYOUT>
-__global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
+template <typename P, int LAYOUT, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
                                                 long env_stride, int view, const uint8_t *__restrict__ fill_mask, int n_envs) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
