@@ -130,6 +130,24 @@ def test_determinism_and_lockstep():
     assert torch.equal(sp, sp[:, :1].expand_as(sp))
 
 
+@pytest.mark.parametrize('n', [1, 5, 67, 2049])
+def test_ragged_batch_sizes(n):
+    """Batch sizes that do not fill a wavefront / a multiple of 8 workgroups: every env equals env k of a big batch
+    driven by the same per-env tape (states and LoRes4E observations, byte for byte)."""
+    import torch
+    t, big = 6, 4096
+    tape = _tape(41, t, big)
+    ref = _make('MoveToRegion-Demo-LoRes4E-v0', big)
+    env = _make('MoveToRegion-Demo-LoRes4E-v0', n)
+    ref.reset(); env.reset()
+    for s in range(t):
+        o_ref, _, _, _ = ref.step(tape[s])
+        o, _, _, _ = env.step(tape[s, :n])
+    assert torch.equal(o, o_ref[:n])
+    assert torch.equal(env.state_p, ref.state_p[:, :n]) and torch.equal(env.state_f, ref.state_f[:, :n])
+    ref.close(); env.close()
+
+
 @pytest.mark.parametrize('task', TASKS)
 def test_render_matches_oracle_bit_exact(task):
     """96x96 ego frames (and the 384x384 native views) of the HIP rasteriser equal the oracle's on the same poses."""

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""one rollout of every Demo task, `--envs` envs per task sharded over the GPUs of the job,
+per-env scores gathered on every rank (RCCL all_gather over xGMI; observations never leave their GPU).
+
+    python tools/rollout_all_tasks.py --envs 8192 [--preproc LoRes4E]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
+        tools/rollout_all_tasks.py --envs 8192
+
+Prints one JSON line per task on rank 0: env-steps/s of the whole job, mean score, episode length.
+"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+TASKS = ['MoveToCorner', 'MoveToRegion', 'MatchRegions', 'MakeLine', 'FindDupe', 'FixColour', 'ClusterColour', 'ClusterShape']
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--envs', type=int, default=8192, help='envs per task over the whole job')
+    ap.add_argument('--preproc', default='LoRes4E')
+    ap.add_argument('--seed', type=int, default=0)
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    import magical_amd
+    from magical_amd.distributed import env_shard, gather_rollout_results, init_from_env
+    rank, world, local_rank = init_from_env(backend='nccl')
+    torch.cuda.set_device(local_rank)
+    lo, hi = env_shard(args.envs, rank, world)
+    for task in TASKS:
+        name = f'{task}-Demo-{args.preproc}-v0' if args.preproc else f'{task}-Demo-v0'
+        env = magical_amd.make(name, n_envs=hi - lo, device=f'cuda:{local_rank}')
+        T = env.max_episode_steps
+        # the action tape of the whole job, every rank takes its slice (same results for any number of GPUs)
+        tape = np.random.RandomState(args.seed).randint(0, 18, size=(T, args.envs)).astype(np.int32)[:, lo:hi]
+        tape = torch.as_tensor(tape, device=env.device)
+        env.reset()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for s in range(T):
+            _, _, done, info = env.step(tape[s])
+        assert done.all()
+        scores = gather_rollout_results(torch.as_tensor(info['eval_score'], device=env.device), args.envs)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=env.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        if rank == 0:
+            print(json.dumps({'task': name, 'n_envs': args.envs, 'n_gpus': world, 'episode_steps': T,
+                              'env_steps_per_s': args.envs * T / dt, 'mean_score': float(scores.mean().item()),
+                              'frac_solved': float((scores > 0.5).double().mean().item())}))
+        env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
