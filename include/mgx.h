@@ -93,6 +93,12 @@ int mgx_world_goal_bb(const mgx_world *w, int ent, double bb[4]);
 /* shapes of entity `ent`: count; per shape kind (0 circle, 2 poly), radius, nverts and local verts xy[nverts*2] */
 int mgx_world_entity_shapes(const mgx_world *w, int ent, int max_shapes, int *kinds, double *radii, int *nverts, double *xy, int xy_stride);
 
+/* draw list: per primitive its template colour (r | g << 8 | b << 16), the entity whose colour paints it (-1: none) and
+ * how (0 darkened, 1 base, 2 lightened twice: entities.py:712-757,807-819); returns the number of primitives */
+int mgx_world_prim_table(const mgx_world *w, int *rgb, int *ent, int *role);
+/* style.py:28-37 evaluated to RGB8 for entity colour 0..3 (red green blue yellow) in `role` */
+int mgx_world_palette(int colour, int role);
+
 /* ---- engine: replaces BaseEnv.step()/render() for N envs ---------------------------------
  * Per-env persistent state lives in three caller-owned DEVICE blobs, all [rows][N] with the env
  * index fastest (coalesced lane<->env access):
@@ -123,6 +129,9 @@ int mgx_engine_substeps(mgx_engine *e, void *state_p, void *state_f, int32_t *st
  * (base_env.py:309-338, benchmarks/__init__.py:80-136,219-256).  out: DEVICE u8, layout per `layout`;
  * env_stride in bytes (multiple of 4).  fill_mask (DEVICE u8[N] or NULL): envs whose stack is (re)filled
  * with 4 copies of the new frame (FlattenFrameStack.reset). */
+/* Test*Colour variants: primitive colours per env, DEVICE int32 [n_prims][N] owned by the caller and read by every
+ * later render call (NULL = the world's own colours again) */
+int mgx_engine_set_prim_colours(mgx_engine *e, const int32_t *prim_rgb);
 int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t env_stride, int view, int layout,
                       const uint8_t *fill_mask, void *stream);
 /* native-resolution (384x384x3, no box filter) render of ONE env, for tests against the oracle/images */

@@ -167,6 +167,15 @@ class BaseEnv(abc.ABC):
         self._reward = torch.zeros(self.n_envs, dtype=torch.float32, device=self.device)
         self._steps = np.zeros(self.n_envs, dtype=np.int64)
         self.phys_vars = np.tile(np.asarray(PhysicsVariables.defaults(), dtype=np.float64), (self.n_envs, 1))   # per env
+        # draw list bookkeeping for per-env colours: template colour, painting entity and role of every primitive
+        n_prims = self._info('n_prims')
+        rgb0, pent, prole = ((C.c_int * n_prims)() for _ in range(3))
+        nat.check(L.mgx_world_prim_table(w, rgb0, pent, prole))
+        self._prim_rgb0, self._prim_ent, self._prim_role = (np.asarray(a[:], dtype=np.int64) for a in (rgb0, pent, prole))
+        self._palette = np.array([[nat.check(L.mgx_world_palette(c, r)) for c in range(4)] for r in range(3)], dtype=np.int64)
+        self._prim_rgb = None        # device int32[n_prims, N], allocated when an env first deviates from the template
+        self._default_colours = np.array([en.COLOUR_ID[e.colour_name] if hasattr(e, 'colour_name') else -1 for e in self._entities], dtype=np.int64)
+        self.entity_colours = np.tile(self._default_colours, (self.n_envs, 1))          # per env
         # pose-blob row of (x, y, angle) per body, -1 where the body is not persistent
         n = nat.check(L.mgx_world_n_state_entries(w))
         self._pose_rows = -np.ones((self.n_bodies, 3), dtype=np.int64)
@@ -196,8 +205,7 @@ class BaseEnv(abc.ABC):
         nat.check(self._lib.mgx_engine_reset(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
                                              self.state_i.data_ptr(), None, self._stream()))
         self._steps[:] = 0
-        if self.rand_dynamics:
-            self._sample_phys_vars(np.arange(self.n_envs))
+        self._randomise(np.arange(self.n_envs))
         if not self._warm:
             # the first pose read-back loads torch's gather / copy kernels (tens of ms, once per process); pay for it
             # here rather than in the middle of the first rollout
@@ -229,17 +237,50 @@ class BaseEnv(abc.ABC):
                 nat.check(self._lib.mgx_engine_reset(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
                                                      self.state_i.data_ptr(), self._done_dev.data_ptr(), self._stream()))
                 self._steps[idx] = 0
-                if self.rand_dynamics:
-                    self._sample_phys_vars(idx)
+                self._randomise(idx)
                 fill = self._done_dev
         obs = self._observe(fill_mask=fill)
         return obs, self._reward, done, {'eval_score': eval_score}
 
-    def _sample_phys_vars(self, env_idx):
-        """base_env.py:198-203: PhysicsVariables.sample(rng) for the envs being reset, five rng.uniform draws each in
-        declaration order (phys_vars.py:84-88), written into the envs' force-limit rows."""
-        vals = np.array([PhysicsVariables.sample(self.rngs[k]) for k in env_idx], dtype=np.float64)
-        self.set_phys_vars(vals, env_idx)
+    # ------------------------------------------------------------------ per-env variation (Test* variants)
+    def sample_variation(self, rng):
+        """Task hook: draw this episode's random choices from `rng` with the same calls, in the same order, as the
+        reference's on_reset() (after the physics variables, base_env.py:198-214).  Return None (Demo) or a dict;
+        supported key: 'colours' = {entity: colour name}."""
+        return None
+
+    def _randomise(self, env_idx):
+        """Per-env draws for the envs being reset, env k from its own stream self.rngs[k]."""
+        pvs, colour_rows = [], []
+        for k in env_idx:
+            rng = self.rngs[k]
+            if self.rand_dynamics:
+                pvs.append(PhysicsVariables.sample(rng))
+            var = self.sample_variation(rng)
+            if var is not None and 'colours' in var:
+                row = self._default_colours.copy()
+                for ent, name in var['colours'].items():
+                    row[self._entities.index(ent)] = en.COLOUR_ID[name]
+                colour_rows.append(row)
+        if pvs:
+            self.set_phys_vars(np.asarray(pvs, dtype=np.float64), env_idx)
+        if colour_rows:
+            self.set_entity_colours(np.asarray(colour_rows), env_idx)
+
+    def set_entity_colours(self, colour_ids, env_idx=None):
+        """colour_ids: int[M, n_entities] (entities.COLOUR_ID values; ignored for the robot) for the envs `env_idx`.
+        Recolours the envs' primitives (fill / darkened outline / lightened goal interior, entities.py:712-757,807-819)."""
+        import torch
+        idx = np.arange(self.n_envs) if env_idx is None else np.asarray(env_idx)
+        colour_ids = np.asarray(colour_ids, dtype=np.int64).reshape(len(idx), len(self._entities))
+        self.entity_colours[idx] = colour_ids
+        rgb = np.tile(self._prim_rgb0[:, None], (1, len(idx)))                       # [n_prims, M]
+        for k in np.nonzero(self._prim_role >= 0)[0]:
+            rgb[k] = self._palette[self._prim_role[k], colour_ids[:, self._prim_ent[k]]]
+        if self._prim_rgb is None:
+            self._prim_rgb = torch.as_tensor(np.tile(self._prim_rgb0[:, None], (1, self.n_envs)).astype(np.int32), device=self.device).contiguous()
+            nat.check(self._lib.mgx_engine_set_prim_colours(self._engine, self._prim_rgb.data_ptr()))
+        self._prim_rgb[:, torch.as_tensor(idx, device=self.device)] = torch.as_tensor(rgb.astype(np.int32), device=self.device)
 
     def set_phys_vars(self, values, env_idx=None):
         """values: float64[M, 5] joint max forces (robot_pos, robot_rot, robot_finger, shape_trans, shape_rot) of the

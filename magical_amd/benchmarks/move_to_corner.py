@@ -1,4 +1,4 @@
-"""MoveToCorner (mirror of magical/benchmarks/move_to_corner.py, Demo branch)."""
+"""MoveToCorner (mirror of magical/benchmarks/move_to_corner.py: Demo, TestColour and TestDynamics branches)."""
 import math
 
 import numpy as np
@@ -10,9 +10,15 @@ from ._scoring import row_norm
 
 class MoveToCornerEnv(BaseEnv):
     def __init__(self, rand_shape_colour=False, rand_shape_type=False, rand_poses=False, debug_reward=False, **kwargs):
-        if rand_shape_colour or rand_shape_type or rand_poses or debug_reward:
-            raise NotImplementedError('only the Demo and TestDynamics variants are built (the other Test* variants need per-env geometry: SURVEY.md §8f)')
+        if rand_shape_type or rand_poses or debug_reward:
+            raise NotImplementedError('built: Demo, TestColour, TestDynamics (shape types and poses need per-env geometry: SURVEY.md §8f)')
+        self.rand_shape_colour = rand_shape_colour
         super().__init__(**kwargs)
+
+    def sample_variation(self, rng):   # move_to_corner.py:42-44
+        if not self.rand_shape_colour:
+            return None
+        return {'colours': {self.__shape_ref: rng.choice(np.asarray(en.SHAPE_COLOURS, dtype='object'))}}
 
     def on_reset(self):   # move_to_corner.py:31-54
         robot = self._make_robot(np.asarray((0.4, -0.0)), 0.55 * math.pi)

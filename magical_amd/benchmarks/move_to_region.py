@@ -1,4 +1,4 @@
-"""MoveToRegion (mirror of magical/benchmarks/move_to_region.py, Demo branch)."""
+"""MoveToRegion (mirror of magical/benchmarks/move_to_region.py: Demo, TestColour and TestDynamics branches)."""
 import numpy as np
 
 from .. import entities as en
@@ -11,9 +11,15 @@ DEFAULT_GOAL_XYHW = (-0.62, -0.17, 0.76, 0.75)
 
 class MoveToRegionEnv(BaseEnv):
     def __init__(self, rand_poses_minor=False, rand_poses_full=False, rand_goal_colour=False, **kwargs):
-        if rand_poses_minor or rand_poses_full or rand_goal_colour:
-            raise NotImplementedError('only the Demo and TestDynamics variants are built (the other Test* variants need per-env geometry: SURVEY.md §8f)')
+        if rand_poses_minor or rand_poses_full:
+            raise NotImplementedError('built: Demo, TestColour, TestDynamics (goal size / poses need per-env geometry: SURVEY.md §8f)')
+        self.rand_goal_colour = rand_goal_colour
         super().__init__(**kwargs)
+
+    def sample_variation(self, rng):   # move_to_region.py:47-51
+        if not self.rand_goal_colour:
+            return None
+        return {'colours': {self.__goal_ref: rng.choice(np.asarray(en.SHAPE_COLOURS, dtype='object'))}}
 
     def on_reset(self):   # move_to_region.py:30-63
         goal = en.GoalRegion(*DEFAULT_GOAL_XYHW, DEFAULT_GOAL_COLOUR)

@@ -164,6 +164,21 @@ int mgx_world_goal_bb(const mgx_world *w, int ent, double bb[4]) {
     bb[0] = cx - hw; bb[1] = cy - hh; bb[2] = cx + hw; bb[3] = cy + hh;
     return MGX_OK;
 }
+int mgx_world_prim_table(const mgx_world *w, int *rgb, int *ent, int *role) {
+    if (!w || !w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
+    int n = (int)w->w.prims.size();
+    for (int k = 0; k < n; k++) {
+        const PrimDef &P = w->w.prims[k];
+        if (rgb) rgb[k] = P.rgb[0] | (P.rgb[1] << 8) | (P.rgb[2] << 16);
+        if (ent) ent[k] = P.ent;
+        if (role) role[k] = P.role;
+    }
+    return n;
+}
+int mgx_world_palette(int colour, int role) {
+    if (colour < 0 || colour > 3 || role < 0 || role > 2) return fail(MGX_ERR_ARG, "colour 0..3, role 0..2");
+    return palette_rgb(colour, role);
+}
 int mgx_world_entity_shapes(const mgx_world *w, int ent, int max_shapes, int *kinds, double *radii, int *nverts, double *xy, int xy_stride) {
     if (!w || !w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
     if (ent < 0 || ent >= (int)w->w.entities.size()) return fail(MGX_ERR_ARG, "entity index out of range");
@@ -427,6 +442,11 @@ int mgx_engine_debug_raster_stop(mgx_engine *e, int phase) { if (e) e->rdev.dbg_
 int mgx_engine_debug_raster_clocks(mgx_engine *e, void *buf) { if (e) e->rdev.dbg_clk = (unsigned long long *)buf; return MGX_OK; }
 int mgx_engine_debug_step_clocks(mgx_engine *e, void *buf) { if (e) e->tdev.dbg_clk = (unsigned long long *)buf; return MGX_OK; }
 int mgx_engine_debug_iterations(mgx_engine *e, int it) { if (e) e->dbg_iterations = it; return MGX_OK; }
+int mgx_engine_set_prim_colours(mgx_engine *e, const int32_t *prim_rgb) {
+    if (!e) return fail(MGX_ERR_ARG, "engine is NULL");
+    e->rdev.prim_rgb_env = prim_rgb;
+    return MGX_OK;
+}
 int mgx_engine_set_timing(mgx_engine *e, int enable) {
     if (!e) return fail(MGX_ERR_ARG, "engine is NULL");
     e->timing = enable < 0 ? 0 : enable;

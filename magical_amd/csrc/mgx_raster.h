@@ -28,7 +28,7 @@ struct RasterOff {
     int elen, earc;                     // line loops: segment length and arclength at the segment start
     int pcx, pcy, prad, papo, pphi;     // per prim (n-gon centre/radius/apothem/phase; line half width in prad)
     int n_d;
-    int bb;                             // per prim bbox in 384-grid units: x0 y0 x1 y1 (ints, inclusive, may be empty)
+    int prgb;                           // per prim colour of THIS env (the template's, or the env's own: TestColour variants)
     // fp32 classification items (8 words each) in FRONT-TO-BACK prim order + per-prim (start | count << 16)
     int items, pitem, n_items;
     int n_i;
@@ -40,7 +40,7 @@ struct RasterOff {
         pcx = o; o += h.n_prims; pcy = o; o += h.n_prims; prad = o; o += h.n_prims; papo = o; o += h.n_prims; pphi = o; o += h.n_prims;
         n_d = o;
         o = 0;
-        bb = o; o += 4 * h.n_prims;
+        prgb = o; o += h.n_prims;
         n_items = h.n_pverts + h.n_prims;          // upper bound: one per polygon edge / line segment / n-gon
         o = (o + 3) & ~3;                          // 16-byte aligned records
         items = o; o += 8 * n_items;
@@ -64,7 +64,8 @@ struct Raster {
     MGX_HD int prim_nv(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 1]; }
     MGX_HD int prim_voff(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 2]; }
     MGX_HD int prim_xf(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 3]; }
-    MGX_HD int prim_rgb(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 4]; }
+    MGX_HD int prim_rgb(int k) const { return i[ro.prgb + k]; }       // after raster_setup_prims
+    MGX_HD int prim_rgb_template(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 4]; }
     MGX_HD int prim_stipple(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 5]; }
     // tq layout: [n_prims * PRIM_RWORDS][pvx n_pverts][pvy n_pverts]
     MGX_HD double prim_r(int k, int j) const { return tq[k * PRIM_RWORDS + j]; }
@@ -119,11 +120,12 @@ MGX_HD void raster_camera(const Raster &rs, double *cam) {
 }
 
 // ---- setup phase 2: screen-space vertices (lane per vertex) and n-gon records (lane per prim)
-MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl) {
+MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_rgb = nullptr, long stride = 0, long env = 0) {
     const TmplHeader &h = *rs.h;
     double cam[6];
     raster_camera(rs, cam);
     for (int k = lane; k < h.n_prims; k += nl) {
+        RI(prgb, k) = env_rgb ? env_rgb[(long)k * stride + env] : rs.prim_rgb_template(k);
         int kind = rs.prim_kind(k), xfw = rs.prim_xf(k);
         int xf = xfw & 0xFF, body = (xfw >> 8) & 0xFF, eye_body = ((xfw >> 16) & 0xFF) - 1;
         int nv = rs.prim_nv(k), vo = rs.prim_voff(k);
@@ -151,24 +153,16 @@ MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl) {
             if (xf == XF_EYE) phi += da;
             if (rs.view == 0) phi -= RD(ba, rs.h->robot_body);
             RD(pphi, k) = phi;
-            int x0 = (int)rz_floor(RD(pcx, k) - rad - 0.5), x1 = (int)ceil(RD(pcx, k) + rad - 0.5);
-            int y0 = (int)rz_floor(RD(pcy, k) - rad - 0.5), y1 = (int)ceil(RD(pcy, k) + rad - 0.5);
-            RI(bb, 4 * k) = x0; RI(bb, 4 * k + 1) = y0; RI(bb, 4 * k + 2) = x1; RI(bb, 4 * k + 3) = y1;
             continue;
         }
-        double minx = 1e30, maxx = -1e30, miny = 1e30, maxy = -1e30;
         for (int i = 0; i < nv; i++) {
             double lx = rs.pvx(vo + i), ly = rs.pvy(vo + i);
             double wx = lx, wy = ly;
             if (xf != XF_WORLD) { wx = bx + (bc * lx - bs * ly); wy = by + (bc * ly + bs * lx); }
             double sx = cam[0] * wx + cam[1] * wy + cam[4], sy = cam[2] * wx + cam[3] * wy + cam[5];
             RD(svx, vo + i) = sx; RD(svy, vo + i) = sy;
-            minx = r_min(minx, sx); maxx = r_max(maxx, sx); miny = r_min(miny, sy); maxy = r_max(maxy, sy);
         }
-        double pad = 0.0;
-        if (kind == PR_LINELOOP) { RD(prad, k) = rs.prim_r(k, 4); pad = rs.prim_r(k, 4) + 1.0; }
-        RI(bb, 4 * k) = (int)rz_floor(minx - pad - 0.5); RI(bb, 4 * k + 1) = (int)rz_floor(miny - pad - 0.5);
-        RI(bb, 4 * k + 2) = (int)ceil(maxx + pad - 0.5); RI(bb, 4 * k + 3) = (int)ceil(maxy + pad - 0.5);
+        if (kind == PR_LINELOOP) RD(prad, k) = rs.prim_r(k, 4);
         {
             // normalised edge functions E(p) = sgn * cross(e, p - a) / |e|: >= 0 inside a polygon; for a line
             // loop |E| is the distance to the segment's carrier line and (eb, -ea) is its unit direction

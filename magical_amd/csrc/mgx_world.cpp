@@ -104,6 +104,11 @@ PrimDef prim(int kind, Rgb c, int xform, int body) {
 
 }  // namespace
 
+int palette_rgb(int colour, int role) {
+    const Rgb c = role == 0 ? DARK[colour] : (role == 1 ? BASE[colour] : LIGHT2[colour]);
+    return c.r | (c.g << 8) | (c.b << 16);
+}
+
 int World::finalize(int max_steps, std::string &err) {
     if (finalized) { err = "world already finalized"; return -3; }
     max_episode_steps = max_steps;
@@ -290,11 +295,11 @@ int World::finalize(int max_steps, std::string &err) {
             rj.p0 = 0.0; rj.p1 = 1.0; rj.max_bias = 0; rj.max_force = pv[4]; rj.pv = 4;
             joints.push_back(rj);
             if (circle) {
-                PrimDef o = prim(PR_NGON, dark, XF_BODY, body); o.ngon = 100; o.radius = size; prims.push_back(o);
-                PrimDef i = prim(PR_NGON, col, XF_BODY, body); i.ngon = 100; i.radius = size - SHAPE_LINE; prims.push_back(i);
+                PrimDef o = prim(PR_NGON, dark, XF_BODY, body); o.ngon = 100; o.radius = size; o.ent = (int)ei; o.role = 0; prims.push_back(o);
+                PrimDef i = prim(PR_NGON, col, XF_BODY, body); i.ngon = 100; i.radius = size - SHAPE_LINE; i.ent = (int)ei; i.role = 1; prims.push_back(i);
             } else {
-                for (auto &g : draw_outer) { PrimDef o = prim(PR_POLY, dark, XF_BODY, body); o.verts = g; prims.push_back(o); }
-                for (auto &g : draw_inner) { PrimDef i = prim(PR_POLY, col, XF_BODY, body); i.verts = g; prims.push_back(i); }
+                for (auto &g : draw_outer) { PrimDef o = prim(PR_POLY, dark, XF_BODY, body); o.verts = g; o.ent = (int)ei; o.role = 0; prims.push_back(o); }
+                for (auto &g : draw_inner) { PrimDef i = prim(PR_POLY, col, XF_BODY, body); i.verts = g; i.ent = (int)ei; i.role = 1; prims.push_back(i); }
             }
         } else {
             // ---------------- GoalRegion (entities.py:790-819): static sensor, drawn only
@@ -302,9 +307,9 @@ int World::finalize(int max_steps, std::string &err) {
             double cx = e.x + e.w / 2, cy = e.y - e.h / 2;
             std::vector<Vec2> rect = draw_rect(e.w, e.h);
             for (auto &v : rect) { v.x += cx; v.y += cy; }
-            PrimDef fill = prim(PR_POLY, LIGHT2[e.colour], XF_WORLD, 0); fill.verts = rect; prims.push_back(fill);
+            PrimDef fill = prim(PR_POLY, LIGHT2[e.colour], XF_WORLD, 0); fill.verts = rect; fill.ent = (int)ei; fill.role = 2; prims.push_back(fill);
             PrimDef outl = prim(PR_LINELOOP, BASE[e.colour], XF_WORLD, 0);
-            outl.verts = rect; outl.line_width = 2.5; outl.stipple = 0x00FF;
+            outl.verts = rect; outl.line_width = 2.5; outl.stipple = 0x00FF; outl.ent = (int)ei; outl.role = 1;
             prims.push_back(outl);
         }
     }

@@ -42,6 +42,7 @@ struct PrimDef {
     double eye_base[2], eye_pre[2];
     double line_width; int stipple;
     double radius; int ngon;
+    int ent = -1, role = -1;   // entity whose colour paints this prim and how (0 darkened, 1 base, 2 lightened x2; -1: fixed colour)
 };
 struct EntityDef {
     int kind;                // 0 robot, 1 shape, 2 goal
@@ -75,6 +76,9 @@ struct World {
     // serialise: header + int words + real words (as double; caller narrows to float if needed)
     void serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<double> &rw, std::vector<double> &pw) const;
 };
+
+// RGB8 (r | g << 8 | b << 16) of entity colour 0..3 in role 0 darkened / 1 base / 2 lightened twice (style.py:28-37)
+int palette_rgb(int colour, int role);
 
 // physics constants of the reference (base_env.py:62-64,194-196,236-239; benchmarks/__init__.py:401-404)
 constexpr double ROBOT_RAD = 0.2;

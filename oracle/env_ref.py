@@ -19,7 +19,7 @@ PHYS_ITER = 10
 
 
 class RefEnv:
-    def __init__(self, task, max_episode_steps=None, gjk_warm=True, rand_dynamics=False, seed=None):
+    def __init__(self, task, max_episode_steps=None, gjk_warm=True, rand_dynamics=False, seed=None, **task_flags):
         self.task_cls = TASKS[task]
         self.max_episode_steps = max_episode_steps or self.task_cls.ep_len
         self.L = lib()
@@ -27,6 +27,7 @@ class RefEnv:
         self.task = None
         self.gjk_warm = gjk_warm
         self.rand_dynamics = rand_dynamics
+        self.task_flags = task_flags                      # rand_* flags of the task constructor
         self.rng = np.random.RandomState(seed=seed)       # base_env.py:133-140
 
     # base_env.py:177-234
@@ -36,7 +37,7 @@ class RefEnv:
         self.world = RefWorld(phys_vars=pv, phys_iter=PHYS_ITER)
         self.L.ref_set_gjk_warm(self.world.h, 1 if self.gjk_warm else 0)
         self.arena = self.world.add(ArenaBoundaries())
-        self.task = self.task_cls(self.world)
+        self.task = self.task_cls(self.world, rng=self.rng, **self.task_flags)
         self._episode_steps = 0
         return None
 

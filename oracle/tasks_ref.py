@@ -1,7 +1,7 @@
-"""Demo-variant task layouts + score_on_end_of_traj restatements.
+"""Task layouts + score_on_end_of_traj restatements.
 
-TEST INFRASTRUCTURE.  One class per reference task file; only the Demo
-(all rand_* False) branches are restated.  Scores follow the reference's
+TEST INFRASTRUCTURE.  One class per reference task file; the Demo (all rand_* False) branches of every task, plus the
+colour-only randomisation branches of MoveToCorner / MoveToRegion (the *-TestColour-* variants).  Scores follow the reference's
 float64 numpy/Python operation order so they can be compared bit-for-bit with
 the product's host scoring.
 """
@@ -10,7 +10,7 @@ import math
 
 import numpy as np
 
-from .entities_ref import GoalRegion, Robot, Shape
+from .entities_ref import SHAPE_COLOURS, GoalRegion, Robot, Shape
 
 ROBOT_RAD = 0.2          # base_env.py:62
 ROBOT_MASS = 1.0         # base_env.py:63
@@ -30,8 +30,10 @@ class TaskRef:
     name = None
     ep_len = None
 
-    def __init__(self, world):
+    def __init__(self, world, rng=None, **flags):
         self.world = world
+        self.rng = rng                 # the env's np.random.RandomState (base_env.py:133-140)
+        self.flags = flags             # rand_* keyword arguments of the reference constructor that are True
         self.on_reset()
 
     def block_pos(self, ent):
@@ -53,7 +55,10 @@ class MoveToCornerRef(TaskRef):
     def on_reset(self):
         w = self.world
         self.robot = w.add(_robot((0.4, -0.0), 0.55 * math.pi))
-        self.shape = w.add(_shape('square', 'red', (0.1, -0.65), 0.13 * math.pi))
+        shape_colour = 'red'
+        if self.flags.get('rand_shape_colour'):          # move_to_corner.py:42-44
+            shape_colour = self.rng.choice(np.asarray(SHAPE_COLOURS, dtype='object'))
+        self.shape = w.add(_shape('square', shape_colour, (0.1, -0.65), 0.13 * math.pi))
 
     def score_on_end_of_traj(self):
         robot_pos = np.asarray(self.block_pos(self.shape))
@@ -71,7 +76,10 @@ class MoveToRegionRef(TaskRef):
 
     def on_reset(self):
         w = self.world
-        self.goal = w.add(GoalRegion(-0.62, -0.17, 0.76, 0.75, 'blue'))
+        goal_colour = 'blue'
+        if self.flags.get('rand_goal_colour'):            # move_to_region.py:47-51
+            goal_colour = self.rng.choice(np.asarray(SHAPE_COLOURS, dtype='object'))
+        self.goal = w.add(GoalRegion(-0.62, -0.17, 0.76, 0.75, goal_colour))
         self.robot = w.add(_robot((0.058, 0.53), -2.13))
 
     def score_on_end_of_traj(self):

@@ -303,6 +303,36 @@ def test_rand_dynamics_matches_oracle(task):
     env.close(); dflt.close()
 
 
+@pytest.mark.parametrize('task,flag', [('MoveToCorner', 'rand_shape_colour'), ('MoveToRegion', 'rand_goal_colour')])
+def test_test_colour_variants_match_oracle(task, flag):
+    """*-TestColour-v0: each env draws its colour from its own stream exactly as the reference's on_reset does
+    (move_to_corner.py:42-44, move_to_region.py:47-51); observations equal the oracle env built with the same draw,
+    byte for byte, across an auto-reset."""
+    from oracle.env_ref import LoRes4ERef, RefEnv
+    n, ep, seed = 6, 3, 77
+    env = _make(f'{task}-TestColour-LoRes4E-v0', n, dtype='f64', max_episode_steps=ep)
+    env.seed(seed)
+    obs = env.reset().cpu().numpy()
+    refs = [LoRes4ERef(RefEnv(task, max_episode_steps=ep, seed=seed + k, **{flag: True})) for k in range(n)]
+    first = [r.reset() for r in refs]
+    cols = set()
+    for k, r in enumerate(refs):
+        ent = r.env.task.shape if task == 'MoveToCorner' else r.env.task.goal
+        cols.add(str(ent.colour_name))
+        assert np.array_equal(obs[k], first[k]), (task, k)
+    assert len(cols) > 1                      # the draws differ between envs
+    tape = _tape(37, 2 * ep, n)
+    for s in range(2 * ep):
+        obs, _, done, _ = env.step(tape[s])
+        obs = obs.cpu().numpy()
+        for k, r in enumerate(refs):
+            o, _, d, _ = r.step(tape[s, k])
+            assert d == done[k]
+            want = r.reset() if d else o      # auto-reset: new draw, stack refilled
+            assert np.array_equal(obs[k], want), (task, s, k)
+    env.close()
+
+
 def test_lores4e_stack_and_autoreset():
     """FlattenFrameStack semantics on device: reset fills 4 copies, step shifts by one frame, auto-reset refills;
     compared with the oracle's LoRes4E pipeline for the first steps."""
