@@ -1,4 +1,4 @@
-"""MakeLine (mirror of magical/benchmarks/make_line.py, Demo branch)."""
+"""MakeLine (mirror of magical/benchmarks/make_line.py: Demo, TestColour and TestDynamics branches)."""
 import numpy as np
 
 from .. import entities as en
@@ -43,8 +43,9 @@ def longest_line(points, inlier_dist, max_separation):
 class MakeLineEnv(BaseEnv):
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
-        if rand_colours or rand_shapes or rand_count or rand_layout_minor or rand_layout_full:
-            raise NotImplementedError('only the Demo and TestDynamics variants are built (the other Test* variants need per-env geometry: SURVEY.md §8f)')
+        if rand_shapes or rand_count or rand_layout_minor or rand_layout_full:
+            raise NotImplementedError('built: Demo, TestColour, TestDynamics (shape types / counts / layouts need per-env geometry: SURVEY.md §8f)')
+        self.rand_colours = rand_colours
         super().__init__(**kwargs)
         self.inlier_dist = self.SHAPE_RAD * INLIER_RAD_MULT
         self.max_sep = self.SHAPE_RAD * MAX_SEP_RADS
@@ -55,6 +56,12 @@ class MakeLineEnv(BaseEnv):
                         for s, c, (p, a) in zip(DEFAULT_BLOCK_SHAPES, DEFAULT_BLOCK_COLOURS, DEFAULT_BLOCK_POSES)]
         self.add_entities(self._blocks)
         self.add_entities([robot])
+
+    def sample_variation(self, rng):   # make_line.py:105-107
+        if not self.rand_colours:
+            return None
+        block_colours = rng.choice(en.SHAPE_COLOUR_NAMES, size=len(self._blocks)).tolist()
+        return {'colours': dict(zip(self._blocks, block_colours))}
 
     def score_on_end_of_traj(self, poses):   # make_line.py:142-152
         bodies = [b.body for b in self._blocks]

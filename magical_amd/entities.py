@@ -60,6 +60,9 @@ SHAPE_COLOURS = (ShapeColour.RED, ShapeColour.GREEN, ShapeColour.BLUE, ShapeColo
 # native enum values (include/mgx.h)
 SHAPE_TYPE_ID = {t: i for i, t in enumerate(ShapeType)}
 COLOUR_ID = {c: i for i, c in enumerate(ShapeColour)}
+# plain-str view of SHAPE_COLOURS for rng.choice: numpy stringifies str-Enum members by their repr on this Python /
+# numpy pair, the reference's environment by their value; the draws (one randint per element) are the same either way
+SHAPE_COLOUR_NAMES = tuple(c.value for c in SHAPE_COLOURS)
 
 
 class Entity:

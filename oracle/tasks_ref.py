@@ -1,7 +1,7 @@
 """Task layouts + score_on_end_of_traj restatements.
 
 TEST INFRASTRUCTURE.  One class per reference task file; the Demo (all rand_* False) branches of every task, plus the
-colour-only randomisation branches of MoveToCorner / MoveToRegion (the *-TestColour-* variants).  Scores follow the reference's
+colour-only randomisation branches of MoveToCorner / MoveToRegion / MatchRegions / MakeLine (*-TestColour-*).  Scores follow the reference's
 float64 numpy/Python operation order so they can be compared bit-for-bit with
 the product's host scoring.
 """
@@ -99,13 +99,16 @@ class MatchRegionsRef(TaskRef):
     def on_reset(self):
         w = self.world
         robot = _robot((-0.5, 0.1), -math.pi * 1.2)
-        self.sensor = w.add(GoalRegion(0.1, 0.7, 0.7, 0.6, 'green'))
+        target_colour = 'green'
+        if self.flags.get('rand_target_colour'):          # match_regions.py:51-58
+            target_colour = self.rng.choice(SHAPE_COLOURS)
+        self.sensor = w.add(GoalRegion(0.1, 0.7, 0.7, 0.6, target_colour))
         target_types = ['star', 'square']
         target_poses = [(0.8, -0.7, 2.37), (-0.68, 0.72, 1.28)]
-        distractor_colours = ['red', 'blue', 'yellow']          # SHAPE_COLOURS minus green
+        distractor_colours = [c for c in SHAPE_COLOURS if c != target_colour]
         distractor_types = [[], ['pentagon'], ['circle', 'pentagon']]
         distractor_poses = [[], [(-0.05, -0.2, -1.09)], [(-0.75, -0.55, 2.78), (0.3, -0.82, -1.15)]]
-        self.target_shapes = [_shape(t, 'green', (x, y), a) for t, (x, y, a) in zip(target_types, target_poses)]
+        self.target_shapes = [_shape(t, target_colour, (x, y), a) for t, (x, y, a) in zip(target_types, target_poses)]
         self.distractor_shapes = []
         for col, types, poses in zip(distractor_colours, distractor_types, distractor_poses):
             for t, (x, y, a) in zip(types, poses):
@@ -162,6 +165,8 @@ class MakeLineRef(TaskRef):
         w = self.world
         robot = _robot((0.702, -0.255), 0.347)
         colours = ['blue', 'yellow', 'red', 'green']
+        if self.flags.get('rand_colours'):                # make_line.py:105-107
+            colours = self.rng.choice(SHAPE_COLOURS, size=4).tolist()
         shapes = ['star', 'circle', 'star', 'pentagon']
         poses = [((0.790, -0.820), -0.721), ((-0.177, 0.383), -1.733),
                  ((-0.051, -0.128), 2.696), ((-0.292, -0.745), -0.159)]

@@ -303,10 +303,11 @@ def test_rand_dynamics_matches_oracle(task):
     env.close(); dflt.close()
 
 
-@pytest.mark.parametrize('task,flag', [('MoveToCorner', 'rand_shape_colour'), ('MoveToRegion', 'rand_goal_colour')])
+@pytest.mark.parametrize('task,flag', [('MoveToCorner', 'rand_shape_colour'), ('MoveToRegion', 'rand_goal_colour'),
+                                       ('MatchRegions', 'rand_target_colour'), ('MakeLine', 'rand_colours')])
 def test_test_colour_variants_match_oracle(task, flag):
     """*-TestColour-v0: each env draws its colour from its own stream exactly as the reference's on_reset does
-    (move_to_corner.py:42-44, move_to_region.py:47-51); observations equal the oracle env built with the same draw,
+    (move_to_corner.py:42-44, move_to_region.py:47-51, match_regions.py:51-58, make_line.py:105-107); observations equal the oracle env built with the same draw,
     byte for byte, across an auto-reset."""
     from oracle.env_ref import LoRes4ERef, RefEnv
     n, ep, seed = 6, 3, 77
@@ -317,8 +318,10 @@ def test_test_colour_variants_match_oracle(task, flag):
     first = [r.reset() for r in refs]
     cols = set()
     for k, r in enumerate(refs):
-        ent = r.env.task.shape if task == 'MoveToCorner' else r.env.task.goal
-        cols.add(str(ent.colour_name))
+        t_ = r.env.task
+        ents = {'MoveToCorner': lambda: [t_.shape], 'MoveToRegion': lambda: [t_.goal], 'MatchRegions': lambda: [t_.sensor],
+                'MakeLine': lambda: t_.blocks}[task]()
+        cols.add(tuple(str(e.colour_name) for e in ents))
         assert np.array_equal(obs[k], first[k]), (task, k)
     assert len(cols) > 1                      # the draws differ between envs
     tape = _tape(37, 2 * ep, n)
