@@ -230,6 +230,7 @@ class BaseEnv(abc.ABC):
         fill = None
         if done.any():
             idx = np.nonzero(done)[0]
+            self._scoring_envs = idx          # which envs the poses belong to (per-env task state of Test* variants)
             eval_score[idx] = self.score_on_end_of_traj(self.get_poses(idx))
             assert np.all((eval_score >= 0) & (eval_score <= 1)), 'eval score out of range'
             if self.auto_reset:
@@ -243,10 +244,10 @@ class BaseEnv(abc.ABC):
         return obs, self._reward, done, {'eval_score': eval_score}
 
     # ------------------------------------------------------------------ per-env variation (Test* variants)
-    def sample_variation(self, rng):
+    def sample_variation(self, rng, k):
         """Task hook: draw this episode's random choices from `rng` with the same calls, in the same order, as the
-        reference's on_reset() (after the physics variables, base_env.py:198-214).  Return None (Demo) or a dict;
-        supported key: 'colours' = {entity: colour name}."""
+        reference's on_reset() (after the physics variables, base_env.py:198-214), for env `k` (tasks keep what their
+        score needs per env).  Return None (Demo) or a dict; supported key: 'colours' = {entity: colour name}."""
         return None
 
     def _randomise(self, env_idx):
@@ -256,7 +257,7 @@ class BaseEnv(abc.ABC):
             rng = self.rngs[k]
             if self.rand_dynamics:
                 pvs.append(PhysicsVariables.sample(rng))
-            var = self.sample_variation(rng)
+            var = self.sample_variation(rng, int(k))
             if var is not None and 'colours' in var:
                 row = self._default_colours.copy()
                 for ent, name in var['colours'].items():

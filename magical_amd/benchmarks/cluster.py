@@ -1,4 +1,4 @@
-"""ClusterColour / ClusterShape (mirror of magical/benchmarks/cluster.py, Demo branch)."""
+"""ClusterColour / ClusterShape (mirror of magical/benchmarks/cluster.py: Demo, TestColour and TestDynamics branches)."""
 import abc
 import enum
 
@@ -15,10 +15,27 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
 
     def __init__(self, rand_shape_colour=False, rand_shape_type=False, rand_layout_minor=False, rand_layout_full=False,
                  rand_shape_count=False, cluster_by=ClusterBy.COLOUR, **kwargs):
-        if rand_shape_colour or rand_shape_type or rand_layout_minor or rand_layout_full or rand_shape_count:
-            raise NotImplementedError('only the Demo and TestDynamics variants are built (the other Test* variants need per-env geometry: SURVEY.md §8f)')
+        if rand_shape_type or rand_layout_minor or rand_layout_full or rand_shape_count:
+            raise NotImplementedError('built: Demo, TestColour, TestDynamics (shape types / counts / layouts need per-env geometry: SURVEY.md §8f)')
         self.cluster_by = cluster_by
+        self.rand_shape_colour = rand_shape_colour
+        self._class_env = None
         super().__init__(**kwargs)
+
+    def sample_variation(self, rng, k):   # cluster.py:91-100: at least one block of each colour, the rest drawn, then shuffled
+        if not self.rand_shape_colour:
+            return None
+        names = en.SHAPE_COLOUR_NAMES
+        colours = list(names)
+        colours.extend([rng.choice(names) for _ in range(len(self.__shape_ents) - len(colours))])
+        rng.shuffle(colours)
+        if self.cluster_by == self.ClusterBy.COLOUR:
+            # class of a block = rank of its colour among the colours present (np.unique sorts them; all four are present)
+            if self._class_env is None:
+                self._class_env = np.tile(self.__class_of_block, (self.n_envs, 1))
+            order = {c: i for i, c in enumerate(sorted(set(colours)))}
+            self._class_env[k] = [order[c] for c in colours]
+        return {'colours': dict(zip(self.__shape_ents, colours))}
 
     def on_reset(self):   # cluster.py:67-164
         robot = self._make_robot(*self.DEFAULT_ROBOT_POSE)
@@ -32,26 +49,32 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
         self.__shape_ents = shape_ents
         self.__members = [[k for k, v in enumerate(c_values_list) if v == c_value]
                           for c_value in self.__characteristic_values]
+        self.__class_of_block = np.array([list(self.__characteristic_values).index(v) for v in c_values_list], dtype=np.int64)
         self.add_entities([robot])
 
     def score_on_end_of_traj(self, poses):   # cluster.py:166-216
         pos = poses[:, [e.body for e in self.__shape_ents], :2]            # [M, n_blocks, 2]
+        M, n_blocks = pos.shape[0], pos.shape[1]
         nvals = len(self.__characteristic_values)
-        centroids = np.zeros((pos.shape[0], nvals, 2))
-        for c_idx, members in enumerate(self.__members):
-            centroids[:, c_idx] = np.mean(pos[:, members, :], axis=1)
+        cls = np.tile(self.__class_of_block, (M, 1)) if self._class_env is None else self._class_env[self._scoring_envs]   # [M, n_blocks]
+        # centroid of every class: np.mean over its members = their sum in block order / their number (adding the
+        # exact zeros of non-members changes nothing, so one loop serves envs with different memberships)
+        sums = np.zeros((M, nvals, 2))
+        counts = np.zeros((M, nvals))
+        rows = np.arange(M)
+        for k in range(n_blocks):
+            sums[rows, cls[:, k]] += pos[:, k]
+            counts[rows, cls[:, k]] += 1.0
+        centroids = sums / counts[:, :, None]
         min_margin = 2.0
-        n_blocks = 0
-        n_correct = np.zeros(pos.shape[0], dtype=np.int64)
-        indices = np.arange(nvals)
-        for c_idx, members in enumerate(self.__members):
-            for k in members:
-                n_blocks += 1
-                centroid_sses = np.sum((pos[:, k, None, :] - centroids)**2, axis=2)     # [M, nvals]
-                true_sse = centroid_sses[:, c_idx]
-                nearest_bad_centroid = np.min(centroid_sses[:, indices != c_idx], axis=1)
-                margin = min_margin * true_sse        # squared distance as margin: reference quirk (cluster.py:203-206)
-                n_correct += (np.sqrt(true_sse) < np.sqrt(nearest_bad_centroid) - margin).astype(np.int64)
+        n_correct = np.zeros(M, dtype=np.int64)
+        for k in range(n_blocks):
+            centroid_sses = np.sum((pos[:, k, None, :] - centroids)**2, axis=2)     # [M, nvals]
+            true_sse = centroid_sses[rows, cls[:, k]]
+            others = np.where(np.arange(nvals)[None, :] == cls[:, k, None], np.inf, centroid_sses)
+            nearest_bad_centroid = np.min(others, axis=1)
+            margin = min_margin * true_sse        # squared distance as margin: reference quirk (cluster.py:203-206)
+            n_correct += (np.sqrt(true_sse) < np.sqrt(nearest_bad_centroid) - margin).astype(np.int64)
         frac_correct = n_correct.astype(np.float64) / max(n_blocks, 1)
         thresh = 0.75
         return np.maximum(frac_correct - thresh, 0) / (1 - thresh)

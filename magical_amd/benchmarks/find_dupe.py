@@ -1,4 +1,4 @@
-"""FindDupe (mirror of magical/benchmarks/find_dupe.py, Demo branch)."""
+"""FindDupe (mirror of magical/benchmarks/find_dupe.py: Demo, TestColour and TestDynamics branches)."""
 import numpy as np
 
 from .. import entities as en
@@ -21,9 +21,27 @@ DEFAULT_QUERY_BLOCK_POSE = ((-0.33, -0.49), -0.51)
 class FindDupeEnv(BaseEnv):
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
-        if rand_colours or rand_shapes or rand_count or rand_layout_minor or rand_layout_full:
-            raise NotImplementedError('only the Demo and TestDynamics variants are built (the other Test* variants need per-env geometry: SURVEY.md §8f)')
+        if rand_shapes or rand_count or rand_layout_minor or rand_layout_full:
+            raise NotImplementedError('built: Demo, TestColour, TestDynamics (shape types / counts / layouts need per-env geometry: SURVEY.md §8f)')
+        self.rand_colours = rand_colours
+        self._is_target_env = None
         super().__init__(**kwargs)
+
+    def sample_variation(self, rng, k):   # find_dupe.py:90-95,126-140
+        if not self.rand_colours:
+            return None
+        names = en.SHAPE_COLOUR_NAMES
+        query_colour = rng.choice(names)
+        out_block_colours = rng.choice(names, size=len(self.__outside_blocks) - 1).tolist()
+        out_block_colours.append(query_colour)               # the last outside block always matches the query
+        if self._is_target_env is None:
+            self._is_target_env = np.tile(self.__is_target, (self.n_envs, 1))
+        # __all_blocks = [query block, *outside blocks]; a block is a target iff it has the query's colour and shape
+        self._is_target_env[k] = [True] + [c == query_colour and s == DEFAULT_QUERY_SHAPE
+                                           for c, s in zip(out_block_colours, DEFAULT_OUT_BLOCK_SHAPES)]
+        colours = {self.__sensor_ref: query_colour, self.__all_blocks[0]: query_colour}
+        colours.update(zip(self.__outside_blocks, out_block_colours))
+        return {'colours': colours}
 
     def on_reset(self):   # find_dupe.py:72-155
         robot = self._make_robot(*DEFAULT_ROBOT_POSE)
@@ -43,12 +61,14 @@ class FindDupeEnv(BaseEnv):
         self.add_entities([query_block])
         self.add_entities([robot])
         self.__all_blocks = [query_block, *outside_blocks]
+        self.__outside_blocks = outside_blocks
         self.__is_target = np.array([b in targets for b in self.__all_blocks])
 
     def score_on_end_of_traj(self, poses):   # find_dupe.py:203-216
         ov = overlapping_ents(self, self.__sensor_ref, self.__all_blocks, poses)
-        n_overlap_targets = ov[:, self.__is_target].sum(axis=1)
-        n_overlap_distractors = ov[:, ~self.__is_target].sum(axis=1)
+        is_target = self.__is_target[None, :] if self._is_target_env is None else self._is_target_env[self._scoring_envs]
+        n_overlap_targets = (ov & is_target).sum(axis=1)
+        n_overlap_distractors = (ov & ~is_target).sum(axis=1)
         n_overlap = ov.sum(axis=1)
         have_two_shapes = (n_overlap_targets >= 2).astype(np.float64)
         contamination_rate = np.where(n_overlap == 0, 0.0, n_overlap_distractors / np.maximum(n_overlap, 1))

@@ -1,4 +1,4 @@
-"""FixColour (mirror of magical/benchmarks/fix_colour.py, Demo branch)."""
+"""FixColour (mirror of magical/benchmarks/fix_colour.py: Demo, TestColour and TestDynamics branches)."""
 import numpy as np
 
 from .. import entities as en
@@ -16,9 +16,29 @@ DEFAULT_REGION_COLOURS = [en.ShapeColour.GREEN, en.ShapeColour.GREEN, en.ShapeCo
 class FixColourEnv(BaseEnv):
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
-        if rand_colours or rand_shapes or rand_count or rand_layout_minor or rand_layout_full:
-            raise NotImplementedError('only the Demo and TestDynamics variants are built (the other Test* variants need per-env geometry: SURVEY.md §8f)')
+        if rand_shapes or rand_count or rand_layout_minor or rand_layout_full:
+            raise NotImplementedError('built: Demo, TestColour, TestDynamics (shape types / counts / layouts need per-env geometry: SURVEY.md §8f)')
+        self.rand_colours = rand_colours
+        self._keep_env = None
         super().__init__(**kwargs)
+
+    def sample_variation(self, rng, k):   # fix_colour.py:84-94
+        if not self.rand_colours:
+            return None
+        names = en.SHAPE_COLOUR_NAMES
+        region_colours = rng.choice(names, size=len(self._blocks)).tolist()
+        block_colours = list(region_colours)
+        odd_idx = rng.randint(len(block_colours))            # one block gets a colour that is not its region's
+        new_col_idx = rng.randint(len(names) - 1)
+        if names[new_col_idx] == block_colours[odd_idx]:
+            new_col_idx += 1
+        block_colours[odd_idx] = names[new_col_idx]
+        if self._keep_env is None:
+            self._keep_env = np.tile(np.asarray(self._keep, dtype=bool), (self.n_envs, 1))
+        self._keep_env[k] = [b == t for b, t in zip(block_colours, region_colours)]
+        colours = dict(zip(self._sensors, region_colours))
+        colours.update(zip(self._blocks, block_colours))
+        return {'colours': colours}
 
     def on_reset(self):   # fix_colour.py:69-141
         robot = self._make_robot(*DEFAULT_ROBOT_POSE)
@@ -34,9 +54,10 @@ class FixColourEnv(BaseEnv):
 
     def score_on_end_of_traj(self, poses):   # fix_colour.py:193-202: list(overlap_ents) == expected, per region
         complete = np.ones(poses.shape[0], dtype=bool)
+        keep = np.tile(np.asarray(self._keep, dtype=bool), (poses.shape[0], 1)) if self._keep_env is None else self._keep_env[self._scoring_envs]
         for k, sensor in enumerate(self._sensors):
             ov = overlapping_ents(self, sensor, self._blocks, poses)
-            expected = np.zeros(len(self._blocks), dtype=bool)
-            expected[k] = self._keep[k]
-            complete &= (ov == expected[None, :]).all(axis=1)
+            expected = np.zeros((poses.shape[0], len(self._blocks)), dtype=bool)
+            expected[:, k] = keep[:, k]
+            complete &= (ov == expected).all(axis=1)
         return np.where(complete, 1.0, 0.0)

@@ -57,7 +57,7 @@ class MakeLineEnv(BaseEnv):
         self.add_entities(self._blocks)
         self.add_entities([robot])
 
-    def sample_variation(self, rng):   # make_line.py:105-107
+    def sample_variation(self, rng, k):   # make_line.py:105-107
         if not self.rand_colours:
             return None
         block_colours = rng.choice(en.SHAPE_COLOUR_NAMES, size=len(self._blocks)).tolist()

@@ -16,7 +16,7 @@ class MatchRegionsEnv(BaseEnv):
         self.rand_target_colour = rand_target_colour
         super().__init__(**kwargs)
 
-    def sample_variation(self, rng):   # match_regions.py:51-58: the sensor and the targets take the drawn colour, the
+    def sample_variation(self, rng, k):   # match_regions.py:51-58: the sensor and the targets take the drawn colour, the
         if not self.rand_target_colour:   # distractor groups the remaining ones in SHAPE_COLOURS order
             return None
         target_colour = rng.choice(en.SHAPE_COLOUR_NAMES)

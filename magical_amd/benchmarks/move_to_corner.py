@@ -15,7 +15,7 @@ class MoveToCornerEnv(BaseEnv):
         self.rand_shape_colour = rand_shape_colour
         super().__init__(**kwargs)
 
-    def sample_variation(self, rng):   # move_to_corner.py:42-44
+    def sample_variation(self, rng, k):   # move_to_corner.py:42-44
         if not self.rand_shape_colour:
             return None
         return {'colours': {self.__shape_ref: rng.choice(np.asarray(en.SHAPE_COLOURS, dtype='object'))}}

@@ -16,7 +16,7 @@ class MoveToRegionEnv(BaseEnv):
         self.rand_goal_colour = rand_goal_colour
         super().__init__(**kwargs)
 
-    def sample_variation(self, rng):   # move_to_region.py:47-51
+    def sample_variation(self, rng, k):   # move_to_region.py:47-51
         if not self.rand_goal_colour:
             return None
         return {'colours': {self.__goal_ref: rng.choice(np.asarray(en.SHAPE_COLOURS, dtype='object'))}}

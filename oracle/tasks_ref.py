@@ -1,7 +1,7 @@
 """Task layouts + score_on_end_of_traj restatements.
 
 TEST INFRASTRUCTURE.  One class per reference task file; the Demo (all rand_* False) branches of every task, plus the
-colour-only randomisation branches of MoveToCorner / MoveToRegion / MatchRegions / MakeLine (*-TestColour-*).  Scores follow the reference's
+colour-only randomisation branches (the *-TestColour-* variants).  Scores follow the reference's
 float64 numpy/Python operation order so they can be compared bit-for-bit with
 the product's host scoring.
 """
@@ -190,17 +190,22 @@ class FindDupeRef(TaskRef):
         robot = _robot((-0.57, 0.25), 3.83)
         out_shapes = ['pentagon', 'circle', 'circle', 'square', 'star', 'pentagon']
         out_colours = ['green', 'red', 'red', 'yellow', 'blue', 'yellow']
+        query_colour = 'yellow'
+        if self.flags.get('rand_colours'):                # find_dupe.py:90-95
+            query_colour = self.rng.choice(SHAPE_COLOURS)
+            out_colours = self.rng.choice(SHAPE_COLOURS, size=len(out_shapes) - 1).tolist()
+            out_colours.append(query_colour)
         out_poses = [((-0.066751, 0.7552), -2.9266), ((-0.05195, 0.31468), 1.5418),
                      ((0.57528, -0.46865), -2.2141), ((0.40594, -0.74977), 0.24582),
                      ((0.45254, 0.3681), -1.0834), ((0.76849, -0.10652), 0.10028)]
-        self.sensor = w.add(GoalRegion(-0.72, -0.22, 0.67, 0.72, 'yellow'))
+        self.sensor = w.add(GoalRegion(-0.72, -0.22, 0.67, 0.72, query_colour))
         self.outside_blocks, self.target_set = [], []
         for s, c, (p, a) in zip(out_shapes, out_colours, out_poses):
             blk = w.add(_shape(s, c, p, a))
             self.outside_blocks.append(blk)
-            if c == 'yellow' and s == 'pentagon':
+            if c == query_colour and s == 'pentagon':
                 self.target_set.append(blk)
-        self.query_block = w.add(_shape('pentagon', 'yellow', (-0.33, -0.49), -0.51))
+        self.query_block = w.add(_shape('pentagon', query_colour, (-0.33, -0.49), -0.51))
         self.target_set.append(self.query_block)
         self.distractor_set = [b for b in self.outside_blocks if b not in self.target_set]
         self.robot = w.add(robot)
@@ -230,6 +235,14 @@ class FixColourRef(TaskRef):
         region_xyhws = [(-0.032, 0.348, 0.427, 0.468), (0.019, -0.391, 0.460, 0.458),
                         (-0.681, 0.196, 0.498, 0.418)]
         region_colours = ['green', 'green', 'red']
+        if self.flags.get('rand_colours'):                # fix_colour.py:84-94
+            region_colours = self.rng.choice(SHAPE_COLOURS, size=len(block_colours)).tolist()
+            block_colours = list(region_colours)
+            odd_idx = self.rng.randint(len(block_colours))
+            new_col_idx = self.rng.randint(len(SHAPE_COLOURS) - 1)
+            if SHAPE_COLOURS[new_col_idx] == block_colours[odd_idx]:
+                new_col_idx += 1
+            block_colours[odd_idx] = SHAPE_COLOURS[new_col_idx]
         self.sensors = [w.add(GoalRegion(*xyhw, col)) for col, xyhw in zip(region_colours, region_xyhws)]
         self.blocks, self.target_blocks = [], []
         for s, c, tc, (p, a) in zip(block_shapes, block_colours, region_colours, block_poses):
@@ -257,9 +270,14 @@ class _ClusterRef(TaskRef):
     def on_reset(self):
         w = self.world
         robot = _robot(*self.ROBOT_POSE)
+        colours = self.COLOURS
+        if self.flags.get('rand_shape_colour'):          # cluster.py:91-100
+            colours = list(SHAPE_COLOURS)
+            colours.extend([self.rng.choice(SHAPE_COLOURS) for _ in range(len(self.POSES) - len(colours))])
+            self.rng.shuffle(colours)
         self.shape_ents = [w.add(_shape(s, c, p, a))
-                           for (p, a), c, s in zip(self.POSES, self.COLOURS, self.SHAPES)]
-        c_values_list = np.asarray(self.COLOURS if self.by == 'colour' else self.SHAPES, dtype='object')
+                           for (p, a), c, s in zip(self.POSES, colours, self.SHAPES)]
+        c_values_list = np.asarray(colours if self.by == 'colour' else self.SHAPES, dtype='object')
         self.characteristic_values = np.unique(c_values_list)
         self.blocks_by_characteristic = {}
         for shape, c_value in zip(self.shape_ents, c_values_list):

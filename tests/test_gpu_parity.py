@@ -304,7 +304,9 @@ def test_rand_dynamics_matches_oracle(task):
 
 
 @pytest.mark.parametrize('task,flag', [('MoveToCorner', 'rand_shape_colour'), ('MoveToRegion', 'rand_goal_colour'),
-                                       ('MatchRegions', 'rand_target_colour'), ('MakeLine', 'rand_colours')])
+                                       ('MatchRegions', 'rand_target_colour'), ('MakeLine', 'rand_colours'),
+                                       ('FindDupe', 'rand_colours'), ('FixColour', 'rand_colours'),
+                                       ('ClusterColour', 'rand_shape_colour'), ('ClusterShape', 'rand_shape_colour')])
 def test_test_colour_variants_match_oracle(task, flag):
     """*-TestColour-v0: each env draws its colour from its own stream exactly as the reference's on_reset does
     (move_to_corner.py:42-44, move_to_region.py:47-51, match_regions.py:51-58, make_line.py:105-107); observations equal the oracle env built with the same draw,
@@ -320,17 +322,20 @@ def test_test_colour_variants_match_oracle(task, flag):
     for k, r in enumerate(refs):
         t_ = r.env.task
         ents = {'MoveToCorner': lambda: [t_.shape], 'MoveToRegion': lambda: [t_.goal], 'MatchRegions': lambda: [t_.sensor],
-                'MakeLine': lambda: t_.blocks}[task]()
+                'MakeLine': lambda: t_.blocks, 'FindDupe': lambda: t_.outside_blocks, 'FixColour': lambda: t_.blocks,
+                'ClusterColour': lambda: t_.shape_ents, 'ClusterShape': lambda: t_.shape_ents}[task]()
         cols.add(tuple(str(e.colour_name) for e in ents))
         assert np.array_equal(obs[k], first[k]), (task, k)
     assert len(cols) > 1                      # the draws differ between envs
     tape = _tape(37, 2 * ep, n)
     for s in range(2 * ep):
-        obs, _, done, _ = env.step(tape[s])
+        obs, _, done, info = env.step(tape[s])
         obs = obs.cpu().numpy()
         for k, r in enumerate(refs):
-            o, _, d, _ = r.step(tape[s, k])
+            o, _, d, inf = r.step(tape[s, k])
             assert d == done[k]
+            if d:                             # the score uses this env's own colour assignment
+                assert inf['eval_score'] == info['eval_score'][k], (task, s, k)
             want = r.reset() if d else o      # auto-reset: new draw, stack refilled
             assert np.array_equal(obs[k], want), (task, s, k)
     env.close()
@@ -388,6 +393,41 @@ def test_scores_bit_exact_on_engine_poses(task):
         b[idx, :3] = poses[k, 1:, :]
         ref.set_bodies(b)
         assert float(ref.task.score_on_end_of_traj()) == info['eval_score'][k], (task, k)
+    env.close()
+
+
+@pytest.mark.parametrize('task,flag', [('ClusterColour', 'rand_shape_colour'), ('FindDupe', 'rand_colours'), ('FixColour', 'rand_colours')])
+def test_scores_with_per_env_colours(task, flag):
+    """The tasks whose score depends on the colours drawn per env (cluster membership, the duplicate set, the regions'
+    expected blocks): product scoring on scrambled poses equals the oracle env that drew the same colours, bit for bit,
+    and actually varies between envs."""
+    from oracle.env_ref import RefEnv
+    n, seed = 24, 5
+    env = _make(f'{task}-TestColour-v0', n, dtype='f64')
+    env.seed(seed)
+    env.reset()
+    refs = [RefEnv(task, seed=seed + k, **{flag: True}) for k in range(n)]
+    for r in refs:
+        r.reset()
+    idx = ref_body_index(refs[0])
+    rs = np.random.RandomState(3)
+    b = env.get_bodies()
+    # scatter the blocks: some clustered near a few attractors / inside the goal regions, some anywhere
+    att = rs.uniform(-0.8, 0.8, size=(4, 2))
+    for k in range(n):
+        for j in range(1, b.shape[1]):
+            b[k, j, :2] = att[rs.randint(4)] + rs.normal(0, 0.08, 2) if rs.rand() < 0.7 else rs.uniform(-0.9, 0.9, 2)
+    env.set_bodies(b)
+    poses = env.get_poses()
+    env._scoring_envs = np.arange(n)
+    got = env.score_on_end_of_traj(poses)
+    want = np.zeros(n)
+    for k, r in enumerate(refs):
+        rb = r.bodies()
+        rb[idx, :3] = poses[k, 1:, :]
+        r.set_bodies(rb)
+        want[k] = float(r.task.score_on_end_of_traj())
+    assert np.array_equal(got, want), (task, got, want)
     env.close()
 
 
