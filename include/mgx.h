@@ -118,6 +118,11 @@ int mgx_engine_lds_bytes(const mgx_engine *e, int which);   /* 0 = step kernel, 
 /* BaseEnv.reset() (base_env.py:177-234): template state -> envs where mask[i] != 0 (mask NULL = all).
  * mask is a DEVICE pointer to u8[N]. */
 int mgx_engine_reset(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const uint8_t *mask, void *stream);
+/* the same with per-env initial entity poses (Test*Jitter / TestLayout variants; geom.py:116-341 picks them on the host):
+ * ent_pose = DEVICE [n_entities * 3][N] (x, y, angle per entity, element type = the pose type of state_p); every body
+ * of an entity follows it rigidly (geom.py pm_shift_bodies); rows of goal entities are ignored */
+int mgx_engine_reset_poses(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const uint8_t *mask,
+                           const void *ent_pose, void *stream);
 /* BaseEnv.step() physics (base_env.py:255-274): set_action + 10 x {Robot.update; space.step(dt)} +
  * episode step counter.  actions: DEVICE i32[N] in [0,18).  done: DEVICE u8[N] (may be NULL). */
 int mgx_engine_step(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const int32_t *actions,

@@ -86,6 +86,7 @@ def lib():
         'mgx_engine_lanes_per_env': [vp],
         'mgx_engine_lds_bytes': [vp, i32],
         'mgx_engine_reset': [vp, vp, vp, vp, vp, vp],
+        'mgx_engine_reset_poses': [vp, vp, vp, vp, vp, vp, vp],
         'mgx_engine_step': [vp, vp, vp, vp, vp, vp, vp],
         'mgx_engine_substeps': [vp, vp, vp, vp, vp, i32, vp],
         'mgx_engine_render': [vp, vp, vp, i64, i32, i32, vp, vp],
@@ -117,7 +118,7 @@ EXPORTED_SYMBOLS = [
     'mgx_world_entity', 'mgx_world_body_table', 'mgx_world_n_state_entries', 'mgx_world_state_entry',
     'mgx_world_goal_bb', 'mgx_world_entity_shapes', 'mgx_world_prim_table', 'mgx_world_palette',
     'mgx_engine_create', 'mgx_engine_destroy', 'mgx_engine_set_prim_colours',
-    'mgx_engine_state_shape', 'mgx_engine_lanes_per_env', 'mgx_engine_lds_bytes', 'mgx_engine_reset',
+    'mgx_engine_state_shape', 'mgx_engine_lanes_per_env', 'mgx_engine_lds_bytes', 'mgx_engine_reset', 'mgx_engine_reset_poses',
     'mgx_engine_step', 'mgx_engine_substeps', 'mgx_engine_render', 'mgx_engine_render_native',
     'mgx_engine_set_timing', 'mgx_engine_timing_read',
 ]

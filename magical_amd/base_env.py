@@ -176,6 +176,11 @@ class BaseEnv(abc.ABC):
         self._prim_rgb = None        # device int32[n_prims, N], allocated when an env first deviates from the template
         self._default_colours = np.array([en.COLOUR_ID[e.colour_name] if hasattr(e, 'colour_name') else -1 for e in self._entities], dtype=np.int64)
         self.entity_colours = np.tile(self._default_colours, (self.n_envs, 1))          # per env
+        # initial (x, y, angle) of every entity, per env (goal regions: their x, y and 0)
+        self._default_poses = np.array([[e.init_pos[0], e.init_pos[1], e.init_angle] if hasattr(e, 'init_pos') else [e.x, e.y, 0.0]
+                                        for e in self._entities], dtype=np.float64)
+        self.entity_poses = np.tile(self._default_poses, (self.n_envs, 1, 1))
+        self._ent_pose = None        # device [n_entities * 3, N], allocated when an env first deviates from the template
         # pose-blob row of (x, y, angle) per body, -1 where the body is not persistent
         n = nat.check(L.mgx_world_n_state_entries(w))
         self._pose_rows = -np.ones((self.n_bodies, 3), dtype=np.int64)
@@ -202,10 +207,7 @@ class BaseEnv(abc.ABC):
     # ------------------------------------------------------------------ reset / step
     def reset(self):
         """base_env.py:177-234 for every env.  Returns the first observation."""
-        nat.check(self._lib.mgx_engine_reset(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
-                                             self.state_i.data_ptr(), None, self._stream()))
-        self._steps[:] = 0
-        self._randomise(np.arange(self.n_envs))
+        self._reset_envs(np.arange(self.n_envs), None)
         if not self._warm:
             # the first pose read-back loads torch's gather / copy kernels (tens of ms, once per process); pay for it
             # here rather than in the middle of the first rollout
@@ -235,10 +237,7 @@ class BaseEnv(abc.ABC):
             assert np.all((eval_score >= 0) & (eval_score <= 1)), 'eval score out of range'
             if self.auto_reset:
                 # the device-side done flags written by the step kernel double as reset + frame-fill masks
-                nat.check(self._lib.mgx_engine_reset(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
-                                                     self.state_i.data_ptr(), self._done_dev.data_ptr(), self._stream()))
-                self._steps[idx] = 0
-                self._randomise(idx)
+                self._reset_envs(idx, self._done_dev)
                 fill = self._done_dev
         obs = self._observe(fill_mask=fill)
         return obs, self._reward, done, {'eval_score': eval_score}
@@ -247,12 +246,16 @@ class BaseEnv(abc.ABC):
     def sample_variation(self, rng, k):
         """Task hook: draw this episode's random choices from `rng` with the same calls, in the same order, as the
         reference's on_reset() (after the physics variables, base_env.py:198-214), for env `k` (tasks keep what their
-        score needs per env).  Return None (Demo) or a dict; supported key: 'colours' = {entity: colour name}."""
+        score needs per env).  Return None (Demo) or a dict; supported keys: 'colours' = {entity: colour name},
+        'poses' = {entity: (x, y, angle)}."""
         return None
 
-    def _randomise(self, env_idx):
-        """Per-env draws for the envs being reset, env k from its own stream self.rngs[k]."""
-        pvs, colour_rows = [], []
+    def _reset_envs(self, env_idx, mask_dev):
+        """BaseEnv.reset() for the envs `env_idx` (device mask `mask_dev`, None = all): per-env draws first (env k from
+        its own stream self.rngs[k], in the reference's order: physics variables, then the task's on_reset choices), then
+        the reset kernel -- with the drawn entity poses if any -- then the drawn force limits and colours."""
+        import torch
+        pvs, colour_rows, pose_rows = [], [], []
         for k in env_idx:
             rng = self.rngs[k]
             if self.rand_dynamics:
@@ -263,6 +266,26 @@ class BaseEnv(abc.ABC):
                 for ent, name in var['colours'].items():
                     row[self._entities.index(ent)] = en.COLOUR_ID[name]
                 colour_rows.append(row)
+            if var is not None and 'poses' in var:
+                row = self._default_poses.copy()
+                for ent, pose in var['poses'].items():
+                    row[self._entities.index(ent)] = pose
+                pose_rows.append(row)
+        sp, sf, si = self.state_p.data_ptr(), self.state_f.data_ptr(), self.state_i.data_ptr()
+        mask = None if mask_dev is None else mask_dev.data_ptr()
+        if pose_rows:
+            self.entity_poses[env_idx] = np.asarray(pose_rows)
+            if self._ent_pose is None:
+                self._ent_pose = torch.as_tensor(np.ascontiguousarray(self.entity_poses.reshape(self.n_envs, -1).T),
+                                                 device=self.device).to(self.state_p.dtype).contiguous()       # [n_ent * 3, N]
+            else:
+                self._ent_pose[:, torch.as_tensor(env_idx, device=self.device)] = torch.as_tensor(
+                    np.ascontiguousarray(self.entity_poses[env_idx].reshape(len(env_idx), -1).T), device=self.device).to(self.state_p.dtype)
+        if self._ent_pose is not None:
+            nat.check(self._lib.mgx_engine_reset_poses(self._engine, sp, sf, si, mask, self._ent_pose.data_ptr(), self._stream()))
+        else:
+            nat.check(self._lib.mgx_engine_reset(self._engine, sp, sf, si, mask, self._stream()))
+        self._steps[env_idx] = 0
         if pvs:
             self.set_phys_vars(np.asarray(pvs, dtype=np.float64), env_idx)
         if colour_rows:

@@ -355,16 +355,23 @@ int mgx_engine_state_shape(const mgx_engine *e, int *rows_p, int *rows_f, int *r
 int mgx_engine_lanes_per_env(const mgx_engine *e) { return e ? e->L : 0; }
 int mgx_engine_lds_bytes(const mgx_engine *e, int which) { return e ? (int)(which == 0 ? e->lds_step : e->lds_raster) : 0; }
 
-int mgx_engine_reset(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const uint8_t *mask, void *stream) {
+static int reset_common(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const uint8_t *mask, const void *ent_pose, void *stream) {
     if (!e || !state_p || !state_f || !state_i) return fail(MGX_ERR_ARG, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
     size_t lds = (size_t)e->tdev.n_words * 4;
     int blocks = (e->n_envs + 63) / 64;
-    if (e->dtype == MGX_F32) hipLaunchKernelGGL((k_reset<float, double>), dim3(blocks), dim3(64), lds, st, e->tdev, (double *)state_p, (float *)state_f, state_i, mask, e->n_envs);
-    else if (e->dtype == MGX_F64) hipLaunchKernelGGL((k_reset<double, double>), dim3(blocks), dim3(64), lds, st, e->tdev, (double *)state_p, (double *)state_f, state_i, mask, e->n_envs);
-    else hipLaunchKernelGGL((k_reset<float, float>), dim3(blocks), dim3(64), lds, st, e->tdev, (float *)state_p, (float *)state_f, state_i, mask, e->n_envs);
+    if (e->dtype == MGX_F32) hipLaunchKernelGGL((k_reset<float, double>), dim3(blocks), dim3(64), lds, st, e->tdev, (double *)state_p, (float *)state_f, state_i, mask, (const double *)ent_pose, e->n_envs);
+    else if (e->dtype == MGX_F64) hipLaunchKernelGGL((k_reset<double, double>), dim3(blocks), dim3(64), lds, st, e->tdev, (double *)state_p, (double *)state_f, state_i, mask, (const double *)ent_pose, e->n_envs);
+    else hipLaunchKernelGGL((k_reset<float, float>), dim3(blocks), dim3(64), lds, st, e->tdev, (float *)state_p, (float *)state_f, state_i, mask, (const float *)ent_pose, e->n_envs);
     HIP_OK(hipGetLastError());
     return MGX_OK;
+}
+int mgx_engine_reset(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const uint8_t *mask, void *stream) {
+    return reset_common(e, state_p, state_f, state_i, mask, nullptr, stream);
+}
+int mgx_engine_reset_poses(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const uint8_t *mask, const void *ent_pose, void *stream) {
+    if (!ent_pose) return fail(MGX_ERR_ARG, "ent_pose is NULL (use mgx_engine_reset for the template poses)");
+    return reset_common(e, state_p, state_f, state_i, mask, ent_pose, stream);
 }
 static int step_common(mgx_engine *e, void *sp, void *sf, int32_t *si, const int32_t *actions, uint8_t *done, int n_sub, int count_step, void *stream) {
     if (!e || !sp || !sf || !si || !actions) return fail(MGX_ERR_ARG, "NULL argument");

@@ -1101,19 +1101,31 @@ MGX_HD void ph_store_state(Env<R, P> &e, P *sp, R *sf, int32_t *si, long stride,
 // BaseEnv.reset() for one env: template poses, zero velocities / accumulators / cache.
 // Bodies with a parent (finger roots) are placed with the SAME rounding sequence the pin-joint
 // preStep uses, so the zero-length PinJoint starts with delta == 0 exactly, as in the reference.
+// ent_pose (optional): [n_entities * 3][stride] per-env (x, y, angle) of every entity (Test*Jitter / Layout variants,
+// geom.py pm_shift_bodies): the entity's bodies follow it rigidly -- the main body takes the pose, the eyes its angle,
+// the finger roots are re-derived from the moved robot exactly as at construction.
 template <typename R, typename P>
-MGX_HD void reset_env_state(const TmplHeader &h, const int32_t *ti, const R *tr, const P *tp, P *sp, R *sf, int32_t *si, long stride, long env) {
+MGX_HD void reset_env_state(const TmplHeader &h, const int32_t *ti, const R *tr, const P *tp, P *sp, R *sf, int32_t *si, long stride, long env,
+                            const P *ent_pose = nullptr) {
     TmplOff to(h);
     for (int k = 0; k < h.n_state; k++) {
         int m = ti[to.state_map + k], comp = m & 15, b = (m >> 4) & 0xFF, row = m >> 12;
         if (comp >= 3) { sf[(long)row * stride + env] = R(0); continue; }
         P v;
         int parent = ti[to.body_parent + b];
+        int ent = ent_pose ? ti[to.body_ent + b] : -1;
         if (parent >= 0 && comp < 2) {
-            P pa = tp[to.p_body_init + 3 * parent + 2], s, c, rx, ry;
+            // parent = the robot's main body: its pose is the template's or this env's entity pose
+            P px = tp[to.p_body_init + 3 * parent], py = tp[to.p_body_init + 3 * parent + 1], pa = tp[to.p_body_init + 3 * parent + 2];
+            if (ent >= 0) { px = ent_pose[(long)(3 * ent) * stride + env]; py = ent_pose[(long)(3 * ent + 1) * stride + env];
+                            pa = ent_pose[(long)(3 * ent + 2) * stride + env] + tp[to.p_body_aoff + parent]; }
+            P s, c, rx, ry;
             r_sincos<P>(pa, s, c);
             anchor_rot<P>(c, s, tp[to.p_body_anchor + 2 * b], tp[to.p_body_anchor + 2 * b + 1], rx, ry);
-            v = comp == 0 ? r_add_nc<P>(tp[to.p_body_init + 3 * parent], rx) : r_add_nc<P>(tp[to.p_body_init + 3 * parent + 1], ry);
+            v = comp == 0 ? r_add_nc<P>(px, rx) : r_add_nc<P>(py, ry);
+        } else if (ent >= 0) {
+            v = ent_pose[(long)(3 * ent + comp) * stride + env];
+            if (comp == 2) v = v + tp[to.p_body_aoff + b];
         } else {
             v = tp[to.p_body_init + 3 * b + comp];
         }

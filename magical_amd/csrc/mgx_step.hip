@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *_
 // BaseEnv.reset(): one thread per env writes the template state into the masked envs
 template <typename R, typename P>
 __global__ __launch_bounds__(64) void k_reset(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
-                                              const uint8_t *__restrict__ mask, int n_envs) {
+                                              const uint8_t *__restrict__ mask, const P *__restrict__ ent_pose, int n_envs) {
     extern __shared__ __align__(16) uint32_t lds[];
     for (int i = threadIdx.x; i < t.n_words; i += 64) lds[i] = t.words[i];
     __syncthreads();
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void k_reset(TmplDev t, P *__restrict__ sp, R *
     long env = (long)blockIdx.x * 64 + threadIdx.x;
     if (env >= n_envs) return;
     if (mask && !mask[env]) return;
-    reset_env_state<R, P>(*h, ti, tr, tp, sp, sf, si, (long)n_envs, env);
+    reset_env_state<R, P>(*h, ti, tr, tp, sp, sf, si, (long)n_envs, env, ent_pose);
 }
 
 }  // namespace mgx

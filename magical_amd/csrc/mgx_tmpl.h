@@ -57,17 +57,18 @@ enum ConstIdx {
 // offsets into the template's int / real arrays
 struct TmplOff {
     // ints
-    int body_type, body_parent, shape_kind, shape_body, shape_voff, shape_nv;
+    int body_type, body_parent, body_ent, shape_kind, shape_body, shape_voff, shape_nv;
     int joint_kind, joint_a, joint_b, joint_acc, joint_pv, pair, state_map, prim_i, body_prow, island_j, n_i;
     // reals
     int body_minv, body_iinv, body_init, body_anchor, shape_r, shape_u, lvx, lvy, lnx, lny;
     int joint_p, prim_r, pvx, pvy, consts, n_r;
     // pose-precision copies (P-typed array): initial poses, body anchors, joint anchors/angles, dt
-    int p_body_init, p_body_anchor, p_joint, p_dt, n_p;
+    int p_body_init, p_body_anchor, p_body_aoff, p_joint, p_dt, n_p;
     MGX_HD explicit TmplOff(const TmplHeader &h) {
         int o = 0;
         body_type = o; o += h.n_bodies;
         body_parent = o; o += h.n_bodies;
+        body_ent = o; o += h.n_bodies;        // entity of the body (per-env reset poses), -1 for the static body
         shape_kind = o; o += h.n_shapes;
         shape_body = o; o += h.n_shapes;
         shape_voff = o; o += h.n_shapes;
@@ -103,6 +104,7 @@ struct TmplOff {
         o = 0;
         p_body_init = o; o += h.n_bodies * 3;
         p_body_anchor = o; o += h.n_bodies * 2;
+        p_body_aoff = o; o += h.n_bodies;     // body angle - entity angle at reset
         p_joint = o; o += h.n_joints * 7;
         p_dt = o; o += 1;
         n_p = o;

@@ -142,9 +142,9 @@ int World::finalize(int max_steps, std::string &err) {
             double radius = ROBOT_RAD, mass = ROBOT_MASS;
             int body = (int)bodies.size();
             robot_body = body; e.body = body;
-            bodies.push_back({BODY_DYNAMIC, 1.0 / mass, 1.0 / moment_for_circle(mass, 0, radius), e.x, e.y, e.angle, -1, 0, 0, 0x1FF});
+            bodies.push_back({BODY_DYNAMIC, 1.0 / mass, 1.0 / moment_for_circle(mass, 0, radius), e.x, e.y, e.angle, -1, 0, 0, 0x1FF, (int)ei, 0.0});
             control_body = (int)bodies.size();
-            bodies.push_back({BODY_KINEMATIC, 0, 0, e.x, e.y, e.angle, -1, 0, 0, 0});
+            bodies.push_back({BODY_KINEMATIC, 0, 0, e.x, e.y, e.angle, -1, 0, 0, 0, (int)ei, 0.0});
             robot_j0 = (int)joints.size();
             JointDef pj = joint(J_PIVOT, control_body, body);              // :255-258
             pj.max_bias = 0; pj.max_force = pv[0]; pj.pv = 0;
@@ -158,7 +158,7 @@ int World::finalize(int max_steps, std::string &err) {
                 eye_bodies[k] = (int)bodies.size();
                 eye_body[k] = eye_bodies[k];
                 bodies.push_back({BODY_DYNAMIC, 1.0 / em, 1.0 / moment_for_circle(em, 0, radius), 0, 0, e.angle, -1, 0, 0,
-                                  (1 << 2) | (1 << 5)});
+                                  (1 << 2) | (1 << 5), (int)ei, 0.0});
                 JointDef sj = joint(J_SPRING, body, eye_bodies[k]);
                 sj.p0 = 0; sj.p1 = 0.1; sj.p2 = 3e-3;
                 joints.push_back(sj);
@@ -184,7 +184,7 @@ int World::finalize(int max_steps, std::string &err) {
                 Vec2 rr = rot(rel, e.angle);
                 int fb = (int)bodies.size();
                 finger_body[k] = fb;
-                bodies.push_back({BODY_DYNAMIC, 1.0 / fm, 1.0 / fi, e.x + rr.x, e.y + rr.y, e.angle + delta, body, rel.x, rel.y, 0x1FF});
+                bodies.push_back({BODY_DYNAMIC, 1.0 / fm, 1.0 / fi, e.x + rr.x, e.y + rr.y, e.angle + delta, body, rel.x, rel.y, 0x1FF, (int)ei, delta});
                 JointDef pin = joint(J_PIN, body, fb);                     // :334-341
                 pin.ax = rel.x; pin.ay = rel.y; pin.bx = 0; pin.by = 0; pin.error_bias = 0.0;
                 pin.p0 = 0.0;   // anchors coincide at construction -> rest length exactly 0
@@ -277,7 +277,7 @@ int World::finalize(int max_steps, std::string &err) {
                 draw_outer = {pv_};
                 draw_inner = {regular_poly(ns, short_side)};
             }
-            bodies.push_back({BODY_DYNAMIC, 1.0 / mass, 1.0 / inertia, e.x, e.y, e.angle, -1, 0, 0, 0x1FF});
+            bodies.push_back({BODY_DYNAMIC, 1.0 / mass, 1.0 / inertia, e.x, e.y, e.angle, -1, 0, 0, 0x1FF, (int)ei, 0.0});
             if (circle) {
                 e.shapes.push_back((int)shapes.size());
                 shapes.push_back({SH_CIRCLE, body, size, 0.5, 0, (int)ei, {}});
@@ -394,7 +394,8 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
     const double dt = 1.0 / FPS / PHYS_STEPS;
     for (int b = 0; b < h.n_bodies; b++) {
         const BodyDef &B = bodies[b];
-        iw[o.body_type + b] = B.type; iw[o.body_parent + b] = B.parent;
+        iw[o.body_type + b] = B.type; iw[o.body_parent + b] = B.parent; iw[o.body_ent + b] = B.ent;
+        pw[o.p_body_aoff + b] = B.aoff;
         rw[o.body_minv + b] = B.m_inv; rw[o.body_iinv + b] = B.i_inv;
         rw[o.body_init + 3 * b] = B.x; rw[o.body_init + 3 * b + 1] = B.y; rw[o.body_init + 3 * b + 2] = B.a;
         rw[o.body_anchor + 2 * b] = B.ax; rw[o.body_anchor + 2 * b + 1] = B.ay;

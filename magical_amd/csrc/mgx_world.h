@@ -22,6 +22,8 @@ struct BodyDef {
     int parent;              // >= 0: position = parent pose applied to (ax, ay) at reset (finger roots)
     double ax, ay;
     int state_mask;          // bit c set: component c (x y a vx vy w vbx vby wb) is persistent state
+    int ent = -1;            // entity this body belongs to (-1: the static body)
+    double aoff = 0;         // body angle = entity angle + aoff at reset (finger roots: +-pi/8)
 };
 struct ShapeDef {
     int kind, body;

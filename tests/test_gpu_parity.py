@@ -341,6 +341,62 @@ def test_test_colour_variants_match_oracle(task, flag):
     env.close()
 
 
+def test_reset_with_per_env_entity_poses():
+    """mgx_engine_reset_poses: an env reset to entity poses P equals, bit for bit, an env whose world was BUILT at P
+    (every body of an entity follows it rigidly, finger roots re-derived as at construction) -- also after stepping
+    and rendering; passing the template's own poses changes nothing."""
+    import math
+    import torch
+    from magical_amd.benchmarks.move_to_corner import MoveToCornerEnv
+    from magical_amd.benchmarks.preproc import wrap_preproc
+    from magical_amd import entities as en
+    n = 5
+    rs = np.random.RandomState(9)
+    robot_pose = [(rs.uniform(-0.5, 0.5), rs.uniform(-0.5, 0.5), rs.uniform(-math.pi, math.pi)) for _ in range(n)]
+    shape_pose = [(rs.uniform(-0.7, -0.6), rs.uniform(0.6, 0.7), rs.uniform(-math.pi, math.pi)) for _ in range(n)]
+
+    class Jittered(MoveToCornerEnv):
+        def sample_variation(self, rng, k):
+            ents = self._entities
+            return {'poses': {ents[0]: robot_pose[k], ents[1]: shape_pose[k]}}
+
+    def built_at(k):
+        class Built(MoveToCornerEnv):
+            def on_reset(self):
+                robot = self._make_robot(np.asarray(robot_pose[k][:2]), robot_pose[k][2])
+                self.add_entities([robot])
+                shape = self._make_shape(shape_type=en.ShapeType.SQUARE, colour_name='red', init_pos=np.asarray(shape_pose[k][:2]),
+                                         init_angle=shape_pose[k][2])
+                self.add_entities([shape])
+                self._MoveToCornerEnv__shape_ref = shape
+        return wrap_preproc(Built, 'LoRes4E')(n_envs=1, device='cuda:0', max_episode_steps=80)
+
+    env = wrap_preproc(Jittered, 'LoRes4E')(n_envs=n, device='cuda:0', max_episode_steps=80)
+    obs = env.reset()
+    tape = _tape(43, 6, n)
+    refs = [built_at(k) for k in range(n)]
+    for k, r in enumerate(refs):
+        o = r.reset()
+        assert torch.equal(env.state_p[:, k], r.state_p[:, 0]) and torch.equal(obs[k], o[0]), k
+    for s in range(6):
+        obs, _, _, _ = env.step(tape[s])
+        for k, r in enumerate(refs):
+            o, _, _, _ = r.step(tape[s, k:k + 1])
+            assert torch.equal(env.state_p[:, k], r.state_p[:, 0]) and torch.equal(env.state_f[:, k], r.state_f[:, 0]), (s, k)
+            assert torch.equal(obs[k], o[0]), (s, k)
+    for r in refs:
+        r.close()
+    env.close()
+    # the template's own poses through the per-env path: identical to the plain reset
+    class Same(MoveToCornerEnv):
+        def sample_variation(self, rng, k):
+            return {'poses': {}}
+    a = Same(n_envs=3, device='cuda:0', max_episode_steps=80); b = MoveToCornerEnv(n_envs=3, device='cuda:0', max_episode_steps=80)
+    a.reset(); b.reset()
+    assert a._ent_pose is not None and torch.equal(a.state_p, b.state_p) and torch.equal(a.state_f, b.state_f)
+    a.close(); b.close()
+
+
 def test_lores4e_stack_and_autoreset():
     """FlattenFrameStack semantics on device: reset fills 4 copies, step shifts by one frame, auto-reset refills;
     compared with the oracle's LoRes4E pipeline for the first steps."""
