@@ -96,6 +96,10 @@ int mgx_world_entity_shapes(const mgx_world *w, int ent, int max_shapes, int *ki
 /* draw list: per primitive its template colour (r | g << 8 | b << 16), the entity whose colour paints it (-1: none) and
  * how (0 darkened, 1 base, 2 lightened twice: entities.py:712-757,807-819); returns the number of primitives */
 int mgx_world_prim_table(const mgx_world *w, int *rgb, int *ent, int *role);
+/* geom.py:116-262 pm_randomise_pose's rejection test, on the host: with entity e at poses[3e..3e+2] = (x, y, angle)
+ * (goals: their box centre), does entity `ent` touch the arena walls or a shape of an entity with enabled[e] != 0
+ * (space.shape_query of each of its shapes, i.e. cpCollide(...).count > 0, ShapeFilter groups honoured)?  1 / 0 */
+int mgx_world_placement_collides(const mgx_world *w, int ent, const double *poses, const uint8_t *enabled);
 /* style.py:28-37 evaluated to RGB8 for entity colour 0..3 (red green blue yellow) in `role` */
 int mgx_world_palette(int colour, int role);
 

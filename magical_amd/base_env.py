@@ -50,6 +50,14 @@ class BaseEnv(abc.ABC):
     SHAPE_RAD = ROBOT_RAD * 0.6
     ARENA_BOUNDS_LRBT = [-1, 1, -1, 1]
     ARENA_SIZE_MAX = max(ARENA_BOUNDS_LRBT)
+    # minor-jitter bounds of the Test*Jitter variants (base_env.py:68-76)
+    RAND_GOAL_MIN_SIZE = 0.5
+    RAND_GOAL_MAX_SIZE = 0.8
+    RAND_GOAL_SIZE_RANGE = RAND_GOAL_MAX_SIZE - RAND_GOAL_MIN_SIZE
+    JITTER_PCT = 0.05
+    JITTER_POS_BOUND = ARENA_SIZE_MAX * JITTER_PCT / 2.0
+    JITTER_ROT_BOUND = JITTER_PCT * np.pi
+    JITTER_TARGET_BOUND = JITTER_PCT * RAND_GOAL_SIZE_RANGE / 2
 
     def __init__(self, *, n_envs=1, device='cuda:0', res_hw=(384, 384), fps=8, phys_steps=10, phys_iter=10,
                  max_episode_steps=None, rand_dynamics=False, ego_view=True, allo_view=True,
@@ -176,8 +184,9 @@ class BaseEnv(abc.ABC):
         self._prim_rgb = None        # device int32[n_prims, N], allocated when an env first deviates from the template
         self._default_colours = np.array([en.COLOUR_ID[e.colour_name] if hasattr(e, 'colour_name') else -1 for e in self._entities], dtype=np.int64)
         self.entity_colours = np.tile(self._default_colours, (self.n_envs, 1))          # per env
-        # initial (x, y, angle) of every entity, per env (goal regions: their x, y and 0)
-        self._default_poses = np.array([[e.init_pos[0], e.init_pos[1], e.init_angle] if hasattr(e, 'init_pos') else [e.x, e.y, 0.0]
+        # initial (x, y, angle) of every entity's main body, per env
+        self._default_poses = np.array([[e.init_pos[0], e.init_pos[1], e.init_angle] if hasattr(e, 'init_pos')
+                                        else [e.x + e.w / 2, e.y - e.h / 2, 0.0]          # GoalRegion body: box centre (entities.py:794-797)
                                         for e in self._entities], dtype=np.float64)
         self.entity_poses = np.tile(self._default_poses, (self.n_envs, 1, 1))
         self._ent_pose = None        # device [n_entities * 3, N], allocated when an env first deviates from the template
@@ -249,6 +258,10 @@ class BaseEnv(abc.ABC):
         score needs per env).  Return None (Demo) or a dict; supported keys: 'colours' = {entity: colour name},
         'poses' = {entity: (x, y, angle)}."""
         return None
+
+    def default_entity_poses(self):
+        """float64[n_entities, 3] copy of the Demo layout, indexed like self._entities (= ent_id order)."""
+        return self._default_poses.copy()
 
     def _reset_envs(self, env_idx, mask_dev):
         """BaseEnv.reset() for the envs `env_idx` (device mask `mask_dev`, None = all): per-env draws first (env k from

@@ -4,21 +4,31 @@ import math
 import numpy as np
 
 from .. import entities as en
+from .. import geom
 from ..base_env import BaseEnv
 from ._scoring import row_norm
 
 
 class MoveToCornerEnv(BaseEnv):
     def __init__(self, rand_shape_colour=False, rand_shape_type=False, rand_poses=False, debug_reward=False, **kwargs):
-        if rand_shape_type or rand_poses or debug_reward:
-            raise NotImplementedError('built: Demo, TestColour, TestDynamics (shape types and poses need per-env geometry: SURVEY.md §8f)')
-        self.rand_shape_colour = rand_shape_colour
+        if rand_shape_type or debug_reward:
+            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestDynamics (shape types need per-env geometry: SURVEY.md §8f)')
+        self.rand_shape_colour, self.rand_poses = rand_shape_colour, rand_poses
         super().__init__(**kwargs)
 
-    def sample_variation(self, rng, k):   # move_to_corner.py:42-44
-        if not self.rand_shape_colour:
+    def sample_variation(self, rng, k):   # move_to_corner.py:42-63, in the reference's order: colour, then poses
+        if not (self.rand_shape_colour or self.rand_poses):
             return None
-        return {'colours': {self.__shape_ref: rng.choice(np.asarray(en.SHAPE_COLOURS, dtype='object'))}}
+        var = {}
+        if self.rand_shape_colour:
+            var['colours'] = {self.__shape_ref: rng.choice(np.asarray(en.SHAPE_COLOURS, dtype='object'))}
+        if self.rand_poses:
+            ents = (self._robot, self.__shape_ref)
+            poses = geom.pm_randomise_all_poses(self, self.default_entity_poses(), ents, self.ARENA_BOUNDS_LRBT, rng,
+                                                rand_pos=True, rand_rot=True, rel_pos_linf_limits=self.JITTER_POS_BOUND,
+                                                rel_rot_limits=self.JITTER_ROT_BOUND)
+            var['poses'] = {e: tuple(poses[e.ent_id]) for e in ents}
+        return var
 
     def on_reset(self):   # move_to_corner.py:31-54
         robot = self._make_robot(np.asarray((0.4, -0.0)), 0.55 * math.pi)

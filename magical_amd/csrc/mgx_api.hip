@@ -175,6 +175,11 @@ int mgx_world_prim_table(const mgx_world *w, int *rgb, int *ent, int *role) {
     }
     return n;
 }
+int mgx_world_placement_collides(const mgx_world *w, int ent, const double *poses, const uint8_t *enabled) {
+    if (!w || !w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
+    if (ent < 0 || ent >= (int)w->w.entities.size() || !poses || !enabled) return fail(MGX_ERR_ARG, "bad entity / NULL argument");
+    return w->w.placement_collides(ent, poses, enabled) ? 1 : 0;
+}
 int mgx_world_palette(int colour, int role) {
     if (colour < 0 || colour > 3 || role < 0 || role > 2) return fail(MGX_ERR_ARG, "colour 0..3, role 0..2");
     return palette_rgb(colour, role);

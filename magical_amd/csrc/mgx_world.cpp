@@ -109,6 +109,108 @@ int palette_rgb(int colour, int role) {
     return c.r | (c.g << 8) | (c.b << 16);
 }
 
+
+// ---------------------------------------------------------------- placement queries (host only)
+namespace {
+struct WShape { int kind; double r; std::vector<Vec2> v; int group; };   // world-space: circle centre / polygon verts / segment ends
+
+double pt_seg_dist2(Vec2 p, Vec2 a, Vec2 b) {
+    double dx = b.x - a.x, dy = b.y - a.y, l2 = dx * dx + dy * dy;
+    double t = l2 > 0 ? ((p.x - a.x) * dx + (p.y - a.y) * dy) / l2 : 0.0;
+    t = t < 0 ? 0 : (t > 1 ? 1 : t);
+    double qx = a.x + t * dx - p.x, qy = a.y + t * dy - p.y;
+    return qx * qx + qy * qy;
+}
+// signed distance of a point to a convex CCW polygon (negative inside)
+double pt_poly_dist(Vec2 p, const std::vector<Vec2> &v) {
+    bool inside = true; double best = 1e300; size_t n = v.size();
+    for (size_t i = 0; i < n; i++) {
+        Vec2 a = v[i], b = v[(i + 1) % n];
+        double cr = (b.x - a.x) * (p.y - a.y) - (b.y - a.y) * (p.x - a.x);
+        if (cr < 0) inside = false;
+        double d2 = pt_seg_dist2(p, a, b);
+        if (d2 < best) best = d2;
+    }
+    return inside ? -std::sqrt(best) : std::sqrt(best);
+}
+// distance between two convex CCW polygons: negative when they overlap, else the exact gap
+double poly_poly_dist(const std::vector<Vec2> &A, const std::vector<Vec2> &B) {
+    auto separated = [](const std::vector<Vec2> &P, const std::vector<Vec2> &Q) {
+        size_t n = P.size();
+        for (size_t i = 0; i < n; i++) {
+            Vec2 a = P[i], b = P[(i + 1) % n];
+            double nx = b.y - a.y, ny = -(b.x - a.x);                 // outward normal of a CCW polygon
+            bool all_out = true;
+            for (auto &q : Q) if ((q.x - a.x) * nx + (q.y - a.y) * ny <= 0) { all_out = false; break; }
+            if (all_out) return true;
+        }
+        return false;
+    };
+    if (!separated(A, B) && !separated(B, A)) return -1.0;
+    double best = 1e300;
+    for (auto &p : A) for (size_t i = 0; i < B.size(); i++) best = std::min(best, pt_seg_dist2(p, B[i], B[(i + 1) % B.size()]));
+    for (auto &p : B) for (size_t i = 0; i < A.size(); i++) best = std::min(best, pt_seg_dist2(p, A[i], A[(i + 1) % A.size()]));
+    return std::sqrt(best);
+}
+// cpCollide(a, b).count > 0 (cpCollision.c: CircleToCircle / CircleToSegment use distsq < mindist^2, the GJK cases d <= mindist)
+bool shapes_touch(const WShape &a, const WShape &b) {
+    if (a.kind > b.kind) return shapes_touch(b, a);
+    double rr = a.r + b.r;
+    if (a.kind == SH_CIRCLE && b.kind == SH_CIRCLE) {
+        double dx = b.v[0].x - a.v[0].x, dy = b.v[0].y - a.v[0].y;
+        return dx * dx + dy * dy < rr * rr;
+    }
+    if (a.kind == SH_CIRCLE && b.kind == SH_SEGMENT) return pt_seg_dist2(a.v[0], b.v[0], b.v[1]) < rr * rr;
+    if (a.kind == SH_CIRCLE && b.kind == SH_POLY) return pt_poly_dist(a.v[0], b.v) <= rr;
+    if (a.kind == SH_SEGMENT && b.kind == SH_POLY) {
+        double best = 1e300;
+        for (auto &p : b.v) best = std::min(best, pt_seg_dist2(p, a.v[0], a.v[1]));
+        for (int k = 0; k < 2; k++) { double d = pt_poly_dist(a.v[k], b.v); if (d <= 0) return true; best = std::min(best, d * d); }
+        return std::sqrt(best) - rr <= 0.0;
+    }
+    if (a.kind == SH_POLY && b.kind == SH_POLY) return poly_poly_dist(a.v, b.v) - rr <= 0.0;
+    return false;   // segment-segment: both static
+}
+}  // namespace
+
+bool World::placement_collides(int ent, const double *poses, const uint8_t *enabled) const {
+    // world-space shapes of entity e at its pose (bodies follow the entity rigidly, as in finalize())
+    auto shapes_of = [&](int e, std::vector<WShape> &out) {
+        const EntityDef &E = entities[e];
+        double x = poses[3 * e], y = poses[3 * e + 1], a = poses[3 * e + 2];
+        if (E.kind == 2) {                      // goal sensor: box (w, h) around its centre, never rotated
+            double hw = E.w / 2, hh = E.h / 2;
+            out.push_back({SH_POLY, 0.0, {{x - hw, y - hh}, {x + hw, y - hh}, {x + hw, y + hh}, {x - hw, y + hh}}, 0});
+            return;
+        }
+        for (const ShapeDef &S : shapes) {
+            if (S.entity != e) continue;
+            const BodyDef &B = bodies[S.body];
+            double bx = x, by = y, ba = a + B.aoff;
+            if (B.parent >= 0) { Vec2 r = rot({B.ax, B.ay}, a + bodies[B.parent].aoff); bx = x + r.x; by = y + r.y; }
+            WShape W{S.kind, S.radius, {}, S.group};
+            if (S.kind == SH_CIRCLE) W.v.push_back({bx, by});
+            else for (auto &lv : S.verts) { Vec2 r = rot(lv, ba); W.v.push_back({bx + r.x, by + r.y}); }
+            out.push_back(W);
+        }
+    };
+    std::vector<WShape> mine;
+    shapes_of(ent, mine);
+    std::vector<WShape> walls;
+    for (const ShapeDef &S : shapes) if (S.kind == SH_SEGMENT) walls.push_back({SH_SEGMENT, S.radius, S.verts, 0});
+    for (auto &m : mine) for (auto &wl : walls) if (shapes_touch(m, wl)) return true;
+    for (int e = 0; e < (int)entities.size(); e++) {
+        if (e == ent || !enabled[e]) continue;
+        std::vector<WShape> theirs;
+        shapes_of(e, theirs);
+        for (auto &m : mine) for (auto &t : theirs) {
+            if (m.group != 0 && m.group == t.group) continue;       // ShapeFilter groups (cpShapeFilterReject)
+            if (shapes_touch(m, t)) return true;
+        }
+    }
+    return false;
+}
+
 int World::finalize(int max_steps, std::string &err) {
     if (finalized) { err = "world already finalized"; return -3; }
     max_episode_steps = max_steps;

@@ -75,6 +75,10 @@ struct World {
     std::vector<int> island_j;         // first joint (pivot) of every block's {pivot, gear} pair
 
     int finalize(int max_steps, std::string &err);
+    // geom.py:116-262 pm_randomise_pose's collision test, on the host: would entity `ent`, with every entity at
+    // poses[3 * e .. 3 * e + 2] (x, y, angle; goals: their box centre), touch the arena walls or a shape of an entity
+    // whose `enabled` flag is set?  (space.shape_query of each of its shapes: Chipmunk's cpCollide count > 0)
+    bool placement_collides(int ent, const double *poses, const uint8_t *enabled) const;
     // serialise: header + int words + real words (as double; caller narrows to float if needed)
     void serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<double> &rw, std::vector<double> &pw) const;
 };

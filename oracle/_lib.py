@@ -64,6 +64,7 @@ def lib():
         'ref_get_joint_acc': (None, [_P, _DP]),
         'ref_get_contacts': (_I, [_P, _DP, _I]),
         'ref_collide_shapes': (_I, [_P, _I, _I, _DP]),
+        'ref_shape_info': (None, [_P, _I, C.POINTER(C.c_int)]),
         'ref_shape_world': (_I, [_P, _I, _DP, _DP, C.POINTER(C.c_int)]),
         'ref_episode_steps': (_I, [_P]),
         'ref_render': (None, [_P, _I, _I, C.c_void_p]),

@@ -38,6 +38,13 @@ class RefEnv:
         self.L.ref_set_gjk_warm(self.world.h, 1 if self.gjk_warm else 0)
         self.arena = self.world.add(ArenaBoundaries())
         self.task = self.task_cls(self.world, rng=self.rng, **self.task_flags)
+        if 'poses' in self.task.choices:
+            # poses were drawn on that world; the episode runs in a fresh one built at them (placement_ref.py)
+            choices = self.task.choices
+            self.world = RefWorld(phys_vars=pv, phys_iter=PHYS_ITER)
+            self.L.ref_set_gjk_warm(self.world.h, 1 if self.gjk_warm else 0)
+            self.arena = self.world.add(ArenaBoundaries())
+            self.task = self.task_cls(self.world, rng=None, replay=choices, **self.task_flags)
         self._episode_steps = 0
         return None
 

@@ -919,6 +919,8 @@ void ref_step(World *w, int action, double fps) {
 
 int ref_nbodies(const World *w) { return w->nbodies; }
 int ref_nshapes(const World *w) { return w->nshapes; }
+/* body, ShapeFilter group and sensor flag of shape s (placement queries, geom.py:116-262) */
+void ref_shape_info(const World *w, int s, int *out) { out[0] = w->shapes[s].body; out[1] = w->shapes[s].group; out[2] = w->shapes[s].sensor; }
 int ref_njoints(const World *w) { return w->njoints; }
 int ref_narbiters(const World *w) { return w->norder; }
 /* out[nbodies][9] = x y a vx vy w vbx vby wb */

@@ -15,6 +15,9 @@ from .entities_ref import SHAPE_COLOURS, GoalRegion, Robot, Shape
 ROBOT_RAD = 0.2          # base_env.py:62
 ROBOT_MASS = 1.0         # base_env.py:63
 SHAPE_RAD = ROBOT_RAD * 0.6   # base_env.py:64
+JITTER_PCT = 0.05             # base_env.py:73-75
+JITTER_POS_BOUND = 1 * JITTER_PCT / 2.0
+JITTER_ROT_BOUND = JITTER_PCT * np.pi
 
 
 def _robot(pos, angle):
@@ -30,11 +33,25 @@ class TaskRef:
     name = None
     ep_len = None
 
-    def __init__(self, world, rng=None, **flags):
+    def __init__(self, world, rng=None, replay=None, **flags):
         self.world = world
         self.rng = rng                 # the env's np.random.RandomState (base_env.py:133-140)
         self.flags = flags             # rand_* keyword arguments of the reference constructor that are True
+        self.choices = {}              # every random choice of this reset, by name ...
+        self.replay = replay           # ... or the choices to rebuild the same world from, without touching the rng
         self.on_reset()
+
+    def draw(self, name, fn):
+        if self.replay is not None:
+            return self.replay[name]
+        self.choices[name] = v = fn()
+        return v
+
+    def jitter(self, entities, **kw):
+        """pm_randomise_all_poses on this (scratch) world; the env then rebuilds the world AT the drawn poses
+        (placement_ref.py explains why)."""
+        from .placement_ref import randomise_all_poses
+        return self.draw('poses', lambda: randomise_all_poses(self.world, entities, [-1, 1, -1, 1], self.rng, **kw))
 
     def block_pos(self, ent):
         return self.world_pose(ent.shape_body)[:2]
@@ -54,11 +71,16 @@ class MoveToCornerRef(TaskRef):
 
     def on_reset(self):
         w = self.world
-        self.robot = w.add(_robot((0.4, -0.0), 0.55 * math.pi))
+        robot_pose, shape_pose = (0.4, -0.0, 0.55 * math.pi), (0.1, -0.65, 0.13 * math.pi)
+        if self.replay is not None and 'poses' in self.replay:
+            robot_pose, shape_pose = self.replay['poses']
+        self.robot = w.add(_robot(robot_pose[:2], robot_pose[2]))
         shape_colour = 'red'
         if self.flags.get('rand_shape_colour'):          # move_to_corner.py:42-44
-            shape_colour = self.rng.choice(np.asarray(SHAPE_COLOURS, dtype='object'))
-        self.shape = w.add(_shape('square', shape_colour, (0.1, -0.65), 0.13 * math.pi))
+            shape_colour = self.draw('colour', lambda: self.rng.choice(np.asarray(SHAPE_COLOURS, dtype='object')))
+        self.shape = w.add(_shape('square', shape_colour, shape_pose[:2], shape_pose[2]))
+        if self.flags.get('rand_poses') and self.replay is None:    # move_to_corner.py:56-63
+            self.jitter([self.robot, self.shape], rel_pos_linf_limits=JITTER_POS_BOUND, rel_rot_limits=JITTER_ROT_BOUND)
 
     def score_on_end_of_traj(self):
         robot_pos = np.asarray(self.block_pos(self.shape))

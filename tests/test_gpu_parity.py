@@ -397,6 +397,48 @@ def test_reset_with_per_env_entity_poses():
     a.close(); b.close()
 
 
+JITTER_CASES = [('MoveToCorner', 'TestJitter', {'rand_poses': True})]
+
+
+@pytest.mark.parametrize('task,variant,flags', JITTER_CASES)
+def test_pose_randomisation_matches_oracle(task, variant, flags):
+    """Test*Jitter / TestLayout: every env draws its entity poses from its own stream with the reference's rejection
+    sampling (geom.py:116-341: product = host sampler over mgx_world_placement_collides, oracle = the same procedure
+    over its GJK/EPA narrowphase).  Same draws -> identical initial poses and first observations; the fp64 engine
+    then tracks the oracle; the second episode draws again."""
+    from oracle.env_ref import LoRes4ERef, RefEnv
+    n, ep, seed = 6, 3, 321
+    env = _make(f'{task}-{variant}-LoRes4E-v0', n, dtype='f64', max_episode_steps=ep)
+    env.seed(seed)
+    obs = env.reset().cpu().numpy()
+    refs = [LoRes4ERef(RefEnv(task, max_episode_steps=ep, seed=seed + k, **flags)) for k in range(n)]
+    first = [r.reset() for r in refs]
+    idx = ref_body_index(refs[0].env)
+    mask = comparable_mask(refs[0].env)
+    def check_reset(obs_now, firsts):
+        got = env.get_bodies()
+        for k, r in enumerate(refs):
+            want = r.env.bodies()[idx][:, :3]
+            err = np.abs(got[k, 1:, :3] - want)[mask[:, :3]].max()
+            assert err < 1e-12, (task, k, err)                      # same draws: the poses agree to rounding
+            assert np.array_equal(obs_now[k], firsts[k]), (task, k)
+        assert np.abs(got[:, 1, :2] - got[0, 1, :2]).max() > 1e-3   # and they differ between envs
+    check_reset(obs, first)
+    tape = _tape(47, 2 * ep, n)
+    for s in range(2 * ep):
+        obs, _, done, _ = env.step(tape[s])
+        obs = obs.cpu().numpy()
+        outs = [r.step(tape[s, k]) for k, r in enumerate(refs)]
+        if done.all():
+            check_reset(obs, [r.reset() for r in refs])
+            continue
+        got = env.get_bodies()
+        for k, r in enumerate(refs):
+            err = np.abs(got[k, 1:, :3] - r.env.bodies()[idx][:, :3])[mask[:, :3]].max()
+            assert err < (1e-8 if s % ep == 0 else 5e-3), (task, s, k, err)
+    env.close()
+
+
 def test_lores4e_stack_and_autoreset():
     """FlattenFrameStack semantics on device: reset fills 4 copies, step shifts by one frame, auto-reset refills;
     compared with the oracle's LoRes4E pipeline for the first steps."""
