@@ -1,10 +1,11 @@
-"""ClusterColour / ClusterShape (mirror of magical/benchmarks/cluster.py: Demo, TestColour and TestDynamics branches)."""
+"""ClusterColour / ClusterShape (mirror of magical/benchmarks/cluster.py: Demo, TestColour, TestJitter, TestLayout and TestDynamics branches)."""
 import abc
 import enum
 
 import numpy as np
 
 from .. import entities as en
+from .. import geom
 from ..base_env import BaseEnv
 
 
@@ -15,27 +16,39 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
 
     def __init__(self, rand_shape_colour=False, rand_shape_type=False, rand_layout_minor=False, rand_layout_full=False,
                  rand_shape_count=False, cluster_by=ClusterBy.COLOUR, **kwargs):
-        if rand_shape_type or rand_layout_minor or rand_layout_full or rand_shape_count:
-            raise NotImplementedError('built: Demo, TestColour, TestDynamics (shape types / counts / layouts need per-env geometry: SURVEY.md §8f)')
+        if rand_shape_type or rand_shape_count:
+            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestLayout, TestDynamics (shape types / counts need per-env geometry: SURVEY.md §8f)')
+        assert not (rand_layout_minor and rand_layout_full)
+        self.rand_layout_minor, self.rand_layout_full = rand_layout_minor, rand_layout_full
         self.cluster_by = cluster_by
         self.rand_shape_colour = rand_shape_colour
         self._class_env = None
         super().__init__(**kwargs)
 
-    def sample_variation(self, rng, k):   # cluster.py:91-100: at least one block of each colour, the rest drawn, then shuffled
-        if not self.rand_shape_colour:
+    def sample_variation(self, rng, k):   # cluster.py:91-100 (colours), :148-161 (poses: robot first, then the blocks)
+        if not (self.rand_shape_colour or self.rand_layout_minor or self.rand_layout_full):
             return None
-        names = en.SHAPE_COLOUR_NAMES
-        colours = list(names)
-        colours.extend([rng.choice(names) for _ in range(len(self.__shape_ents) - len(colours))])
-        rng.shuffle(colours)
-        if self.cluster_by == self.ClusterBy.COLOUR:
-            # class of a block = rank of its colour among the colours present (np.unique sorts them; all four are present)
-            if self._class_env is None:
-                self._class_env = np.tile(self.__class_of_block, (self.n_envs, 1))
-            order = {c: i for i, c in enumerate(sorted(set(colours)))}
-            self._class_env[k] = [order[c] for c in colours]
-        return {'colours': dict(zip(self.__shape_ents, colours))}
+        var = {}
+        if self.rand_shape_colour:
+            # at least one block of each colour, the rest drawn, then shuffled
+            names = en.SHAPE_COLOUR_NAMES
+            colours = list(names)
+            colours.extend([rng.choice(names) for _ in range(len(self.__shape_ents) - len(colours))])
+            rng.shuffle(colours)
+            if self.cluster_by == self.ClusterBy.COLOUR:
+                # class of a block = rank of its colour among the colours present (np.unique sorts them; all four are present)
+                if self._class_env is None:
+                    self._class_env = np.tile(self.__class_of_block, (self.n_envs, 1))
+                order = {c: i for i, c in enumerate(sorted(set(colours)))}
+                self._class_env[k] = [order[c] for c in colours]
+            var['colours'] = dict(zip(self.__shape_ents, colours))
+        if self.rand_layout_minor or self.rand_layout_full:
+            all_ents = [self._robot, *self.__shape_ents]
+            pos_limit, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if self.rand_layout_minor else (None, None)
+            poses = geom.pm_randomise_all_poses(self, self.default_entity_poses(), all_ents, self.ARENA_BOUNDS_LRBT, rng,
+                                                rand_pos=True, rand_rot=True, rel_pos_linf_limits=pos_limit, rel_rot_limits=rot_limit)
+            var['poses'] = {e: tuple(poses[e.ent_id]) for e in all_ents}
+        return var
 
     def on_reset(self):   # cluster.py:67-164
         robot = self._make_robot(*self.DEFAULT_ROBOT_POSE)

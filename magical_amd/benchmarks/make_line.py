@@ -1,7 +1,8 @@
-"""MakeLine (mirror of magical/benchmarks/make_line.py: Demo, TestColour and TestDynamics branches)."""
+"""MakeLine (mirror of magical/benchmarks/make_line.py: Demo, TestColour, TestJitter, TestLayout and TestDynamics branches)."""
 import numpy as np
 
 from .. import entities as en
+from .. import geom
 from ..base_env import BaseEnv
 from ._scoring import row_norm
 
@@ -43,9 +44,10 @@ def longest_line(points, inlier_dist, max_separation):
 class MakeLineEnv(BaseEnv):
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
-        if rand_shapes or rand_count or rand_layout_minor or rand_layout_full:
-            raise NotImplementedError('built: Demo, TestColour, TestDynamics (shape types / counts / layouts need per-env geometry: SURVEY.md §8f)')
-        self.rand_colours = rand_colours
+        if rand_shapes or rand_count:
+            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestLayout, TestDynamics (shape types / counts need per-env geometry: SURVEY.md §8f)')
+        assert not (rand_layout_minor and rand_layout_full)
+        self.rand_colours, self.rand_layout_minor, self.rand_layout_full = rand_colours, rand_layout_minor, rand_layout_full
         super().__init__(**kwargs)
         self.inlier_dist = self.SHAPE_RAD * INLIER_RAD_MULT
         self.max_sep = self.SHAPE_RAD * MAX_SEP_RADS
@@ -57,11 +59,20 @@ class MakeLineEnv(BaseEnv):
         self.add_entities(self._blocks)
         self.add_entities([robot])
 
-    def sample_variation(self, rng, k):   # make_line.py:105-107
-        if not self.rand_colours:
+    def sample_variation(self, rng, k):   # make_line.py:105-107 (colours), :124-139 (poses: robot first, then the blocks)
+        if not (self.rand_colours or self.rand_layout_minor or self.rand_layout_full):
             return None
-        block_colours = rng.choice(en.SHAPE_COLOUR_NAMES, size=len(self._blocks)).tolist()
-        return {'colours': dict(zip(self._blocks, block_colours))}
+        var = {}
+        if self.rand_colours:
+            block_colours = rng.choice(en.SHAPE_COLOUR_NAMES, size=len(self._blocks)).tolist()
+            var['colours'] = dict(zip(self._blocks, block_colours))
+        if self.rand_layout_minor or self.rand_layout_full:
+            all_ents = (self._robot, *self._blocks)
+            pos_limits, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if self.rand_layout_minor else (None, None)
+            poses = geom.pm_randomise_all_poses(self, self.default_entity_poses(), all_ents, self.ARENA_BOUNDS_LRBT, rng,
+                                                rand_pos=True, rand_rot=True, rel_pos_linf_limits=pos_limits, rel_rot_limits=rot_limit)
+            var['poses'] = {e: tuple(poses[e.ent_id]) for e in all_ents}
+        return var
 
     def score_on_end_of_traj(self, poses):   # make_line.py:142-152
         bodies = [b.body for b in self._blocks]

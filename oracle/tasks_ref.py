@@ -188,12 +188,19 @@ class MakeLineRef(TaskRef):
         robot = _robot((0.702, -0.255), 0.347)
         colours = ['blue', 'yellow', 'red', 'green']
         if self.flags.get('rand_colours'):                # make_line.py:105-107
-            colours = self.rng.choice(SHAPE_COLOURS, size=4).tolist()
+            colours = self.draw('colours', lambda: self.rng.choice(SHAPE_COLOURS, size=4).tolist())
         shapes = ['star', 'circle', 'star', 'pentagon']
         poses = [((0.790, -0.820), -0.721), ((-0.177, 0.383), -1.733),
                  ((-0.051, -0.128), 2.696), ((-0.292, -0.745), -0.159)]
+        if self.replay is not None and 'poses' in self.replay:
+            (rx, ry, ra), *bp = self.replay['poses']
+            robot = _robot((rx, ry), ra)
+            poses = [((x, y), a) for x, y, a in bp]
         self.blocks = [w.add(_shape(s, c, p, a)) for s, c, (p, a) in zip(shapes, colours, poses)]
         self.robot = w.add(robot)
+        if (self.flags.get('rand_layout_minor') or self.flags.get('rand_layout_full')) and self.replay is None:   # make_line.py:124-139
+            lim = dict(rel_pos_linf_limits=JITTER_POS_BOUND, rel_rot_limits=JITTER_ROT_BOUND) if self.flags.get('rand_layout_minor') else {}
+            self.jitter([self.robot, *self.blocks], **lim)
 
     def score_on_end_of_traj(self):
         points = np.asarray([self.block_pos(b) for b in self.blocks], dtype='float64')
@@ -294,17 +301,28 @@ class _ClusterRef(TaskRef):
         robot = _robot(*self.ROBOT_POSE)
         colours = self.COLOURS
         if self.flags.get('rand_shape_colour'):          # cluster.py:91-100
-            colours = list(SHAPE_COLOURS)
-            colours.extend([self.rng.choice(SHAPE_COLOURS) for _ in range(len(self.POSES) - len(colours))])
-            self.rng.shuffle(colours)
+            def draw_colours():
+                cs = list(SHAPE_COLOURS)
+                cs.extend([self.rng.choice(SHAPE_COLOURS) for _ in range(len(self.POSES) - len(cs))])
+                self.rng.shuffle(cs)
+                return cs
+            colours = self.draw('colours', draw_colours)
+        poses = self.POSES
+        if self.replay is not None and 'poses' in self.replay:
+            (rx, ry, ra), *bp = self.replay['poses']
+            robot = _robot((rx, ry), ra)
+            poses = [((x, y), a) for x, y, a in bp]
         self.shape_ents = [w.add(_shape(s, c, p, a))
-                           for (p, a), c, s in zip(self.POSES, colours, self.SHAPES)]
+                           for (p, a), c, s in zip(poses, colours, self.SHAPES)]
         c_values_list = np.asarray(colours if self.by == 'colour' else self.SHAPES, dtype='object')
         self.characteristic_values = np.unique(c_values_list)
         self.blocks_by_characteristic = {}
         for shape, c_value in zip(self.shape_ents, c_values_list):
             self.blocks_by_characteristic.setdefault(c_value, []).append(shape)
         self.robot = w.add(robot)
+        if (self.flags.get('rand_layout_minor') or self.flags.get('rand_layout_full')) and self.replay is None:   # cluster.py:148-161
+            lim = dict(rel_pos_linf_limits=JITTER_POS_BOUND, rel_rot_limits=JITTER_ROT_BOUND) if self.flags.get('rand_layout_minor') else {}
+            self.jitter([self.robot, *self.shape_ents], **lim)
 
     def score_on_end_of_traj(self):
         nvals = len(self.characteristic_values)

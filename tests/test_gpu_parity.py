@@ -397,7 +397,9 @@ def test_reset_with_per_env_entity_poses():
     a.close(); b.close()
 
 
-JITTER_CASES = [('MoveToCorner', 'TestJitter', {'rand_poses': True})]
+JITTER_CASES = [('MoveToCorner', 'TestJitter', {'rand_poses': True}),
+                ('MakeLine', 'TestJitter', {'rand_layout_minor': True}), ('MakeLine', 'TestLayout', {'rand_layout_full': True}),
+                ('ClusterColour', 'TestJitter', {'rand_layout_minor': True}), ('ClusterShape', 'TestLayout', {'rand_layout_full': True})]
 
 
 @pytest.mark.parametrize('task,variant,flags', JITTER_CASES)
