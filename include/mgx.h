@@ -100,6 +100,19 @@ int mgx_world_prim_table(const mgx_world *w, int *rgb, int *ent, int *role);
  * (goals: their box centre), does entity `ent` touch the arena walls or a shape of an entity with enabled[e] != 0
  * (space.shape_query of each of its shapes, i.e. cpCollide(...).count > 0, ShapeFilter groups honoured)?  1 / 0 */
 int mgx_world_placement_collides(const mgx_world *w, int ent, const double *poses, const uint8_t *enabled);
+/* geom.py:285-341 pm_randomise_all_poses for the entities ents[0..n) of ONE env, natively: poses [n_entities][3] in/out;
+ * ignore[n_entities] (or NULL); per listed entity rand_pos / rand_rot flags and position / rotation limits (< 0: none).
+ * The draws come from the np.random.RandomState stream handed over as its MT19937 state (key[624], pos) and are the
+ * ones RandomState.uniform would make (x, y, angle per attempt); the state is advanced in place.  Returns the number
+ * of rejected attempts, or MGX_ERR_CAPACITY when placement fails 10 times over */
+int mgx_world_randomise_all_poses(const mgx_world *w, double *poses, const int *ents, int n, const uint8_t *ignore,
+                                  const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
+                                  const double *pos_limits, const double *rot_limits, uint32_t *mt_key, int *mt_pos);
+/* the same for m envs in one call: poses [m][n_entities][3]; mt_state_addr[k] = address of env k's live numpy
+ * mt19937_state { uint32 key[624]; int pos; } (RandomState._bit_generator.ctypes.state_address), advanced in place */
+int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses, const int *ents, int n, const uint8_t *ignore,
+                                        const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
+                                        const double *pos_limits, const double *rot_limits, const uint64_t *mt_state_addr);
 /* style.py:28-37 evaluated to RGB8 for entity colour 0..3 (red green blue yellow) in `role` */
 int mgx_world_palette(int colour, int role);
 

@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-Wno-unused-parameter', '-o', LIB_PATH] + [os.path.join(_CSRC, f) for f in _SOURCES]
+           '-Wno-unused-parameter', '-pthread', '-o', LIB_PATH] + [os.path.join(_CSRC, f) for f in _SOURCES]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)
@@ -80,7 +80,11 @@ def lib():
         'mgx_world_entity_shapes': [vp, i32, i32, ip, dp, ip, dp, i32],
         'mgx_world_prim_table': [vp, ip, ip, ip],
         'mgx_world_palette': [i32, i32],
+        'mgx_world_randomise_all_poses_batch': [vp, i32, dp, ip, i32, C.POINTER(C.c_uint8), dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8),
+                                                dp, dp, C.POINTER(C.c_uint64)],
         'mgx_world_placement_collides': [vp, i32, dp, C.POINTER(C.c_uint8)],
+        'mgx_world_randomise_all_poses': [vp, dp, ip, i32, C.POINTER(C.c_uint8), dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), dp, dp,
+                                          C.POINTER(C.c_uint32), ip],
         'mgx_engine_set_prim_colours': [vp, vp],
         'mgx_engine_create': [vp, i32, i32, i32, i32, C.POINTER(vp)],
         'mgx_engine_state_shape': [vp, ip, ip, ip, ip, ip],
@@ -117,7 +121,7 @@ EXPORTED_SYMBOLS = [
     'mgx_last_error', 'mgx_version', 'mgx_world_create', 'mgx_world_destroy', 'mgx_world_set_phys_vars',
     'mgx_world_add_robot', 'mgx_world_add_shape', 'mgx_world_add_goal', 'mgx_world_finalize', 'mgx_world_info',
     'mgx_world_entity', 'mgx_world_body_table', 'mgx_world_n_state_entries', 'mgx_world_state_entry',
-    'mgx_world_goal_bb', 'mgx_world_entity_shapes', 'mgx_world_prim_table', 'mgx_world_palette', 'mgx_world_placement_collides',
+    'mgx_world_goal_bb', 'mgx_world_entity_shapes', 'mgx_world_prim_table', 'mgx_world_palette', 'mgx_world_placement_collides', 'mgx_world_randomise_all_poses', 'mgx_world_randomise_all_poses_batch',
     'mgx_engine_create', 'mgx_engine_destroy', 'mgx_engine_set_prim_colours',
     'mgx_engine_state_shape', 'mgx_engine_lanes_per_env', 'mgx_engine_lds_bytes', 'mgx_engine_reset', 'mgx_engine_reset_poses',
     'mgx_engine_step', 'mgx_engine_substeps', 'mgx_engine_render', 'mgx_engine_render_native',

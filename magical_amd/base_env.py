@@ -256,7 +256,9 @@ class BaseEnv(abc.ABC):
         """Task hook: draw this episode's random choices from `rng` with the same calls, in the same order, as the
         reference's on_reset() (after the physics variables, base_env.py:198-214), for env `k` (tasks keep what their
         score needs per env).  Return None (Demo) or a dict; supported keys: 'colours' = {entity: colour name},
-        'poses' = {entity: (x, y, angle)}."""
+        'poses' = {entity: (x, y, angle)}, 'randomise_poses' = (entities, kwargs of geom.pm_randomise_all_poses) -- the
+        pose draws must come last in the reference's on_reset (they do in every task), because they are made after this
+        hook returns, for all envs in one native call."""
         return None
 
     def default_entity_poses(self):
@@ -268,7 +270,7 @@ class BaseEnv(abc.ABC):
         its own stream self.rngs[k], in the reference's order: physics variables, then the task's on_reset choices), then
         the reset kernel -- with the drawn entity poses if any -- then the drawn force limits and colours."""
         import torch
-        pvs, colour_rows, pose_rows = [], [], []
+        pvs, colour_rows, pose_rows, pose_spec = [], [], [], None
         for k in env_idx:
             rng = self.rngs[k]
             if self.rand_dynamics:
@@ -284,6 +286,15 @@ class BaseEnv(abc.ABC):
                 for ent, pose in var['poses'].items():
                     row[self._entities.index(ent)] = pose
                 pose_rows.append(row)
+            if var is not None and 'randomise_poses' in var:
+                pose_spec = var['randomise_poses']       # the same for every env of a task: one native call below
+        if pose_spec is not None:
+            # geom.py pm_randomise_all_poses for all envs being reset, each on its own stream, natively
+            from . import geom
+            ents, kwargs = pose_spec
+            batch = np.ascontiguousarray(np.tile(self._default_poses, (len(env_idx), 1, 1)))
+            geom.pm_randomise_all_poses_batch(self, batch, ents, self.ARENA_BOUNDS_LRBT, [self.rngs[k] for k in env_idx], **kwargs)
+            pose_rows = list(batch)
         sp, sf, si = self.state_p.data_ptr(), self.state_f.data_ptr(), self.state_i.data_ptr()
         mask = None if mask_dev is None else mask_dev.data_ptr()
         if pose_rows:

@@ -5,7 +5,6 @@ import enum
 import numpy as np
 
 from .. import entities as en
-from .. import geom
 from ..base_env import BaseEnv
 
 
@@ -45,9 +44,7 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
         if self.rand_layout_minor or self.rand_layout_full:
             all_ents = [self._robot, *self.__shape_ents]
             pos_limit, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if self.rand_layout_minor else (None, None)
-            poses = geom.pm_randomise_all_poses(self, self.default_entity_poses(), all_ents, self.ARENA_BOUNDS_LRBT, rng,
-                                                rand_pos=True, rand_rot=True, rel_pos_linf_limits=pos_limit, rel_rot_limits=rot_limit)
-            var['poses'] = {e: tuple(poses[e.ent_id]) for e in all_ents}
+            var['randomise_poses'] = (all_ents, dict(rand_pos=True, rand_rot=True, rel_pos_linf_limits=pos_limit, rel_rot_limits=rot_limit))
         return var
 
     def on_reset(self):   # cluster.py:67-164

@@ -4,7 +4,6 @@ import math
 import numpy as np
 
 from .. import entities as en
-from .. import geom
 from ..base_env import BaseEnv
 from ._scoring import row_norm
 
@@ -23,11 +22,8 @@ class MoveToCornerEnv(BaseEnv):
         if self.rand_shape_colour:
             var['colours'] = {self.__shape_ref: rng.choice(np.asarray(en.SHAPE_COLOURS, dtype='object'))}
         if self.rand_poses:
-            ents = (self._robot, self.__shape_ref)
-            poses = geom.pm_randomise_all_poses(self, self.default_entity_poses(), ents, self.ARENA_BOUNDS_LRBT, rng,
-                                                rand_pos=True, rand_rot=True, rel_pos_linf_limits=self.JITTER_POS_BOUND,
-                                                rel_rot_limits=self.JITTER_ROT_BOUND)
-            var['poses'] = {e: tuple(poses[e.ent_id]) for e in ents}
+            var['randomise_poses'] = ((self._robot, self.__shape_ref), dict(
+                rand_pos=True, rand_rot=True, rel_pos_linf_limits=self.JITTER_POS_BOUND, rel_rot_limits=self.JITTER_ROT_BOUND))
         return var
 
     def on_reset(self):   # move_to_corner.py:31-54

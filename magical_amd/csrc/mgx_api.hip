@@ -2,6 +2,7 @@
 // kernel launches.  Device state blobs and output tensors are owned by the caller (PyTorch);
 // the engine owns only its small constant template buffers and timing events.
 #include <hip/hip_runtime.h>
+#include <thread>
 #include <type_traits>
 
 #include <cstdio>
@@ -179,6 +180,57 @@ int mgx_world_placement_collides(const mgx_world *w, int ent, const double *pose
     if (!w || !w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
     if (ent < 0 || ent >= (int)w->w.entities.size() || !poses || !enabled) return fail(MGX_ERR_ARG, "bad entity / NULL argument");
     return w->w.placement_collides(ent, poses, enabled) ? 1 : 0;
+}
+int mgx_world_randomise_all_poses(const mgx_world *w, double *poses, const int *ents, int n, const uint8_t *ignore,
+                                  const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
+                                  const double *pos_limits, const double *rot_limits, uint32_t *mt_key, int *mt_pos) {
+    if (!w || !w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
+    if (!poses || !ents || n < 1 || !arena_lrbt || !rand_pos || !rand_rot || !pos_limits || !rot_limits || !mt_key || !mt_pos)
+        return fail(MGX_ERR_ARG, "NULL argument");
+    if (*mt_pos < 0 || *mt_pos > 624) return fail(MGX_ERR_ARG, "bad MT19937 position");
+    for (int i = 0; i < n; i++) if (ents[i] < 0 || ents[i] >= (int)w->w.entities.size()) return fail(MGX_ERR_ARG, "entity index out of range");
+    int rc = w->w.randomise_all_poses(poses, ents, n, ignore, arena_lrbt, rand_pos, rand_rot, pos_limits, rot_limits, mt_key, mt_pos);
+    if (rc < 0) return fail(MGX_ERR_CAPACITY, "could not place the entities (PlacementError after 10 retries)");
+    return rc;
+}
+int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses, const int *ents, int n, const uint8_t *ignore,
+                                        const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
+                                        const double *pos_limits, const double *rot_limits, const uint64_t *mt_state_addr) {
+    if (!w || !w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
+    if (m < 0 || !poses || !ents || n < 1 || !arena_lrbt || !rand_pos || !rand_rot || !pos_limits || !rot_limits || !mt_state_addr)
+        return fail(MGX_ERR_ARG, "NULL argument");
+    const int ne = (int)w->w.entities.size();
+    for (int i = 0; i < n; i++) if (ents[i] < 0 || ents[i] >= ne) return fail(MGX_ERR_ARG, "entity index out of range");
+    // envs are independent (own stream, own poses): spread them over a few host threads
+    int n_threads = (int)std::thread::hardware_concurrency();
+    n_threads = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
+    if (m < 64) n_threads = 1;
+    std::vector<long> rej(n_threads, 0);
+    std::vector<int> bad(n_threads, 0);
+    auto work = [&](int t) {
+        for (int k = t; k < m; k += n_threads) {
+            // numpy's mt19937_state: uint32 key[624]; int pos
+            uint32_t *key = reinterpret_cast<uint32_t *>((uintptr_t)mt_state_addr[k]);
+            int *pos = reinterpret_cast<int *>((uintptr_t)mt_state_addr[k] + 624 * sizeof(uint32_t));
+            if (!key || *pos < 0 || *pos > 624) { bad[t] = 1; return; }
+            int rc = w->w.randomise_all_poses(poses + (size_t)k * ne * 3, ents, n, ignore, arena_lrbt, rand_pos, rand_rot, pos_limits, rot_limits, key, pos);
+            if (rc < 0) { bad[t] = 2; return; }
+            rej[t] += rc;
+        }
+    };
+    if (n_threads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; t++) pool.emplace_back(work, t);
+        for (auto &th : pool) th.join();
+    }
+    long rejected = 0;
+    for (int t = 0; t < n_threads; t++) {
+        if (bad[t] == 1) return fail(MGX_ERR_ARG, "bad MT19937 state");
+        if (bad[t] == 2) return fail(MGX_ERR_CAPACITY, "could not place the entities (PlacementError after 10 retries)");
+        rejected += rej[t];
+    }
+    return (int)(rejected > 0x7fffffff ? 0x7fffffff : rejected);
 }
 int mgx_world_palette(int colour, int role) {
     if (colour < 0 || colour > 3 || role < 0 || role > 2) return fail(MGX_ERR_ARG, "colour 0..3, role 0..2");

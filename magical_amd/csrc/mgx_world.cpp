@@ -2,6 +2,7 @@
 // See mgx_world.h for the reference lines each builder follows.
 #include "mgx_world.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -209,6 +210,71 @@ bool World::placement_collides(int ent, const double *poses, const uint8_t *enab
         }
     }
     return false;
+}
+
+// ---------------------------------------------------------------- np.random.RandomState's generator (host only)
+namespace {
+// MT19937 exactly as numpy's legacy RandomState runs it (randomkit / mt19937.c): same tempering, same refill, and
+// random_sample() = (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53; uniform(lo, hi) = lo + (hi - lo) * random_sample()
+struct Mt19937 {
+    uint32_t *key; int *pos;
+    void refill() {
+        constexpr uint32_t N = 624, M = 397, MATRIX_A = 0x9908b0dfu, UPPER = 0x80000000u, LOWER = 0x7fffffffu;
+        uint32_t y; uint32_t i;
+        for (i = 0; i < N - M; i++) { y = (key[i] & UPPER) | (key[i + 1] & LOWER); key[i] = key[i + M] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX_A); }
+        for (; i < N - 1; i++) { y = (key[i] & UPPER) | (key[i + 1] & LOWER); key[i] = key[i + (M - N)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX_A); }
+        y = (key[N - 1] & UPPER) | (key[0] & LOWER);
+        key[N - 1] = key[M - 1] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX_A);
+        *pos = 0;
+    }
+    uint32_t next32() {
+        if (*pos == 624) refill();
+        uint32_t y = key[(*pos)++];
+        y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+        return y;
+    }
+    double next_double() { int32_t a = next32() >> 5, b = next32() >> 6; return (a * 67108864.0 + b) / 9007199254740992.0; }
+    double uniform(double lo, double hi) { return lo + (hi - lo) * next_double(); }
+};
+}  // namespace
+
+int World::randomise_all_poses(double *poses, const int *ents, int n, const uint8_t *ignore, const double arena[4],
+                               const uint8_t *rand_pos, const uint8_t *rand_rot, const double *pos_limits, const double *rot_limits,
+                               uint32_t *mt_key, int *mt_pos) const {
+    Mt19937 rng{mt_key, mt_pos};
+    const int ne = (int)entities.size(), max_retries = 10, max_tries = 10000;
+    int rejected = 0;
+    for (int retry = 0; retry < max_retries; retry++) {
+        std::vector<uint8_t> enabled(ne, 1);
+        for (int i = 0; i < n; i++) enabled[ents[i]] = 0;                 // categories = 0 until its turn
+        for (int e = 0; e < ne; e++) if (ignore && ignore[e]) enabled[e] = 0;
+        bool failed = false;
+        for (int i = 0; i < n && !failed; i++) {
+            const int e = ents[i];
+            enabled[e] = 1;
+            // ---- pm_randomise_pose (geom.py:116-262)
+            const double ox = poses[3 * e], oy = poses[3 * e + 1], oa = poses[3 * e + 2];
+            double x0 = arena[0], x1 = arena[1], y0 = arena[2], y1 = arena[3], r0 = -PI, r1 = PI;
+            if (pos_limits[i] >= 0) {
+                x0 = std::max(arena[0], ox - pos_limits[i]); x1 = std::min(arena[1], ox + pos_limits[i]);
+                y0 = std::max(arena[2], oy - pos_limits[i]); y1 = std::min(arena[3], oy + pos_limits[i]);
+            }
+            if (rot_limits[i] >= 0) { r0 = oa - rot_limits[i]; r1 = oa + rot_limits[i]; }
+            int n_tries = 0;
+            for (; n_tries < max_tries; n_tries++) {
+                if (rand_pos[i]) { poses[3 * e] = rng.uniform(x0, x1); poses[3 * e + 1] = rng.uniform(y0, y1); }
+                if (rand_rot[i]) poses[3 * e + 2] = rng.uniform(r0, r1);
+                if (!placement_collides(e, poses, enabled.data())) break;
+            }
+            rejected += n_tries;
+            if (n_tries == max_tries) {                                    // PlacementError: put it back, start over
+                poses[3 * e] = ox; poses[3 * e + 1] = oy; poses[3 * e + 2] = oa;
+                failed = true;
+            }
+        }
+        if (!failed) return rejected;
+    }
+    return -1;
 }
 
 int World::finalize(int max_steps, std::string &err) {

@@ -79,6 +79,12 @@ struct World {
     // poses[3 * e .. 3 * e + 2] (x, y, angle; goals: their box centre), touch the arena walls or a shape of an entity
     // whose `enabled` flag is set?  (space.shape_query of each of its shapes: Chipmunk's cpCollide count > 0)
     bool placement_collides(int ent, const double *poses, const uint8_t *enabled) const;
+    // geom.py:285-341 pm_randomise_all_poses for the entities ents[0..n): draws from the MT19937 stream (key[624], pos)
+    // exactly what np.random.RandomState.uniform would (x, y, angle per attempt), entity after entity; limits < 0 = none.
+    // Returns the number of rejected attempts, or -1 after max_retries placement failures.
+    int randomise_all_poses(double *poses, const int *ents, int n, const uint8_t *ignore, const double arena_lrbt[4],
+                            const uint8_t *rand_pos, const uint8_t *rand_rot, const double *pos_limits, const double *rot_limits,
+                            uint32_t *mt_key, int *mt_pos) const;
     // serialise: header + int words + real words (as double; caller narrows to float if needed)
     void serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<double> &rw, std::vector<double> &pw) const;
 };

@@ -65,12 +65,37 @@ def pm_randomise_pose(env, poses, ent_id, enabled, arena_lrbt, rng, rand_pos=Tru
 
 
 def pm_randomise_all_poses(env, poses, entities, arena_lrbt, rng, rand_pos=True, rand_rot=True, rel_pos_linf_limits=None,
-                           rel_rot_limits=None, ignore=(), max_retries=10, rejection_tests=()):
+                           rel_rot_limits=None, ignore=(), max_retries=10, rejection_tests=(), native=True):
     """geom.py:285-341.  entities: the Entity objects to randomise, in order; `ignore`: entities whose shapes never
-    count (the reference's ignore_shapes).  `poses` (float64[n_entities, 3], indexed by ent_id) is updated in place."""
+    count (the reference's ignore_shapes).  `poses` (float64[n_entities, 3], indexed by ent_id) is updated in place.
+
+    Without custom rejection tests the whole procedure runs natively (mgx_world_randomise_all_poses) on the
+    RandomState's own MT19937 stream, which it advances exactly as the Python loop below would."""
     n = len(entities)
     lst = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * n
     pos_limits, rot_limits, rand_pos, rand_rot = lst(rel_pos_linf_limits), lst(rel_rot_limits), lst(rand_pos), lst(rand_rot)
+    if native and not rejection_tests and max_retries == 10:
+        kind, key, pos, has_gauss, cached = rng.get_state()
+        assert kind == 'MT19937'
+        key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+        cpos = C.c_int(int(pos))
+        ents = (C.c_int * n)(*[e.ent_id for e in entities])
+        ign = np.zeros(len(poses), dtype=np.uint8)
+        for e in ignore:
+            ign[e.ent_id] = 1
+        u8 = lambda v: np.asarray([1 if x else 0 for x in v], dtype=np.uint8)
+        lim = lambda v: np.asarray([-1.0 if x is None else float(x) for x in v], dtype=np.float64)
+        rp, rr, pl, rl = u8(rand_pos), u8(rand_rot), lim(pos_limits), lim(rot_limits)
+        arena = np.asarray(arena_lrbt, dtype=np.float64)
+        assert poses.dtype == np.float64 and poses.flags.c_contiguous
+        P8, PD = C.POINTER(C.c_uint8), C.POINTER(C.c_double)
+        rc = env._lib.mgx_world_randomise_all_poses(
+            env._world, poses.ctypes.data_as(PD), ents, n, ign.ctypes.data_as(P8), arena.ctypes.data_as(PD), rp.ctypes.data_as(P8),
+            rr.ctypes.data_as(P8), pl.ctypes.data_as(PD), rl.ctypes.data_as(PD), key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cpos))
+        rng.set_state((kind, key, cpos.value, has_gauss, cached))
+        if rc < 0:
+            raise PlacementError(env._lib.mgx_last_error().decode())
+        return poses
     for retry in range(max_retries):
         enabled = np.ones(len(poses), dtype=np.uint8)
         for e in list(entities) + list(ignore):
@@ -86,4 +111,34 @@ def pm_randomise_all_poses(env, poses, entities, arena_lrbt, rng, rand_pos=True,
                 break
         else:
             break
+    return poses
+
+
+def pm_randomise_all_poses_batch(env, poses, entities, arena_lrbt, rngs, rand_pos=True, rand_rot=True, rel_pos_linf_limits=None,
+                                 rel_rot_limits=None, ignore=()):
+    """pm_randomise_all_poses for M envs in one native call: poses float64[M, n_entities, 3] (updated in place), rngs the
+    M envs' np.random.RandomState objects, whose MT19937 states are advanced in place through their ctypes address."""
+    m, n = len(rngs), len(entities)
+    lst = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * n
+    pos_limits, rot_limits, rand_pos, rand_rot = lst(rel_pos_linf_limits), lst(rel_rot_limits), lst(rand_pos), lst(rand_rot)
+    addrs = np.empty(m, dtype=np.uint64)
+    for i, rng in enumerate(rngs):
+        bg = rng._bit_generator
+        assert type(bg).__name__ == 'MT19937'
+        addrs[i] = bg.ctypes.state_address
+    ents = (C.c_int * n)(*[e.ent_id for e in entities])
+    ign = np.zeros(poses.shape[1], dtype=np.uint8)
+    for e in ignore:
+        ign[e.ent_id] = 1
+    u8 = lambda v: np.asarray([1 if x else 0 for x in v], dtype=np.uint8)
+    lim = lambda v: np.asarray([-1.0 if x is None else float(x) for x in v], dtype=np.float64)
+    rp, rr, pl, rl = u8(rand_pos), u8(rand_rot), lim(pos_limits), lim(rot_limits)
+    arena = np.asarray(arena_lrbt, dtype=np.float64)
+    assert poses.dtype == np.float64 and poses.flags.c_contiguous and poses.shape[0] == m
+    P8, PD = C.POINTER(C.c_uint8), C.POINTER(C.c_double)
+    rc = env._lib.mgx_world_randomise_all_poses_batch(
+        env._world, m, poses.ctypes.data_as(PD), ents, n, ign.ctypes.data_as(P8), arena.ctypes.data_as(PD), rp.ctypes.data_as(P8),
+        rr.ctypes.data_as(P8), pl.ctypes.data_as(PD), rl.ctypes.data_as(PD), addrs.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if rc < 0:
+        raise PlacementError(env._lib.mgx_last_error().decode())
     return poses

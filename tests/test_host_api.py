@@ -136,3 +136,61 @@ def test_spaces_standins():
     assert list(d.spaces) == ['allo', 'ego'] and d['ego'] == b
     assert d.contains(d.sample(np.random.RandomState(1)))
     assert spaces.to_gym(a) is a or type(spaces.to_gym(a)).__name__ == 'Discrete'
+
+
+def test_native_pose_sampler_matches_python_and_numpy_stream():
+    """mgx_world_randomise_all_poses draws from the RandomState's MT19937 state exactly what the Python mirror of
+    geom.py:116-341 draws through rng.uniform: same poses, and the stream ends in the same place (no GPU needed: the
+    world builder is host code)."""
+    from magical_amd import _native, geom
+    if not os.path.exists(_native.LIB_PATH):
+        pytest.skip('HIP library not built')
+    L = _native.lib()
+
+    class Ent:
+        def __init__(self, i):
+            self.ent_id = i
+
+    class Shim:          # what geom.py needs of an env
+        _lib = L
+    w = ctypes.c_void_p()
+    _native.check(L.mgx_world_create(ctypes.byref(w)))
+    Shim._world = w
+    layout = [('robot', 0.7, -0.3, 0.8)] + [('shape', t, c, x, y, a) for (t, c, x, y, a) in [
+        (5, 2, -0.51, 0.14, -0.39), (6, 2, -0.13, -0.71, 1.05), (1, 2, -0.74, -0.1, 1.16), (2, 1, -0.08, -0.43, -0.64),
+        (2, 1, 0.52, 0.19, -1.18), (1, 0, -0.53, -0.22, 2.94), (6, 3, -0.54, 0.48, 0.07), (2, 3, -0.17, 0.64, -2.33)]]
+    poses0 = []
+    for ent in layout:
+        if ent[0] == 'robot':
+            _native.check(L.mgx_world_add_robot(w, ent[1], ent[2], ent[3])); poses0.append(ent[1:4])
+        else:
+            _native.check(L.mgx_world_add_shape(w, ent[1], ent[2], ent[3], ent[4], ent[5])); poses0.append(ent[3:6])
+    _native.check(L.mgx_world_finalize(w, 100))
+    ents = [Ent(i) for i in range(len(layout))]
+    for seed, limits in [(0, (None, None)), (1, (0.025, 0.05 * np.pi)), (2, (None, None)), (3, (0.3, None))]:
+        r1, r2 = np.random.RandomState(seed), np.random.RandomState(seed)
+        r1.uniform(); r2.uniform()        # start mid-stream
+        p1 = geom.pm_randomise_all_poses(Shim, np.array(poses0, dtype=np.float64), ents, [-1, 1, -1, 1], r1,
+                                         rel_pos_linf_limits=limits[0], rel_rot_limits=limits[1], native=True)
+        p2 = geom.pm_randomise_all_poses(Shim, np.array(poses0, dtype=np.float64), ents, [-1, 1, -1, 1], r2,
+                                         rel_pos_linf_limits=limits[0], rel_rot_limits=limits[1], native=False)
+        assert np.array_equal(p1, p2), (seed, p1 - p2)
+        assert r1.randint(1 << 30) == r2.randint(1 << 30)        # both streams advanced identically
+        if limits[0] is None:
+            assert np.abs(p1 - np.array(poses0)).max() > 0.2     # a full layout really moves things
+        # the batch entry point working on the live RandomState states: same poses, same stream positions
+        r3 = [np.random.RandomState(seed), np.random.RandomState(seed + 100)]
+        for r in r3:
+            r.uniform()
+        pb = np.ascontiguousarray(np.tile(np.array(poses0, dtype=np.float64), (2, 1, 1)))
+        geom.pm_randomise_all_poses_batch(Shim, pb, ents, [-1, 1, -1, 1], r3, rel_pos_linf_limits=limits[0], rel_rot_limits=limits[1])
+        assert np.array_equal(pb[0], p1) and not np.array_equal(pb[1], p1)
+        r4 = np.random.RandomState(seed); r4.uniform()
+        geom.pm_randomise_all_poses(Shim, np.array(poses0, dtype=np.float64), ents, [-1, 1, -1, 1], r4,
+                                    rel_pos_linf_limits=limits[0], rel_rot_limits=limits[1], native=False)
+        assert r3[0].randint(1 << 30) == r4.randint(1 << 30)
+        # nothing overlaps, nothing pokes through the walls
+        en_all = np.ones(len(layout), dtype=np.uint8)
+        for e in ents:
+            assert not geom.placement_collides(Shim, e.ent_id, p1, en_all)
+    L.mgx_world_destroy(w)
