@@ -98,8 +98,9 @@ int mgx_world_entity_shapes(const mgx_world *w, int ent, int max_shapes, int *ki
 int mgx_world_prim_table(const mgx_world *w, int *rgb, int *ent, int *role);
 /* geom.py:116-262 pm_randomise_pose's rejection test, on the host: with entity e at poses[3e..3e+2] = (x, y, angle)
  * (goals: their box centre), does entity `ent` touch the arena walls or a shape of an entity with enabled[e] != 0
- * (space.shape_query of each of its shapes, i.e. cpCollide(...).count > 0, ShapeFilter groups honoured)?  1 / 0 */
-int mgx_world_placement_collides(const mgx_world *w, int ent, const double *poses, const uint8_t *enabled);
+ * (space.shape_query of each of its shapes, i.e. cpCollide(...).count > 0, ShapeFilter groups honoured)?  1 / 0.
+ * ent_hw: NULL, or [n_entities][2] = this env's (h, w) of every goal region (geom.py:344-360 randomise_hw) */
+int mgx_world_placement_collides(const mgx_world *w, int ent, const double *poses, const uint8_t *enabled, const double *ent_hw);
 /* geom.py:285-341 pm_randomise_all_poses for the entities ents[0..n) of ONE env, natively: poses [n_entities][3] in/out;
  * ignore[n_entities] (or NULL); per listed entity rand_pos / rand_rot flags and position / rotation limits (< 0: none).
  * The draws come from the np.random.RandomState stream handed over as its MT19937 state (key[624], pos) and are the
@@ -107,12 +108,13 @@ int mgx_world_placement_collides(const mgx_world *w, int ent, const double *pose
  * of rejected attempts, or MGX_ERR_CAPACITY when placement fails 10 times over */
 int mgx_world_randomise_all_poses(const mgx_world *w, double *poses, const int *ents, int n, const uint8_t *ignore,
                                   const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
-                                  const double *pos_limits, const double *rot_limits, uint32_t *mt_key, int *mt_pos);
+                                  const double *pos_limits, const double *rot_limits, uint32_t *mt_key, int *mt_pos, const double *ent_hw);
 /* the same for m envs in one call: poses [m][n_entities][3]; mt_state_addr[k] = address of env k's live numpy
  * mt19937_state { uint32 key[624]; int pos; } (RandomState._bit_generator.ctypes.state_address), advanced in place */
 int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses, const int *ents, int n, const uint8_t *ignore,
                                         const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
-                                        const double *pos_limits, const double *rot_limits, const uint64_t *mt_state_addr);
+                                        const double *pos_limits, const double *rot_limits, const uint64_t *mt_state_addr,
+                                        const double *ent_hw /* NULL or [m][n_entities][2] */);
 /* style.py:28-37 evaluated to RGB8 for entity colour 0..3 (red green blue yellow) in `role` */
 int mgx_world_palette(int colour, int role);
 
@@ -154,6 +156,10 @@ int mgx_engine_substeps(mgx_engine *e, void *state_p, void *state_f, int32_t *st
 /* Test*Colour variants: primitive colours per env, DEVICE int32 [n_prims][N] owned by the caller and read by every
  * later render call (NULL = the world's own colours again) */
 int mgx_engine_set_prim_colours(mgx_engine *e, const int32_t *prim_rgb);
+/* Test*Jitter / TestLayout variants with goal regions: the regions' rectangles per env, DEVICE double [n_goals * 4][N]
+ * = x, y (top-left corner), h, w per goal in entity order (entities.py:769-819), caller-owned, read by every later
+ * render call (NULL = the world's own rectangles again).  Goal regions are sensors: physics never sees them */
+int mgx_engine_set_goal_rects(mgx_engine *e, const double *goal_xyhw);
 int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t env_stride, int view, int layout,
                       const uint8_t *fill_mask, void *stream);
 /* native-resolution (384x384x3, no box filter) render of ONE env, for tests against the oracle/images */

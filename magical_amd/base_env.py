@@ -190,6 +190,12 @@ class BaseEnv(abc.ABC):
                                         for e in self._entities], dtype=np.float64)
         self.entity_poses = np.tile(self._default_poses, (self.n_envs, 1, 1))
         self._ent_pose = None        # device [n_entities * 3, N], allocated when an env first deviates from the template
+        # goal regions (sensors: rendering + scoring only): GoalRegion(x, y, h, w) per env, in entity order
+        self._goal_ent_idx = [i for i, e in enumerate(self._entities) if isinstance(e, en.GoalRegion)]
+        self._goal_xyhw0 = np.array([[self._entities[i].x, self._entities[i].y, self._entities[i].h, self._entities[i].w]
+                                     for i in self._goal_ent_idx], dtype=np.float64).reshape(-1, 4)
+        self.goal_xyhw = np.tile(self._goal_xyhw0, (self.n_envs, 1, 1))
+        self._goal_rect = None       # device float64 [n_goals * 4, N], allocated when an env first deviates
         # pose-blob row of (x, y, angle) per body, -1 where the body is not persistent
         n = nat.check(L.mgx_world_n_state_entries(w))
         self._pose_rows = -np.ones((self.n_bodies, 3), dtype=np.int64)
@@ -256,7 +262,8 @@ class BaseEnv(abc.ABC):
         """Task hook: draw this episode's random choices from `rng` with the same calls, in the same order, as the
         reference's on_reset() (after the physics variables, base_env.py:198-214), for env `k` (tasks keep what their
         score needs per env).  Return None (Demo) or a dict; supported keys: 'colours' = {entity: colour name},
-        'poses' = {entity: (x, y, angle)}, 'randomise_poses' = (entities, kwargs of geom.pm_randomise_all_poses) -- the
+        'poses' = {entity: (x, y, angle)}, 'goal_hw' = {goal region: (h, w)},
+        'randomise_poses' = (entities, kwargs of geom.pm_randomise_all_poses) -- the
         pose draws must come last in the reference's on_reset (they do in every task), because they are made after this
         hook returns, for all envs in one native call."""
         return None
@@ -270,7 +277,7 @@ class BaseEnv(abc.ABC):
         its own stream self.rngs[k], in the reference's order: physics variables, then the task's on_reset choices), then
         the reset kernel -- with the drawn entity poses if any -- then the drawn force limits and colours."""
         import torch
-        pvs, colour_rows, pose_rows, pose_spec = [], [], [], None
+        pvs, colour_rows, pose_rows, pose_spec, hw_rows = [], [], [], None, {}
         for k in env_idx:
             rng = self.rngs[k]
             if self.rand_dynamics:
@@ -288,13 +295,34 @@ class BaseEnv(abc.ABC):
                 pose_rows.append(row)
             if var is not None and 'randomise_poses' in var:
                 pose_spec = var['randomise_poses']       # the same for every env of a task: one native call below
-        if pose_spec is not None:
-            # geom.py pm_randomise_all_poses for all envs being reset, each on its own stream, natively
-            from . import geom
-            ents, kwargs = pose_spec
+            if var is not None and 'goal_hw' in var:
+                hw_rows[int(k)] = {self._entities.index(g): hw for g, hw in var['goal_hw'].items()}
+        ent_hw = None
+        if hw_rows:
+            # resized goal regions keep their top-left corner (GoalRegion(x, y, h, w), entities.py:769-797): new centre
+            ent_hw = np.zeros((len(env_idx), len(self._entities), 2), dtype=np.float64)
+            ent_hw[:, self._goal_ent_idx] = self._goal_xyhw0[:, 2:]
+            for i, k in enumerate(env_idx):
+                for e, (h, w) in hw_rows.get(int(k), {}).items():
+                    ent_hw[i, e] = (h, w)
+        if pose_spec is not None or hw_rows:
             batch = np.ascontiguousarray(np.tile(self._default_poses, (len(env_idx), 1, 1)))
-            geom.pm_randomise_all_poses_batch(self, batch, ents, self.ARENA_BOUNDS_LRBT, [self.rngs[k] for k in env_idx], **kwargs)
+            if ent_hw is not None:
+                for g, e in enumerate(self._goal_ent_idx):
+                    batch[:, e, 0] = self._goal_xyhw0[g, 0] + ent_hw[:, e, 1] / 2
+                    batch[:, e, 1] = self._goal_xyhw0[g, 1] - ent_hw[:, e, 0] / 2
+            if pose_spec is not None:
+                # geom.py pm_randomise_all_poses for all envs being reset, each on its own stream, natively
+                from . import geom
+                ents, kwargs = pose_spec
+                geom.pm_randomise_all_poses_batch(self, batch, ents, self.ARENA_BOUNDS_LRBT, [self.rngs[k] for k in env_idx],
+                                                  ent_hw=ent_hw, **kwargs)
             pose_rows = list(batch)
+            if len(self._goal_ent_idx):
+                # the goal regions' rectangles of these envs, back in GoalRegion(x, y, h, w) form: x, y = top-left corner
+                hw = ent_hw[:, self._goal_ent_idx] if ent_hw is not None else np.tile(self._goal_xyhw0[:, 2:], (len(env_idx), 1, 1))
+                c = batch[:, self._goal_ent_idx, :2]
+                self.set_goal_rects(np.stack([c[..., 0] - hw[..., 1] / 2, c[..., 1] + hw[..., 0] / 2, hw[..., 0], hw[..., 1]], axis=-1), env_idx)
         sp, sf, si = self.state_p.data_ptr(), self.state_f.data_ptr(), self.state_i.data_ptr()
         mask = None if mask_dev is None else mask_dev.data_ptr()
         if pose_rows:
@@ -329,6 +357,32 @@ class BaseEnv(abc.ABC):
             self._prim_rgb = torch.as_tensor(np.tile(self._prim_rgb0[:, None], (1, self.n_envs)).astype(np.int32), device=self.device).contiguous()
             nat.check(self._lib.mgx_engine_set_prim_colours(self._engine, self._prim_rgb.data_ptr()))
         self._prim_rgb[:, torch.as_tensor(idx, device=self.device)] = torch.as_tensor(rgb.astype(np.int32), device=self.device)
+
+    def set_goal_rects(self, xyhw, env_idx=None):
+        """xyhw: float64[M, n_goals, 4] = GoalRegion(x, y, h, w) of every goal region for the envs `env_idx`: what the
+        rasteriser draws and what score_on_end_of_traj() sees as the sensors."""
+        import torch
+        idx = np.arange(self.n_envs) if env_idx is None else np.asarray(env_idx)
+        xyhw = np.asarray(xyhw, dtype=np.float64).reshape(len(idx), len(self._goal_ent_idx), 4)
+        self.goal_xyhw[idx] = xyhw
+        if self._goal_rect is None:
+            if self.state_p.dtype != torch.float64:
+                raise NotImplementedError('per-env goal rectangles need fp64 poses (dtype f32 or f64)')
+            self._goal_rect = torch.as_tensor(np.ascontiguousarray(self.goal_xyhw.reshape(self.n_envs, -1).T), device=self.device).contiguous()
+            nat.check(self._lib.mgx_engine_set_goal_rects(self._engine, self._goal_rect.data_ptr()))
+        else:
+            self._goal_rect[:, torch.as_tensor(idx, device=self.device)] = torch.as_tensor(
+                np.ascontiguousarray(xyhw.reshape(len(idx), -1).T), device=self.device)
+
+    def goal_bb(self, goal):
+        """Sensor box (l, b, r, t) of a goal region for the envs being scored: scalars while every env has the
+        template's rectangle, float64[M] arrays otherwise (same arithmetic as mgx_world_goal_bb, entities.py:794-797)."""
+        if self._goal_rect is None:
+            return goal.bb
+        g = self._goal_ent_idx.index(self._entities.index(goal))
+        x, y, h, w = (self.goal_xyhw[self._scoring_envs, g, c] for c in range(4))
+        cx, cy, hw, hh = x + w / 2, y - h / 2, w / 2, h / 2
+        return cx - hw, cy - hh, cx + hw, cy + hh
 
     def set_phys_vars(self, values, env_idx=None):
         """values: float64[M, 5] joint max forces (robot_pos, robot_rot, robot_finger, shape_trans, shape_rot) of the

@@ -44,8 +44,8 @@ def _shape_hits_box(kind, radius, verts, pose, bb):
     """Does the shape (at poses[M,3]) overlap the axis-aligned sensor box?  Mirrors
     space.shape_query(goal_shape) -> cpShapesCollide(...).count > 0 (entities.py:837-838):
     overlap iff the minimum separation between the cores is <= the shape's radius."""
-    l, b, r, t = bb
     x, y, a = pose[:, 0], pose[:, 1], pose[:, 2]
+    l, b, r, t = (np.broadcast_to(np.asarray(v, dtype=np.float64), x.shape) for v in bb)      # scalars or one box per env
     if kind == 0:   # circle
         dx = np.maximum(np.maximum(l - x, 0.0), x - r)
         dy = np.maximum(np.maximum(b - y, 0.0), y - t)
@@ -54,14 +54,14 @@ def _shape_hits_box(kind, radius, verts, pose, bb):
     wx = x[:, None] + (c[:, None] * verts[None, :, 0] - s[:, None] * verts[None, :, 1])
     wy = y[:, None] + (c[:, None] * verts[None, :, 1] + s[:, None] * verts[None, :, 0])
     sep = np.maximum.reduce([l - wx.max(axis=1), wx.min(axis=1) - r, b - wy.max(axis=1), wy.min(axis=1) - t])
-    corners = np.array([(l, b), (r, b), (r, t), (l, t)], dtype=np.float64)
+    corner_x, corner_y = np.stack([l, r, r, l], axis=1), np.stack([b, b, t, t], axis=1)      # [M, 4]
     n = verts.shape[0]
     for i in range(n):
         j = (i + 1) % n
         ex, ey = wx[:, j] - wx[:, i], wy[:, j] - wy[:, i]
         ln = np.sqrt(ex * ex + ey * ey)
         nx, ny = ey / ln, -ex / ln           # outward normal of a CCW polygon
-        d = np.min(nx[:, None] * (corners[None, :, 0] - wx[:, i, None]) + ny[:, None] * (corners[None, :, 1] - wy[:, i, None]), axis=1)
+        d = np.min(nx[:, None] * (corner_x - wx[:, i, None]) + ny[:, None] * (corner_y - wy[:, i, None]), axis=1)
         sep = np.maximum(sep, d)
     return sep <= radius
 
@@ -70,7 +70,8 @@ def overlapping_ents(env, goal, ents, poses):
     """GoalRegion.get_overlapping_ents(com_overlap=True) (entities.py:821-881), batched:
     bool[M, len(ents)] -- an entity counts iff EVERY one of its shapes overlaps the sensor AND its
     body position lies inside the sensor's bounding box."""
-    l, b, r, t = goal.bb
+    bb = env.goal_bb(goal)
+    l, b, r, t = bb
     out = np.zeros((poses.shape[0], len(ents)), dtype=bool)
     for k, ent in enumerate(ents):
         pose = poses[:, ent.body, :]
@@ -79,6 +80,6 @@ def overlapping_ents(env, goal, ents, poses):
         if not hasattr(ent, '_shapes_cache'):
             ent._shapes_cache = entity_shapes(env, ent)
         for kind, radius, verts in ent._shapes_cache:
-            ok &= _shape_hits_box(kind, radius, verts, pose, goal.bb)
+            ok &= _shape_hits_box(kind, radius, verts, pose, bb)
         out[:, k] = ok
     return out

@@ -1,9 +1,10 @@
-"""MatchRegions (mirror of magical/benchmarks/match_regions.py: Demo, TestColour and TestDynamics branches)."""
+"""MatchRegions (mirror of magical/benchmarks/match_regions.py: Demo, TestColour, TestJitter, TestLayout and TestDynamics branches)."""
 import math
 
 import numpy as np
 
 from .. import entities as en
+from .. import geom
 from ..base_env import BaseEnv
 from ._scoring import overlapping_ents
 
@@ -11,20 +12,33 @@ from ._scoring import overlapping_ents
 class MatchRegionsEnv(BaseEnv):
     def __init__(self, rand_target_colour=False, rand_shape_type=False, rand_shape_count=False,
                  rand_layout_minor=False, rand_layout_full=False, **kwargs):
-        if rand_shape_type or rand_shape_count or rand_layout_minor or rand_layout_full:
-            raise NotImplementedError('built: Demo, TestColour, TestDynamics (shape types / counts / layouts need per-env geometry: SURVEY.md §8f)')
-        self.rand_target_colour = rand_target_colour
+        if rand_shape_type or rand_shape_count:
+            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestLayout, TestDynamics (shape types / counts need per-env geometry: SURVEY.md §8f)')
+        assert not (rand_layout_minor and rand_layout_full)
+        self.rand_target_colour, self.rand_layout_minor, self.rand_layout_full = rand_target_colour, rand_layout_minor, rand_layout_full
         super().__init__(**kwargs)
 
-    def sample_variation(self, rng, k):   # match_regions.py:51-58: the sensor and the targets take the drawn colour, the
-        if not self.rand_target_colour:   # distractor groups the remaining ones in SHAPE_COLOURS order
+    def sample_variation(self, rng, k):   # match_regions.py:51-72 (colour, then the region's size), :166-188 (poses)
+        if not (self.rand_target_colour or self.rand_layout_minor or self.rand_layout_full):
             return None
-        target_colour = rng.choice(en.SHAPE_COLOUR_NAMES)
-        distractor_colours = [c for c in en.SHAPE_COLOUR_NAMES if c != target_colour]
-        colours = {self.__sensor_ref: target_colour}
-        colours.update({s: target_colour for s in self.__target_shapes})
-        colours.update({s: distractor_colours[g] for s, g in zip(self.__distractor_shapes, self.__distractor_group)})
-        return {'colours': colours}
+        var = {}
+        if self.rand_target_colour:
+            # the sensor and the targets take the drawn colour, the distractor groups the remaining ones in SHAPE_COLOURS order
+            target_colour = rng.choice(en.SHAPE_COLOUR_NAMES)
+            distractor_colours = [c for c in en.SHAPE_COLOUR_NAMES if c != target_colour]
+            colours = {self.__sensor_ref: target_colour}
+            colours.update({s: target_colour for s in self.__target_shapes})
+            colours.update({s: distractor_colours[g] for s, g in zip(self.__distractor_shapes, self.__distractor_group)})
+            var['colours'] = colours
+        if self.rand_layout_minor or self.rand_layout_full:
+            hw_bound = self.JITTER_TARGET_BOUND if self.rand_layout_minor else None
+            var['goal_hw'] = {self.__sensor_ref: geom.randomise_hw(self.RAND_GOAL_MIN_SIZE, self.RAND_GOAL_MAX_SIZE, rng,
+                                                                   current_hw=(0.7, 0.6), linf_bound=hw_bound)}
+            all_ents = (self.__sensor_ref, self._robot, *self.__target_shapes, *self.__distractor_shapes)
+            pos_limits, rot_limits = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if self.rand_layout_minor else (None, None)
+            var['randomise_poses'] = (all_ents, dict(rand_pos=True, rand_rot=[False] + [True] * (len(all_ents) - 1),
+                                                     rel_pos_linf_limits=pos_limits, rel_rot_limits=rot_limits))
+        return var
 
     def on_reset(self):   # match_regions.py:44-162
         robot = self._make_robot(np.asarray((-0.5, 0.1)), -math.pi * 1.2)

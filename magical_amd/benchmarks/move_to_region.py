@@ -1,7 +1,8 @@
-"""MoveToRegion (mirror of magical/benchmarks/move_to_region.py: Demo, TestColour and TestDynamics branches)."""
+"""MoveToRegion (mirror of magical/benchmarks/move_to_region.py: all six variants)."""
 import numpy as np
 
 from .. import entities as en
+from .. import geom
 from ..base_env import BaseEnv
 
 DEFAULT_ROBOT_POSE = ((0.058, 0.53), -2.13)
@@ -11,15 +12,26 @@ DEFAULT_GOAL_XYHW = (-0.62, -0.17, 0.76, 0.75)
 
 class MoveToRegionEnv(BaseEnv):
     def __init__(self, rand_poses_minor=False, rand_poses_full=False, rand_goal_colour=False, **kwargs):
-        if rand_poses_minor or rand_poses_full:
-            raise NotImplementedError('built: Demo, TestColour, TestDynamics (goal size / poses need per-env geometry: SURVEY.md §8f)')
-        self.rand_goal_colour = rand_goal_colour
+        assert not (rand_poses_minor and rand_poses_full), "cannot specify both 'rand_poses_minor' and 'rand_poses_full'"
+        self.rand_poses_minor, self.rand_poses_full, self.rand_goal_colour = rand_poses_minor, rand_poses_full, rand_goal_colour
         super().__init__(**kwargs)
 
-    def sample_variation(self, rng, k):   # move_to_region.py:47-51
-        if not self.rand_goal_colour:
+    def sample_variation(self, rng, k):   # move_to_region.py:31-78, in the reference's order: goal size, colour, then poses
+        if not (self.rand_poses_minor or self.rand_poses_full or self.rand_goal_colour):
             return None
-        return {'colours': {self.__goal_ref: rng.choice(np.asarray(en.SHAPE_COLOURS, dtype='object'))}}
+        var = {}
+        if self.rand_poses_minor or self.rand_poses_full:
+            hw_bound = self.JITTER_TARGET_BOUND if self.rand_poses_minor else None
+            var['goal_hw'] = {self.__goal_ref: geom.randomise_hw(self.RAND_GOAL_MIN_SIZE, self.RAND_GOAL_MAX_SIZE, rng,
+                                                                 current_hw=DEFAULT_GOAL_XYHW[2:], linf_bound=hw_bound)}
+        if self.rand_goal_colour:
+            var['colours'] = {self.__goal_ref: rng.choice(np.asarray(en.SHAPE_COLOURS, dtype='object'))}
+        if self.rand_poses_minor or self.rand_poses_full:
+            # the goal region is never rotated; under minor jitter only the robot's rotation is bounded
+            pos_limits, rot_limits = (self.JITTER_POS_BOUND, [None, self.JITTER_ROT_BOUND]) if self.rand_poses_minor else (None, None)
+            var['randomise_poses'] = ((self.__goal_ref, self._robot), dict(
+                rand_pos=True, rand_rot=(False, True), rel_pos_linf_limits=pos_limits, rel_rot_limits=rot_limits))
+        return var
 
     def on_reset(self):   # move_to_region.py:30-63
         goal = en.GoalRegion(*DEFAULT_GOAL_XYHW, DEFAULT_GOAL_COLOUR)
@@ -31,6 +43,6 @@ class MoveToRegionEnv(BaseEnv):
     def score_on_end_of_traj(self, poses):   # move_to_region.py:85-94
         # goal_shape.point_query(robot_pos)[0] <= 0  <=>  not strictly outside any face of the box
         x, y = poses[:, self._robot.body, 0], poses[:, self._robot.body, 1]
-        l, b, r, t = self.__goal_ref.bb
+        l, b, r, t = self.goal_bb(self.__goal_ref)
         outside = (x - r > 0.0) | (y - t > 0.0) | (l - x > 0.0) | (b - y > 0.0)
         return np.where(outside, 0.0, 1.0)

@@ -176,26 +176,26 @@ int mgx_world_prim_table(const mgx_world *w, int *rgb, int *ent, int *role) {
     }
     return n;
 }
-int mgx_world_placement_collides(const mgx_world *w, int ent, const double *poses, const uint8_t *enabled) {
+int mgx_world_placement_collides(const mgx_world *w, int ent, const double *poses, const uint8_t *enabled, const double *ent_hw) {
     if (!w || !w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
     if (ent < 0 || ent >= (int)w->w.entities.size() || !poses || !enabled) return fail(MGX_ERR_ARG, "bad entity / NULL argument");
-    return w->w.placement_collides(ent, poses, enabled) ? 1 : 0;
+    return w->w.placement_collides(ent, poses, enabled, ent_hw) ? 1 : 0;
 }
 int mgx_world_randomise_all_poses(const mgx_world *w, double *poses, const int *ents, int n, const uint8_t *ignore,
                                   const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
-                                  const double *pos_limits, const double *rot_limits, uint32_t *mt_key, int *mt_pos) {
+                                  const double *pos_limits, const double *rot_limits, uint32_t *mt_key, int *mt_pos, const double *ent_hw) {
     if (!w || !w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
     if (!poses || !ents || n < 1 || !arena_lrbt || !rand_pos || !rand_rot || !pos_limits || !rot_limits || !mt_key || !mt_pos)
         return fail(MGX_ERR_ARG, "NULL argument");
     if (*mt_pos < 0 || *mt_pos > 624) return fail(MGX_ERR_ARG, "bad MT19937 position");
     for (int i = 0; i < n; i++) if (ents[i] < 0 || ents[i] >= (int)w->w.entities.size()) return fail(MGX_ERR_ARG, "entity index out of range");
-    int rc = w->w.randomise_all_poses(poses, ents, n, ignore, arena_lrbt, rand_pos, rand_rot, pos_limits, rot_limits, mt_key, mt_pos);
+    int rc = w->w.randomise_all_poses(poses, ents, n, ignore, arena_lrbt, rand_pos, rand_rot, pos_limits, rot_limits, mt_key, mt_pos, ent_hw);
     if (rc < 0) return fail(MGX_ERR_CAPACITY, "could not place the entities (PlacementError after 10 retries)");
     return rc;
 }
 int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses, const int *ents, int n, const uint8_t *ignore,
                                         const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
-                                        const double *pos_limits, const double *rot_limits, const uint64_t *mt_state_addr) {
+                                        const double *pos_limits, const double *rot_limits, const uint64_t *mt_state_addr, const double *ent_hw) {
     if (!w || !w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
     if (m < 0 || !poses || !ents || n < 1 || !arena_lrbt || !rand_pos || !rand_rot || !pos_limits || !rot_limits || !mt_state_addr)
         return fail(MGX_ERR_ARG, "NULL argument");
@@ -213,7 +213,8 @@ int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses
             uint32_t *key = reinterpret_cast<uint32_t *>((uintptr_t)mt_state_addr[k]);
             int *pos = reinterpret_cast<int *>((uintptr_t)mt_state_addr[k] + 624 * sizeof(uint32_t));
             if (!key || *pos < 0 || *pos > 624) { bad[t] = 1; return; }
-            int rc = w->w.randomise_all_poses(poses + (size_t)k * ne * 3, ents, n, ignore, arena_lrbt, rand_pos, rand_rot, pos_limits, rot_limits, key, pos);
+            int rc = w->w.randomise_all_poses(poses + (size_t)k * ne * 3, ents, n, ignore, arena_lrbt, rand_pos, rand_rot, pos_limits, rot_limits, key, pos,
+                                              ent_hw ? ent_hw + (size_t)k * ne * 2 : nullptr);
             if (rc < 0) { bad[t] = 2; return; }
             rej[t] += rc;
         }
@@ -509,6 +510,12 @@ int mgx_engine_debug_iterations(mgx_engine *e, int it) { if (e) e->dbg_iteration
 int mgx_engine_set_prim_colours(mgx_engine *e, const int32_t *prim_rgb) {
     if (!e) return fail(MGX_ERR_ARG, "engine is NULL");
     e->rdev.prim_rgb_env = prim_rgb;
+    return MGX_OK;
+}
+int mgx_engine_set_goal_rects(mgx_engine *e, const double *goal_xyhw) {
+    if (!e) return fail(MGX_ERR_ARG, "engine is NULL");
+    if (e->dtype == MGX_F32_PURE && goal_xyhw) return fail(MGX_ERR_ARG, "per-env goal rectangles need the fp64 pose type");
+    e->rdev.goal_xyhw_env = goal_xyhw;
     return MGX_OK;
 }
 int mgx_engine_set_timing(mgx_engine *e, int enable) {

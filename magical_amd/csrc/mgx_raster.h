@@ -66,7 +66,8 @@ struct Raster {
     MGX_HD int prim_xf(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 3]; }
     MGX_HD int prim_rgb(int k) const { return i[ro.prgb + k]; }       // after raster_setup_prims
     MGX_HD int prim_rgb_template(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 4]; }
-    MGX_HD int prim_stipple(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 5]; }
+    MGX_HD int prim_stipple(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 5] & 0xFFFF; }
+    MGX_HD int prim_goal(int k) const { return (ti[to.prim_i + k * PRIM_IWORDS + 5] >> 16) - 1; }   // goal region ordinal, -1: none
     // tq layout: [n_prims * PRIM_RWORDS][pvx n_pverts][pvy n_pverts]
     MGX_HD double prim_r(int k, int j) const { return tq[k * PRIM_RWORDS + j]; }
     MGX_HD double pvx(int v) const { return tq[h->n_prims * PRIM_RWORDS + v]; }
@@ -120,7 +121,8 @@ MGX_HD void raster_camera(const Raster &rs, double *cam) {
 }
 
 // ---- setup phase 2: screen-space vertices (lane per vertex) and n-gon records (lane per prim)
-MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_rgb = nullptr, long stride = 0, long env = 0) {
+MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_rgb = nullptr, long stride = 0, long env = 0,
+                               const double *env_goal = nullptr) {
     const TmplHeader &h = *rs.h;
     double cam[6];
     raster_camera(rs, cam);
@@ -155,8 +157,18 @@ MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_
             RD(pphi, k) = phi;
             continue;
         }
+        // goal regions whose rectangle differs per env (x, y = top-left corner, then h, w): rebuild the four corners
+        // the way the world builder does (gym_render.py:449-453 order around the box centre, entities.py:794-797)
+        const int goal = env_goal ? rs.prim_goal(k) : -1;
+        double gx = 0, gy = 0, gh = 0, gw = 0, gcx = 0, gcy = 0;
+        if (goal >= 0) {
+            gx = env_goal[(long)(4 * goal) * stride + env]; gy = env_goal[(long)(4 * goal + 1) * stride + env];
+            gh = env_goal[(long)(4 * goal + 2) * stride + env]; gw = env_goal[(long)(4 * goal + 3) * stride + env];
+            gcx = gx + gw / 2; gcy = gy - gh / 2;
+        }
         for (int i = 0; i < nv; i++) {
             double lx = rs.pvx(vo + i), ly = rs.pvy(vo + i);
+            if (goal >= 0) { lx = ((i == 1 || i == 2) ? gw / 2 : -gw / 2) + gcx; ly = ((i < 2) ? gh / 2 : -gh / 2) + gcy; }
             double wx = lx, wy = ly;
             if (xf != XF_WORLD) { wx = bx + (bc * lx - bs * ly); wy = by + (bc * ly + bs * lx); }
             double sx = cam[0] * wx + cam[1] * wy + cam[4], sy = cam[2] * wx + cam[3] * wy + cam[5];

@@ -26,6 +26,7 @@ struct RasterDev {
     unsigned long long *dbg_clk;   // development probe: per-block phase clocks [n_envs][16] (NULL = off)
     int dbg_stop;                  // development probe: return after phase k (0 = run everything)
     const int32_t *prim_rgb_env;   // [n_prims][n_envs] per-env primitive colours (NULL: the template's)
+    const double *goal_xyhw_env;   // [n_goals * 4][n_envs] per-env goal rectangles x, y (top-left), h, w (NULL: the template's)
     int qcap;                      // queue entries in use (<= QCAP; tests shrink it to exercise the overflow rounds)
     int ecap;                      // phase E records in use (<= ECAP; likewise)
 };
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
     // phase S: screen-space setup (lane per body, lane per primitive, lane per primitive again for the item list)
     raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
     __syncthreads();
-    raster_setup_prims(rs, tid, 256, t.prim_rgb_env, (long)n_envs, env);
+    raster_setup_prims(rs, tid, 256, t.prim_rgb_env, (long)n_envs, env, t.goal_xyhw_env);
     __syncthreads();
     raster_setup_items(rs, tid, 256);
     __syncthreads();
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster_native(RasterD
               reinterpret_cast<int32_t *>(lds + t.lds_tmpl_words + 2 * t.scratch_d), view);
     raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
     __syncthreads();
-    raster_setup_prims(rs, tid, 256, t.prim_rgb_env, (long)n_envs, env);
+    raster_setup_prims(rs, tid, 256, t.prim_rgb_env, (long)n_envs, env, t.goal_xyhw_env);
     __syncthreads();
     const int pix = blockIdx.x * 256 + tid;
     if (pix >= NATIVE_RES * NATIVE_RES) return;

@@ -174,13 +174,13 @@ bool shapes_touch(const WShape &a, const WShape &b) {
 }
 }  // namespace
 
-bool World::placement_collides(int ent, const double *poses, const uint8_t *enabled) const {
+bool World::placement_collides(int ent, const double *poses, const uint8_t *enabled, const double *ent_hw) const {
     // world-space shapes of entity e at its pose (bodies follow the entity rigidly, as in finalize())
     auto shapes_of = [&](int e, std::vector<WShape> &out) {
         const EntityDef &E = entities[e];
         double x = poses[3 * e], y = poses[3 * e + 1], a = poses[3 * e + 2];
         if (E.kind == 2) {                      // goal sensor: box (w, h) around its centre, never rotated
-            double hw = E.w / 2, hh = E.h / 2;
+            double hw = (ent_hw ? ent_hw[2 * e + 1] : E.w) / 2, hh = (ent_hw ? ent_hw[2 * e] : E.h) / 2;
             out.push_back({SH_POLY, 0.0, {{x - hw, y - hh}, {x + hw, y - hh}, {x + hw, y + hh}, {x - hw, y + hh}}, 0});
             return;
         }
@@ -240,7 +240,7 @@ struct Mt19937 {
 
 int World::randomise_all_poses(double *poses, const int *ents, int n, const uint8_t *ignore, const double arena[4],
                                const uint8_t *rand_pos, const uint8_t *rand_rot, const double *pos_limits, const double *rot_limits,
-                               uint32_t *mt_key, int *mt_pos) const {
+                               uint32_t *mt_key, int *mt_pos, const double *ent_hw) const {
     Mt19937 rng{mt_key, mt_pos};
     const int ne = (int)entities.size(), max_retries = 10, max_tries = 10000;
     int rejected = 0;
@@ -264,7 +264,7 @@ int World::randomise_all_poses(double *poses, const int *ents, int n, const uint
             for (; n_tries < max_tries; n_tries++) {
                 if (rand_pos[i]) { poses[3 * e] = rng.uniform(x0, x1); poses[3 * e + 1] = rng.uniform(y0, y1); }
                 if (rand_rot[i]) poses[3 * e + 2] = rng.uniform(r0, r1);
-                if (!placement_collides(e, poses, enabled.data())) break;
+                if (!placement_collides(e, poses, enabled.data(), ent_hw)) break;
             }
             rejected += n_tries;
             if (n_tries == max_tries) {                                    // PlacementError: put it back, start over
@@ -301,7 +301,7 @@ int World::finalize(int max_steps, std::string &err) {
         prims.push_back(ln);
     }
 
-    int n_blocks = 0;
+    int n_blocks = 0, n_goals = 0;
     for (size_t ei = 0; ei < entities.size(); ei++) {
         EntityDef &e = entities[ei];
         if (e.kind == 0) {
@@ -475,9 +475,10 @@ int World::finalize(int max_steps, std::string &err) {
             double cx = e.x + e.w / 2, cy = e.y - e.h / 2;
             std::vector<Vec2> rect = draw_rect(e.w, e.h);
             for (auto &v : rect) { v.x += cx; v.y += cy; }
-            PrimDef fill = prim(PR_POLY, LIGHT2[e.colour], XF_WORLD, 0); fill.verts = rect; fill.ent = (int)ei; fill.role = 2; prims.push_back(fill);
+            const int goal_ord = n_goals++;
+            PrimDef fill = prim(PR_POLY, LIGHT2[e.colour], XF_WORLD, 0); fill.verts = rect; fill.ent = (int)ei; fill.role = 2; fill.goal = goal_ord; prims.push_back(fill);
             PrimDef outl = prim(PR_LINELOOP, BASE[e.colour], XF_WORLD, 0);
-            outl.verts = rect; outl.line_width = 2.5; outl.stipple = 0x00FF; outl.ent = (int)ei; outl.role = 1;
+            outl.verts = rect; outl.line_width = 2.5; outl.stipple = 0x00FF; outl.ent = (int)ei; outl.role = 1; outl.goal = goal_ord;
             prims.push_back(outl);
         }
     }
@@ -642,7 +643,7 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
         pi[0] = P.kind; pi[1] = nv; pi[2] = pvoff;
         pi[3] = P.xform | (P.body << 8) | ((P.eye_body + 1) << 16);
         pi[4] = P.rgb[0] | (P.rgb[1] << 8) | (P.rgb[2] << 16);
-        pi[5] = P.stipple;
+        pi[5] = P.stipple | ((P.goal + 1) << 16);      // low 16 bits: line stipple; high: 1 + goal ordinal
         pr[0] = P.eye_base[0]; pr[1] = P.eye_base[1]; pr[2] = P.eye_pre[0]; pr[3] = P.eye_pre[1];
         pr[4] = 0.5 * (P.line_width + 1.0);
         pr[5] = P.radius;

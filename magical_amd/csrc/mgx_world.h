@@ -44,6 +44,7 @@ struct PrimDef {
     double eye_base[2], eye_pre[2];
     double line_width; int stipple;
     double radius; int ngon;
+    int goal = -1;             // ordinal of the goal region this prim draws (-1: none): per-env rectangles (Test*Jitter / Layout)
     int ent = -1, role = -1;   // entity whose colour paints this prim and how (0 darkened, 1 base, 2 lightened x2; -1: fixed colour)
 };
 struct EntityDef {
@@ -78,13 +79,14 @@ struct World {
     // geom.py:116-262 pm_randomise_pose's collision test, on the host: would entity `ent`, with every entity at
     // poses[3 * e .. 3 * e + 2] (x, y, angle; goals: their box centre), touch the arena walls or a shape of an entity
     // whose `enabled` flag is set?  (space.shape_query of each of its shapes: Chipmunk's cpCollide count > 0)
-    bool placement_collides(int ent, const double *poses, const uint8_t *enabled) const;
+    // ent_hw (optional): [n_entities][2] = this env's (h, w) of every goal region (rows of other entities ignored)
+    bool placement_collides(int ent, const double *poses, const uint8_t *enabled, const double *ent_hw = nullptr) const;
     // geom.py:285-341 pm_randomise_all_poses for the entities ents[0..n): draws from the MT19937 stream (key[624], pos)
     // exactly what np.random.RandomState.uniform would (x, y, angle per attempt), entity after entity; limits < 0 = none.
     // Returns the number of rejected attempts, or -1 after max_retries placement failures.
     int randomise_all_poses(double *poses, const int *ents, int n, const uint8_t *ignore, const double arena_lrbt[4],
                             const uint8_t *rand_pos, const uint8_t *rand_rot, const double *pos_limits, const double *rot_limits,
-                            uint32_t *mt_key, int *mt_pos) const;
+                            uint32_t *mt_key, int *mt_pos, const double *ent_hw = nullptr) const;
     // serialise: header + int words + real words (as double; caller narrows to float if needed)
     void serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<double> &rw, std::vector<double> &pw) const;
 };

@@ -18,15 +18,16 @@ class PlacementError(Exception):
     """geom.py:110-113."""
 
 
-def placement_collides(env, ent_id, poses, enabled):
+def placement_collides(env, ent_id, poses, enabled, ent_hw=None):
     poses = np.ascontiguousarray(poses, dtype=np.float64)
     enabled = np.ascontiguousarray(enabled, dtype=np.uint8)
+    hw = None if ent_hw is None else np.ascontiguousarray(ent_hw, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
     return bool(nat.check(env._lib.mgx_world_placement_collides(
-        env._world, int(ent_id), poses.ctypes.data_as(C.POINTER(C.c_double)), enabled.ctypes.data_as(C.POINTER(C.c_uint8)))))
+        env._world, int(ent_id), poses.ctypes.data_as(C.POINTER(C.c_double)), enabled.ctypes.data_as(C.POINTER(C.c_uint8)), hw)))
 
 
 def pm_randomise_pose(env, poses, ent_id, enabled, arena_lrbt, rng, rand_pos=True, rand_rot=True, rel_pos_linf_limit=None,
-                      rel_rot_limit=None, rejection_tests=()):
+                      rel_rot_limit=None, rejection_tests=(), ent_hw=None):
     """geom.py:116-262.  `poses[ent_id]` is updated in place; returns the number of rejected attempts."""
     assert rand_pos or rand_rot, 'need to randomise at least one thing, or placement may be impossible'
     orig = poses[ent_id].copy()
@@ -49,7 +50,7 @@ def pm_randomise_pose(env, poses, ent_id, enabled, arena_lrbt, rng, rand_pos=Tru
             poses[ent_id, 1] = rng.uniform(*pos_y_minmax)
         if rand_rot:
             poses[ent_id, 2] = rng.uniform(rot_min, rot_max)
-        reject = placement_collides(env, ent_id, poses, enabled)
+        reject = placement_collides(env, ent_id, poses, enabled, ent_hw)
         if not reject:
             for rejection_test in rejection_tests:
                 reject = reject or rejection_test(poses)
@@ -65,7 +66,7 @@ def pm_randomise_pose(env, poses, ent_id, enabled, arena_lrbt, rng, rand_pos=Tru
 
 
 def pm_randomise_all_poses(env, poses, entities, arena_lrbt, rng, rand_pos=True, rand_rot=True, rel_pos_linf_limits=None,
-                           rel_rot_limits=None, ignore=(), max_retries=10, rejection_tests=(), native=True):
+                           rel_rot_limits=None, ignore=(), max_retries=10, rejection_tests=(), native=True, ent_hw=None):
     """geom.py:285-341.  entities: the Entity objects to randomise, in order; `ignore`: entities whose shapes never
     count (the reference's ignore_shapes).  `poses` (float64[n_entities, 3], indexed by ent_id) is updated in place.
 
@@ -91,7 +92,8 @@ def pm_randomise_all_poses(env, poses, entities, arena_lrbt, rng, rand_pos=True,
         P8, PD = C.POINTER(C.c_uint8), C.POINTER(C.c_double)
         rc = env._lib.mgx_world_randomise_all_poses(
             env._world, poses.ctypes.data_as(PD), ents, n, ign.ctypes.data_as(P8), arena.ctypes.data_as(PD), rp.ctypes.data_as(P8),
-            rr.ctypes.data_as(P8), pl.ctypes.data_as(PD), rl.ctypes.data_as(PD), key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cpos))
+            rr.ctypes.data_as(P8), pl.ctypes.data_as(PD), rl.ctypes.data_as(PD), key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cpos),
+            None if ent_hw is None else np.ascontiguousarray(ent_hw, dtype=np.float64).ctypes.data_as(PD))
         rng.set_state((kind, key, cpos.value, has_gauss, cached))
         if rc < 0:
             raise PlacementError(env._lib.mgx_last_error().decode())
@@ -104,7 +106,7 @@ def pm_randomise_all_poses(env, poses, entities, arena_lrbt, rng, rand_pos=True,
             enabled[ent.ent_id] = 1
             try:
                 pm_randomise_pose(env, poses, ent.ent_id, enabled, arena_lrbt, rng, rand_pos=rp, rand_rot=rr,
-                                  rel_pos_linf_limit=pl, rel_rot_limit=rl, rejection_tests=rejection_tests)
+                                  rel_pos_linf_limit=pl, rel_rot_limit=rl, rejection_tests=rejection_tests, ent_hw=ent_hw)
             except PlacementError:
                 if retry == max_retries - 1:
                     raise
@@ -115,7 +117,7 @@ def pm_randomise_all_poses(env, poses, entities, arena_lrbt, rng, rand_pos=True,
 
 
 def pm_randomise_all_poses_batch(env, poses, entities, arena_lrbt, rngs, rand_pos=True, rand_rot=True, rel_pos_linf_limits=None,
-                                 rel_rot_limits=None, ignore=()):
+                                 rel_rot_limits=None, ignore=(), ent_hw=None):
     """pm_randomise_all_poses for M envs in one native call: poses float64[M, n_entities, 3] (updated in place), rngs the
     M envs' np.random.RandomState objects, whose MT19937 states are advanced in place through their ctypes address."""
     m, n = len(rngs), len(entities)
@@ -138,7 +140,22 @@ def pm_randomise_all_poses_batch(env, poses, entities, arena_lrbt, rngs, rand_po
     P8, PD = C.POINTER(C.c_uint8), C.POINTER(C.c_double)
     rc = env._lib.mgx_world_randomise_all_poses_batch(
         env._world, m, poses.ctypes.data_as(PD), ents, n, ign.ctypes.data_as(P8), arena.ctypes.data_as(PD), rp.ctypes.data_as(P8),
-        rr.ctypes.data_as(P8), pl.ctypes.data_as(PD), rl.ctypes.data_as(PD), addrs.ctypes.data_as(C.POINTER(C.c_uint64)))
+        rr.ctypes.data_as(P8), pl.ctypes.data_as(PD), rl.ctypes.data_as(PD), addrs.ctypes.data_as(C.POINTER(C.c_uint64)),
+        None if ent_hw is None else np.ascontiguousarray(ent_hw, dtype=np.float64).ctypes.data_as(PD))
     if rc < 0:
         raise PlacementError(env._lib.mgx_last_error().decode())
     return poses
+
+
+def randomise_hw(min_side, max_side, rng, current_hw=None, linf_bound=None):
+    """geom.py:344-360: height and width of a goal region, two draws (h, then w)."""
+    assert min_side <= max_side
+    minima = np.asarray((min_side, min_side))
+    maxima = np.asarray((max_side, max_side))
+    if linf_bound is not None:
+        assert linf_bound == float(linf_bound) and current_hw is not None and len(current_hw) == 2
+        current_hw = np.asarray(current_hw)
+        minima = np.maximum(minima, current_hw - linf_bound)
+        maxima = np.minimum(maxima, current_hw + linf_bound)
+    h, w = rng.uniform(minima, maxima)
+    return h, w

@@ -18,6 +18,20 @@ SHAPE_RAD = ROBOT_RAD * 0.6   # base_env.py:64
 JITTER_PCT = 0.05             # base_env.py:73-75
 JITTER_POS_BOUND = 1 * JITTER_PCT / 2.0
 JITTER_ROT_BOUND = JITTER_PCT * np.pi
+RAND_GOAL_MIN_SIZE, RAND_GOAL_MAX_SIZE = 0.5, 0.8          # base_env.py:68-69
+JITTER_TARGET_BOUND = JITTER_PCT * (RAND_GOAL_MAX_SIZE - RAND_GOAL_MIN_SIZE) / 2   # base_env.py:76
+
+
+def randomise_hw(min_side, max_side, rng, current_hw=None, linf_bound=None):
+    """geom.py:344-360."""
+    minima = np.asarray((min_side, min_side))
+    maxima = np.asarray((max_side, max_side))
+    if linf_bound is not None:
+        current_hw = np.asarray(current_hw)
+        minima = np.maximum(minima, current_hw - linf_bound)
+        maxima = np.minimum(maxima, current_hw + linf_bound)
+    h, w = rng.uniform(minima, maxima)
+    return h, w
 
 
 def _robot(pos, angle):
@@ -98,11 +112,23 @@ class MoveToRegionRef(TaskRef):
 
     def on_reset(self):
         w = self.world
+        minor, full = self.flags.get('rand_poses_minor'), self.flags.get('rand_poses_full')
+        gx, gy, gh, gw = -0.62, -0.17, 0.76, 0.75
+        if minor or full:                                 # move_to_region.py:32-45
+            gh, gw = self.draw('goal_hw', lambda: randomise_hw(RAND_GOAL_MIN_SIZE, RAND_GOAL_MAX_SIZE, self.rng, current_hw=(gh, gw),
+                                                               linf_bound=JITTER_TARGET_BOUND if minor else None))
         goal_colour = 'blue'
         if self.flags.get('rand_goal_colour'):            # move_to_region.py:47-51
-            goal_colour = self.rng.choice(np.asarray(SHAPE_COLOURS, dtype='object'))
-        self.goal = w.add(GoalRegion(-0.62, -0.17, 0.76, 0.75, goal_colour))
-        self.robot = w.add(_robot((0.058, 0.53), -2.13))
+            goal_colour = self.draw('colour', lambda: self.rng.choice(np.asarray(SHAPE_COLOURS, dtype='object')))
+        robot_pose = (0.058, 0.53, -2.13)
+        if self.replay is not None and 'poses' in self.replay:
+            (cx, cy, _), robot_pose = self.replay['poses']
+            gx, gy = cx - gw / 2, cy + gh / 2             # GoalRegion(x, y, h, w): top-left corner of the box around the body
+        self.goal = w.add(GoalRegion(gx, gy, gh, gw, goal_colour))
+        self.robot = w.add(_robot(robot_pose[:2], robot_pose[2]))
+        if (minor or full) and self.replay is None:       # move_to_region.py:63-78
+            lim = dict(rel_pos_linf_limits=JITTER_POS_BOUND, rel_rot_limits=[None, JITTER_ROT_BOUND]) if minor else {}
+            self.jitter([self.goal, self.robot], rand_rot=(False, True), **lim)
 
     def score_on_end_of_traj(self):
         # goal_shape.point_query(robot_pos) -> cpPolyShapePointQuery: dist <= 0
@@ -123,13 +149,24 @@ class MatchRegionsRef(TaskRef):
         robot = _robot((-0.5, 0.1), -math.pi * 1.2)
         target_colour = 'green'
         if self.flags.get('rand_target_colour'):          # match_regions.py:51-58
-            target_colour = self.rng.choice(SHAPE_COLOURS)
-        self.sensor = w.add(GoalRegion(0.1, 0.7, 0.7, 0.6, target_colour))
+            target_colour = self.draw('colour', lambda: self.rng.choice(SHAPE_COLOURS))
+        minor, full = self.flags.get('rand_layout_minor'), self.flags.get('rand_layout_full')
+        gx, gy, gh, gw = 0.1, 0.7, 0.7, 0.6
+        if minor or full:                                 # match_regions.py:63-72
+            gh, gw = self.draw('goal_hw', lambda: randomise_hw(RAND_GOAL_MIN_SIZE, RAND_GOAL_MAX_SIZE, self.rng, current_hw=(gh, gw),
+                                                               linf_bound=JITTER_TARGET_BOUND if minor else None))
         target_types = ['star', 'square']
         target_poses = [(0.8, -0.7, 2.37), (-0.68, 0.72, 1.28)]
         distractor_colours = [c for c in SHAPE_COLOURS if c != target_colour]
         distractor_types = [[], ['pentagon'], ['circle', 'pentagon']]
         distractor_poses = [[], [(-0.05, -0.2, -1.09)], [(-0.75, -0.55, 2.78), (0.3, -0.82, -1.15)]]
+        if self.replay is not None and 'poses' in self.replay:
+            (cx, cy, _), (rx, ry, ra), *sp = self.replay['poses']
+            gx, gy = cx - gw / 2, cy + gh / 2
+            robot = _robot((rx, ry), ra)
+            target_poses, rest = sp[:2], sp[2:]
+            distractor_poses = [[], rest[:1], rest[1:3]]
+        self.sensor = w.add(GoalRegion(gx, gy, gh, gw, target_colour))
         self.target_shapes = [_shape(t, target_colour, (x, y), a) for t, (x, y, a) in zip(target_types, target_poses)]
         self.distractor_shapes = []
         for col, types, poses in zip(distractor_colours, distractor_types, distractor_poses):
@@ -138,6 +175,10 @@ class MatchRegionsRef(TaskRef):
         for e in self.target_shapes + self.distractor_shapes:
             w.add(e)
         self.robot = w.add(robot)
+        if (minor or full) and self.replay is None:       # match_regions.py:166-188: the region is never rotated
+            all_ents = [self.sensor, self.robot, *self.target_shapes, *self.distractor_shapes]
+            lim = dict(rel_pos_linf_limits=JITTER_POS_BOUND, rel_rot_limits=JITTER_ROT_BOUND) if minor else {}
+            self.jitter(all_ents, rand_rot=[False] + [True] * (len(all_ents) - 1), **lim)
 
     def score_on_end_of_traj(self):
         ents = self.target_shapes + self.distractor_shapes

@@ -399,7 +399,10 @@ def test_reset_with_per_env_entity_poses():
 
 JITTER_CASES = [('MoveToCorner', 'TestJitter', {'rand_poses': True}),
                 ('MakeLine', 'TestJitter', {'rand_layout_minor': True}), ('MakeLine', 'TestLayout', {'rand_layout_full': True}),
-                ('ClusterColour', 'TestJitter', {'rand_layout_minor': True}), ('ClusterShape', 'TestLayout', {'rand_layout_full': True})]
+                ('ClusterColour', 'TestJitter', {'rand_layout_minor': True}), ('ClusterShape', 'TestLayout', {'rand_layout_full': True}),
+                ('MoveToRegion', 'TestJitter', {'rand_poses_minor': True}), ('MoveToRegion', 'TestLayout', {'rand_poses_full': True}),
+                ('MoveToRegion', 'TestAll', {'rand_poses_full': True, 'rand_goal_colour': True, 'rand_dynamics': True}),
+                ('MatchRegions', 'TestJitter', {'rand_layout_minor': True}), ('MatchRegions', 'TestLayout', {'rand_layout_full': True})]
 
 
 @pytest.mark.parametrize('task,variant,flags', JITTER_CASES)
@@ -428,10 +431,12 @@ def test_pose_randomisation_matches_oracle(task, variant, flags):
     check_reset(obs, first)
     tape = _tape(47, 2 * ep, n)
     for s in range(2 * ep):
-        obs, _, done, _ = env.step(tape[s])
+        obs, _, done, info = env.step(tape[s])
         obs = obs.cpu().numpy()
         outs = [r.step(tape[s, k]) for k, r in enumerate(refs)]
         if done.all():
+            for k, (_, _, d, inf) in enumerate(outs):           # the score sees this env's own goal rectangle
+                assert d and abs(inf['eval_score'] - info['eval_score'][k]) < 1e-12, (task, k)
             check_reset(obs, [r.reset() for r in refs])
             continue
         got = env.get_bodies()
