@@ -113,8 +113,8 @@ int mgx_world_randomise_all_poses(const mgx_world *w, double *poses, const int *
  * mt19937_state { uint32 key[624]; int pos; } (RandomState._bit_generator.ctypes.state_address), advanced in place */
 int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses, const int *ents, int n, const uint8_t *ignore,
                                         const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
-                                        const double *pos_limits, const double *rot_limits, const uint64_t *mt_state_addr,
-                                        const double *ent_hw /* NULL or [m][n_entities][2] */);
+                                        const double *pos_limits, const double *rot_limits, int limits_per_env /* limits are [m][n] */,
+                                        const uint64_t *mt_state_addr, const double *ent_hw /* NULL or [m][n_entities][2] */);
 /* style.py:28-37 evaluated to RGB8 for entity colour 0..3 (red green blue yellow) in `role` */
 int mgx_world_palette(int colour, int role);
 

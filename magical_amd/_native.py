@@ -81,7 +81,7 @@ def lib():
         'mgx_world_prim_table': [vp, ip, ip, ip],
         'mgx_world_palette': [i32, i32],
         'mgx_world_randomise_all_poses_batch': [vp, i32, dp, ip, i32, C.POINTER(C.c_uint8), dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8),
-                                                dp, dp, C.POINTER(C.c_uint64), dp],
+                                                dp, dp, i32, C.POINTER(C.c_uint64), dp],
         'mgx_world_placement_collides': [vp, i32, dp, C.POINTER(C.c_uint8), dp],
         'mgx_world_randomise_all_poses': [vp, dp, ip, i32, C.POINTER(C.c_uint8), dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), dp, dp,
                                           C.POINTER(C.c_uint32), ip, dp],

@@ -263,7 +263,8 @@ class BaseEnv(abc.ABC):
         reference's on_reset() (after the physics variables, base_env.py:198-214), for env `k` (tasks keep what their
         score needs per env).  Return None (Demo) or a dict; supported keys: 'colours' = {entity: colour name},
         'poses' = {entity: (x, y, angle)}, 'goal_hw' = {goal region: (h, w)},
-        'randomise_poses' = (entities, kwargs of geom.pm_randomise_all_poses) -- the
+        'randomise_poses' = (entities, kwargs of geom.pm_randomise_all_poses), or a list of such stages and callables
+        stage(poses[M, n_entities, 3], ent_hw[M, n_entities, 2] or None, place(entities, **kwargs)) -- the
         pose draws must come last in the reference's on_reset (they do in every task), because they are made after this
         hook returns, for all envs in one native call."""
         return None
@@ -314,9 +315,17 @@ class BaseEnv(abc.ABC):
             if pose_spec is not None:
                 # geom.py pm_randomise_all_poses for all envs being reset, each on its own stream, natively
                 from . import geom
-                ents, kwargs = pose_spec
-                geom.pm_randomise_all_poses_batch(self, batch, ents, self.ARENA_BOUNDS_LRBT, [self.rngs[k] for k in env_idx],
-                                                  ent_hw=ent_hw, **kwargs)
+                rngs = [self.rngs[k] for k in env_idx]
+                stages = pose_spec if isinstance(pose_spec, list) else [pose_spec]
+                for stage in stages:
+                    if callable(stage):
+                        # task-specific step between placements (e.g. move a block onto its region), or a placement whose
+                        # limits depend on the env; gets the poses so far, the envs' goal sizes and a runner for placements
+                        stage(batch, ent_hw, lambda ents, **kw: geom.pm_randomise_all_poses_batch(
+                            self, batch, ents, self.ARENA_BOUNDS_LRBT, rngs, ent_hw=ent_hw, **kw))
+                    else:
+                        ents, kwargs = stage
+                        geom.pm_randomise_all_poses_batch(self, batch, ents, self.ARENA_BOUNDS_LRBT, rngs, ent_hw=ent_hw, **kwargs)
             pose_rows = list(batch)
             if len(self._goal_ent_idx):
                 # the goal regions' rectangles of these envs, back in GoalRegion(x, y, h, w) form: x, y = top-left corner

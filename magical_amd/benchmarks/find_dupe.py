@@ -1,7 +1,8 @@
-"""FindDupe (mirror of magical/benchmarks/find_dupe.py: Demo, TestColour and TestDynamics branches)."""
+"""FindDupe (mirror of magical/benchmarks/find_dupe.py: Demo, TestColour, TestJitter, TestLayout and TestDynamics branches)."""
 import numpy as np
 
 from .. import entities as en
+from .. import geom
 from ..base_env import BaseEnv
 from ._scoring import overlapping_ents
 
@@ -21,27 +22,52 @@ DEFAULT_QUERY_BLOCK_POSE = ((-0.33, -0.49), -0.51)
 class FindDupeEnv(BaseEnv):
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
-        if rand_shapes or rand_count or rand_layout_minor or rand_layout_full:
-            raise NotImplementedError('built: Demo, TestColour, TestDynamics (shape types / counts / layouts need per-env geometry: SURVEY.md §8f)')
-        self.rand_colours = rand_colours
+        if rand_shapes or rand_count:
+            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestLayout, TestDynamics (shape types / counts need per-env geometry: SURVEY.md §8f)')
+        assert not (rand_layout_minor and rand_layout_full)
+        self.rand_colours, self.rand_layout_minor, self.rand_layout_full = rand_colours, rand_layout_minor, rand_layout_full
         self._is_target_env = None
         super().__init__(**kwargs)
 
-    def sample_variation(self, rng, k):   # find_dupe.py:90-95,126-140
-        if not self.rand_colours:
+    def sample_variation(self, rng, k):   # find_dupe.py:90-95 (colours), :101-112 (region size), :157-196 (poses)
+        if not (self.rand_colours or self.rand_layout_minor or self.rand_layout_full):
             return None
-        names = en.SHAPE_COLOUR_NAMES
-        query_colour = rng.choice(names)
-        out_block_colours = rng.choice(names, size=len(self.__outside_blocks) - 1).tolist()
-        out_block_colours.append(query_colour)               # the last outside block always matches the query
-        if self._is_target_env is None:
-            self._is_target_env = np.tile(self.__is_target, (self.n_envs, 1))
-        # __all_blocks = [query block, *outside blocks]; a block is a target iff it has the query's colour and shape
-        self._is_target_env[k] = [True] + [c == query_colour and s == DEFAULT_QUERY_SHAPE
-                                           for c, s in zip(out_block_colours, DEFAULT_OUT_BLOCK_SHAPES)]
-        colours = {self.__sensor_ref: query_colour, self.__all_blocks[0]: query_colour}
-        colours.update(zip(self.__outside_blocks, out_block_colours))
-        return {'colours': colours}
+        var = {}
+        if self.rand_colours:
+            names = en.SHAPE_COLOUR_NAMES
+            query_colour = rng.choice(names)
+            out_block_colours = rng.choice(names, size=len(self.__outside_blocks) - 1).tolist()
+            out_block_colours.append(query_colour)               # the last outside block always matches the query
+            if self._is_target_env is None:
+                self._is_target_env = np.tile(self.__is_target, (self.n_envs, 1))
+            # __all_blocks = [query block, *outside blocks]; a block is a target iff it has the query's colour and shape
+            self._is_target_env[k] = [True] + [c == query_colour and s == DEFAULT_QUERY_SHAPE
+                                               for c, s in zip(out_block_colours, DEFAULT_OUT_BLOCK_SHAPES)]
+            colours = {self.__sensor_ref: query_colour, self.__all_blocks[0]: query_colour}
+            colours.update(zip(self.__outside_blocks, out_block_colours))
+            var['colours'] = colours
+        if self.rand_layout_minor or self.rand_layout_full:
+            minor = self.rand_layout_minor
+            var['goal_hw'] = {self.__sensor_ref: geom.randomise_hw(self.RAND_GOAL_MIN_SIZE, self.RAND_GOAL_MAX_SIZE, rng,
+                                                                   current_hw=DEFAULT_TARGET_REGION_XYHW[2:],
+                                                                   linf_bound=self.JITTER_TARGET_BOUND if minor else None)}
+            sensor, query = self.__sensor_ref, self.__all_blocks[0]
+            all_ents = (sensor, self._robot, *self.__outside_blocks)
+            pos_limits, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if minor else (None, None)
+
+            def place_query(poses, ent_hw, place):
+                # the query block goes onto the (moved) region and is then jittered so that it stays mostly inside it
+                poses[:, query.ent_id, :2] = poses[:, sensor.ent_id, :2]
+                lim = np.maximum(0.0, np.minimum(ent_hw[:, sensor.ent_id, 0], ent_hw[:, sensor.ent_id, 1]) / 2 - self.SHAPE_RAD / 2)
+                if minor:
+                    lim = np.minimum(self.JITTER_POS_BOUND, lim)
+                place([query], rand_pos=True, rand_rot=True, rel_pos_linf_limits=lim[:, None],
+                      rel_rot_limits=np.full((len(lim), 1), np.nan if rot_limit is None else rot_limit), ignore=[sensor])
+            var['randomise_poses'] = [
+                (all_ents, dict(rand_pos=True, rand_rot=[False] + [True] * (len(all_ents) - 1), rel_pos_linf_limits=pos_limits,
+                                rel_rot_limits=rot_limit, ignore=[query])),
+                place_query]
+        return var
 
     def on_reset(self):   # find_dupe.py:72-155
         robot = self._make_robot(*DEFAULT_ROBOT_POSE)

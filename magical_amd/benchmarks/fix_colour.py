@@ -1,7 +1,8 @@
-"""FixColour (mirror of magical/benchmarks/fix_colour.py: Demo, TestColour and TestDynamics branches)."""
+"""FixColour (mirror of magical/benchmarks/fix_colour.py: Demo, TestColour, TestJitter, TestLayout and TestDynamics branches)."""
 import numpy as np
 
 from .. import entities as en
+from .. import geom
 from ..base_env import BaseEnv
 from ._scoring import overlapping_ents
 
@@ -11,34 +12,61 @@ DEFAULT_BLOCK_SHAPES = [en.ShapeType.PENTAGON, en.ShapeType.SQUARE, en.ShapeType
 DEFAULT_BLOCK_POSES = [((0.289, 0.030), 0.307), ((0.133, -0.561), 1.699), ((-0.336, 0.000), -1.529)]
 DEFAULT_REGION_XYHWS = [(-0.032, 0.348, 0.427, 0.468), (0.019, -0.391, 0.460, 0.458), (-0.681, 0.196, 0.498, 0.418)]
 DEFAULT_REGION_COLOURS = [en.ShapeColour.GREEN, en.ShapeColour.GREEN, en.ShapeColour.RED]
+MIN_GOAL_SIZE, MAX_GOAL_SIZE = 0.4, 0.5      # fix_colour.py:13-14
 
 
 class FixColourEnv(BaseEnv):
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
-        if rand_shapes or rand_count or rand_layout_minor or rand_layout_full:
-            raise NotImplementedError('built: Demo, TestColour, TestDynamics (shape types / counts / layouts need per-env geometry: SURVEY.md §8f)')
-        self.rand_colours = rand_colours
+        if rand_shapes or rand_count:
+            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestLayout, TestDynamics (shape types / counts need per-env geometry: SURVEY.md §8f)')
+        assert not (rand_layout_minor and rand_layout_full)
+        self.rand_colours, self.rand_layout_minor, self.rand_layout_full = rand_colours, rand_layout_minor, rand_layout_full
         self._keep_env = None
         super().__init__(**kwargs)
 
-    def sample_variation(self, rng, k):   # fix_colour.py:84-94
-        if not self.rand_colours:
+    def sample_variation(self, rng, k):   # fix_colour.py:84-94 (colours), :102-113 (region sizes), :143-187 (poses)
+        if not (self.rand_colours or self.rand_layout_minor or self.rand_layout_full):
             return None
-        names = en.SHAPE_COLOUR_NAMES
-        region_colours = rng.choice(names, size=len(self._blocks)).tolist()
-        block_colours = list(region_colours)
-        odd_idx = rng.randint(len(block_colours))            # one block gets a colour that is not its region's
-        new_col_idx = rng.randint(len(names) - 1)
-        if names[new_col_idx] == block_colours[odd_idx]:
-            new_col_idx += 1
-        block_colours[odd_idx] = names[new_col_idx]
-        if self._keep_env is None:
-            self._keep_env = np.tile(np.asarray(self._keep, dtype=bool), (self.n_envs, 1))
-        self._keep_env[k] = [b == t for b, t in zip(block_colours, region_colours)]
-        colours = dict(zip(self._sensors, region_colours))
-        colours.update(zip(self._blocks, block_colours))
-        return {'colours': colours}
+        var = {}
+        if self.rand_colours:
+            names = en.SHAPE_COLOUR_NAMES
+            region_colours = rng.choice(names, size=len(self._blocks)).tolist()
+            block_colours = list(region_colours)
+            odd_idx = rng.randint(len(block_colours))            # one block gets a colour that is not its region's
+            new_col_idx = rng.randint(len(names) - 1)
+            if names[new_col_idx] == block_colours[odd_idx]:
+                new_col_idx += 1
+            block_colours[odd_idx] = names[new_col_idx]
+            if self._keep_env is None:
+                self._keep_env = np.tile(np.asarray(self._keep, dtype=bool), (self.n_envs, 1))
+            self._keep_env[k] = [b == t for b, t in zip(block_colours, region_colours)]
+            colours = dict(zip(self._sensors, region_colours))
+            colours.update(zip(self._blocks, block_colours))
+            var['colours'] = colours
+        if self.rand_layout_minor or self.rand_layout_full:
+            minor = self.rand_layout_minor
+            hw_bound = self.JITTER_TARGET_BOUND if minor else None
+            var['goal_hw'] = {s: geom.randomise_hw(MIN_GOAL_SIZE, MAX_GOAL_SIZE, rng, current_hw=xyhw[2:], linf_bound=hw_bound)
+                              for s, xyhw in zip(self._sensors, DEFAULT_REGION_XYHWS)}
+            sensors, blocks, robot = self._sensors, self._blocks, self._robot
+            pos_limits, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if minor else (None, None)
+
+            def place_blocks(poses, ent_hw, place):
+                # every block goes onto its (moved) region, then each is jittered inside its own region
+                for block, sensor in zip(blocks, sensors):
+                    poses[:, block.ent_id, :2] = poses[:, sensor.ent_id, :2]
+                for block, sensor in zip(blocks, sensors):
+                    lim = np.maximum(0.0, np.minimum(ent_hw[:, sensor.ent_id, 0], ent_hw[:, sensor.ent_id, 1]) / 2 - self.SHAPE_RAD)
+                    if minor:
+                        lim = np.minimum(self.JITTER_POS_BOUND, lim)
+                    place([block], rand_pos=True, rand_rot=True, rel_pos_linf_limits=lim[:, None],
+                          rel_rot_limits=np.full((len(lim), 1), np.nan if rot_limit is None else rot_limit), ignore=[sensor])
+            var['randomise_poses'] = [
+                ((*sensors, robot), dict(rand_pos=True, rand_rot=[False] * len(sensors) + [True], rel_pos_linf_limits=pos_limits,
+                                         rel_rot_limits=rot_limit, ignore=blocks)),
+                place_blocks]
+        return var
 
     def on_reset(self):   # fix_colour.py:69-141
         robot = self._make_robot(*DEFAULT_ROBOT_POSE)

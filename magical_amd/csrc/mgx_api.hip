@@ -195,7 +195,8 @@ int mgx_world_randomise_all_poses(const mgx_world *w, double *poses, const int *
 }
 int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses, const int *ents, int n, const uint8_t *ignore,
                                         const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
-                                        const double *pos_limits, const double *rot_limits, const uint64_t *mt_state_addr, const double *ent_hw) {
+                                        const double *pos_limits, const double *rot_limits, int limits_per_env,
+                                        const uint64_t *mt_state_addr, const double *ent_hw) {
     if (!w || !w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
     if (m < 0 || !poses || !ents || n < 1 || !arena_lrbt || !rand_pos || !rand_rot || !pos_limits || !rot_limits || !mt_state_addr)
         return fail(MGX_ERR_ARG, "NULL argument");
@@ -213,7 +214,8 @@ int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses
             uint32_t *key = reinterpret_cast<uint32_t *>((uintptr_t)mt_state_addr[k]);
             int *pos = reinterpret_cast<int *>((uintptr_t)mt_state_addr[k] + 624 * sizeof(uint32_t));
             if (!key || *pos < 0 || *pos > 624) { bad[t] = 1; return; }
-            int rc = w->w.randomise_all_poses(poses + (size_t)k * ne * 3, ents, n, ignore, arena_lrbt, rand_pos, rand_rot, pos_limits, rot_limits, key, pos,
+            const size_t lo = limits_per_env ? (size_t)k * n : 0;
+            int rc = w->w.randomise_all_poses(poses + (size_t)k * ne * 3, ents, n, ignore, arena_lrbt, rand_pos, rand_rot, pos_limits + lo, rot_limits + lo, key, pos,
                                               ent_hw ? ent_hw + (size_t)k * ne * 2 : nullptr);
             if (rc < 0) { bad[t] = 2; return; }
             rej[t] += rc;

@@ -119,10 +119,22 @@ def pm_randomise_all_poses(env, poses, entities, arena_lrbt, rng, rand_pos=True,
 def pm_randomise_all_poses_batch(env, poses, entities, arena_lrbt, rngs, rand_pos=True, rand_rot=True, rel_pos_linf_limits=None,
                                  rel_rot_limits=None, ignore=(), ent_hw=None):
     """pm_randomise_all_poses for M envs in one native call: poses float64[M, n_entities, 3] (updated in place), rngs the
-    M envs' np.random.RandomState objects, whose MT19937 states are advanced in place through their ctypes address."""
+    M envs' np.random.RandomState objects, whose MT19937 states are advanced in place through their ctypes address.
+    The limits are scalars / per-entity lists as in the reference, or float64[M, n] arrays (NaN = no limit) when they
+    differ between envs (a block jittered inside its own env's goal region)."""
     m, n = len(rngs), len(entities)
     lst = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * n
-    pos_limits, rot_limits, rand_pos, rand_rot = lst(rel_pos_linf_limits), lst(rel_rot_limits), lst(rand_pos), lst(rand_rot)
+    rand_pos, rand_rot = lst(rand_pos), lst(rand_rot)
+    per_env = isinstance(rel_pos_linf_limits, np.ndarray) or isinstance(rel_rot_limits, np.ndarray)
+
+    def lim(v):
+        if isinstance(v, np.ndarray):
+            a = np.asarray(v, dtype=np.float64).reshape(m, n)
+        else:
+            a = np.asarray([np.nan if x is None else float(x) for x in lst(v)], dtype=np.float64)
+            a = np.tile(a, (m, 1)) if per_env else a
+        return np.ascontiguousarray(np.where(np.isnan(a), -1.0, a))
+    pl, rl = lim(rel_pos_linf_limits), lim(rel_rot_limits)
     addrs = np.empty(m, dtype=np.uint64)
     for i, rng in enumerate(rngs):
         bg = rng._bit_generator
@@ -133,14 +145,13 @@ def pm_randomise_all_poses_batch(env, poses, entities, arena_lrbt, rngs, rand_po
     for e in ignore:
         ign[e.ent_id] = 1
     u8 = lambda v: np.asarray([1 if x else 0 for x in v], dtype=np.uint8)
-    lim = lambda v: np.asarray([-1.0 if x is None else float(x) for x in v], dtype=np.float64)
-    rp, rr, pl, rl = u8(rand_pos), u8(rand_rot), lim(pos_limits), lim(rot_limits)
+    rp, rr = u8(rand_pos), u8(rand_rot)
     arena = np.asarray(arena_lrbt, dtype=np.float64)
     assert poses.dtype == np.float64 and poses.flags.c_contiguous and poses.shape[0] == m
     P8, PD = C.POINTER(C.c_uint8), C.POINTER(C.c_double)
     rc = env._lib.mgx_world_randomise_all_poses_batch(
         env._world, m, poses.ctypes.data_as(PD), ents, n, ign.ctypes.data_as(P8), arena.ctypes.data_as(PD), rp.ctypes.data_as(P8),
-        rr.ctypes.data_as(P8), pl.ctypes.data_as(PD), rl.ctypes.data_as(PD), addrs.ctypes.data_as(C.POINTER(C.c_uint64)),
+        rr.ctypes.data_as(P8), pl.ctypes.data_as(PD), rl.ctypes.data_as(PD), 1 if per_env else 0, addrs.ctypes.data_as(C.POINTER(C.c_uint64)),
         None if ent_hw is None else np.ascontiguousarray(ent_hw, dtype=np.float64).ctypes.data_as(PD))
     if rc < 0:
         raise PlacementError(env._lib.mgx_last_error().decode())

@@ -61,6 +61,9 @@ class TaskRef:
         self.choices[name] = v = fn()
         return v
 
+    def main_pose(self, ent):
+        return tuple(float(v) for v in self.world_pose(ent.bodies[0]))
+
     def jitter(self, entities, **kw):
         """pm_randomise_all_poses on this (scratch) world; the env then rebuilds the world AT the drawn poses
         (placement_ref.py explains why)."""
@@ -262,23 +265,52 @@ class FindDupeRef(TaskRef):
         out_colours = ['green', 'red', 'red', 'yellow', 'blue', 'yellow']
         query_colour = 'yellow'
         if self.flags.get('rand_colours'):                # find_dupe.py:90-95
-            query_colour = self.rng.choice(SHAPE_COLOURS)
-            out_colours = self.rng.choice(SHAPE_COLOURS, size=len(out_shapes) - 1).tolist()
-            out_colours.append(query_colour)
+            def draw_colours():
+                q = self.rng.choice(SHAPE_COLOURS)
+                return q, self.rng.choice(SHAPE_COLOURS, size=len(out_shapes) - 1).tolist() + [q]
+            query_colour, out_colours = self.draw('colours', draw_colours)
         out_poses = [((-0.066751, 0.7552), -2.9266), ((-0.05195, 0.31468), 1.5418),
                      ((0.57528, -0.46865), -2.2141), ((0.40594, -0.74977), 0.24582),
                      ((0.45254, 0.3681), -1.0834), ((0.76849, -0.10652), 0.10028)]
-        self.sensor = w.add(GoalRegion(-0.72, -0.22, 0.67, 0.72, query_colour))
+        minor, full = self.flags.get('rand_layout_minor'), self.flags.get('rand_layout_full')
+        gx, gy, gh, gw = -0.72, -0.22, 0.67, 0.72
+        if minor or full:                                 # find_dupe.py:101-112
+            gh, gw = self.draw('goal_hw', lambda: randomise_hw(RAND_GOAL_MIN_SIZE, RAND_GOAL_MAX_SIZE, self.rng, current_hw=(gh, gw),
+                                                               linf_bound=JITTER_TARGET_BOUND if minor else None))
+        query_pose = ((-0.33, -0.49), -0.51)
+        if self.replay is not None and 'poses' in self.replay:
+            P = self.replay['poses']
+            (cx, cy, _) = P['sensor']
+            gx, gy = cx - gw / 2, cy + gh / 2
+            robot = _robot(P['robot'][:2], P['robot'][2])
+            out_poses = [((x, y), a) for x, y, a in P['outside']]
+            query_pose = (P['query'][:2], P['query'][2])
+        self.sensor = w.add(GoalRegion(gx, gy, gh, gw, query_colour))
         self.outside_blocks, self.target_set = [], []
         for s, c, (p, a) in zip(out_shapes, out_colours, out_poses):
             blk = w.add(_shape(s, c, p, a))
             self.outside_blocks.append(blk)
             if c == query_colour and s == 'pentagon':
                 self.target_set.append(blk)
-        self.query_block = w.add(_shape('pentagon', query_colour, (-0.33, -0.49), -0.51))
+        self.query_block = w.add(_shape('pentagon', query_colour, *query_pose))
         self.target_set.append(self.query_block)
         self.distractor_set = [b for b in self.outside_blocks if b not in self.target_set]
         self.robot = w.add(robot)
+        if (minor or full) and self.replay is None:       # find_dupe.py:157-196
+            from . import placement_ref as pr
+            all_ents = [self.sensor, self.robot, *self.outside_blocks]
+            lim = dict(rel_pos_linf_limits=JITTER_POS_BOUND, rel_rot_limits=JITTER_ROT_BOUND) if minor else {}
+            pr.randomise_all_poses(w, all_ents, [-1, 1, -1, 1], self.rng, rand_rot=[False] + [True] * (len(all_ents) - 1),
+                                   ignore_shapes=self.query_block.shapes, **lim)
+            # the query block last: onto the (moved) region, then jittered so that it stays mostly inside it
+            query_pos_limit = max(0, min(gh, gw) / 2 - SHAPE_RAD / 2)
+            if minor:
+                query_pos_limit = min(JITTER_POS_BOUND, query_pos_limit)
+            pr.shift_bodies(w, self.query_block.bodies, self.main_pose(self.sensor)[:2], self.main_pose(self.query_block)[2])
+            pr.randomise_pose(w, self.query_block, [-1, 1, -1, 1], self.rng, rel_pos_linf_limit=query_pos_limit,
+                              rel_rot_limit=JITTER_ROT_BOUND if minor else None, ignore=set(self.sensor.shapes))
+            self.choices['poses'] = {'sensor': self.main_pose(self.sensor), 'robot': self.main_pose(self.robot),
+                                     'outside': [self.main_pose(b) for b in self.outside_blocks], 'query': self.main_pose(self.query_block)}
 
     def score_on_end_of_traj(self):
         overlap = self.sensor.get_overlapping_ents([self.query_block, *self.outside_blocks])
@@ -306,13 +338,26 @@ class FixColourRef(TaskRef):
                         (-0.681, 0.196, 0.498, 0.418)]
         region_colours = ['green', 'green', 'red']
         if self.flags.get('rand_colours'):                # fix_colour.py:84-94
-            region_colours = self.rng.choice(SHAPE_COLOURS, size=len(block_colours)).tolist()
-            block_colours = list(region_colours)
-            odd_idx = self.rng.randint(len(block_colours))
-            new_col_idx = self.rng.randint(len(SHAPE_COLOURS) - 1)
-            if SHAPE_COLOURS[new_col_idx] == block_colours[odd_idx]:
-                new_col_idx += 1
-            block_colours[odd_idx] = SHAPE_COLOURS[new_col_idx]
+            def draw_colours():
+                rc = self.rng.choice(SHAPE_COLOURS, size=len(block_colours)).tolist()
+                bc = list(rc)
+                odd_idx = self.rng.randint(len(bc))
+                new_col_idx = self.rng.randint(len(SHAPE_COLOURS) - 1)
+                if SHAPE_COLOURS[new_col_idx] == bc[odd_idx]:
+                    new_col_idx += 1
+                bc[odd_idx] = SHAPE_COLOURS[new_col_idx]
+                return rc, bc
+            region_colours, block_colours = self.draw('colours', draw_colours)
+        minor, full = self.flags.get('rand_layout_minor'), self.flags.get('rand_layout_full')
+        if minor or full:                                 # fix_colour.py:102-113 (MIN / MAX_GOAL_SIZE = 0.4 / 0.5, :13-14)
+            hws = self.draw('goal_hw', lambda: [randomise_hw(0.4, 0.5, self.rng, current_hw=hw, linf_bound=JITTER_TARGET_BOUND if minor else None)
+                                                for _, _, *hw in region_xyhws])
+            region_xyhws = [(x, y, h, w_) for (x, y, _, _), (h, w_) in zip(region_xyhws, hws)]
+        if self.replay is not None and 'poses' in self.replay:
+            P = self.replay['poses']
+            region_xyhws = [(cx - w_ / 2, cy + h / 2, h, w_) for (cx, cy, _), (_, _, h, w_) in zip(P['sensors'], region_xyhws)]
+            robot = _robot(P['robot'][:2], P['robot'][2])
+            block_poses = [((x, y), a) for x, y, a in P['blocks']]
         self.sensors = [w.add(GoalRegion(*xyhw, col)) for col, xyhw in zip(region_colours, region_xyhws)]
         self.blocks, self.target_blocks = [], []
         for s, c, tc, (p, a) in zip(block_shapes, block_colours, region_colours, block_poses):
@@ -322,6 +367,23 @@ class FixColourRef(TaskRef):
         for b in self.blocks:
             w.add(b)
         self.robot = w.add(robot)
+        if (minor or full) and self.replay is None:       # fix_colour.py:143-187
+            from . import placement_ref as pr
+            n = len(self.sensors)
+            lim = dict(rel_pos_linf_limits=JITTER_POS_BOUND, rel_rot_limits=JITTER_ROT_BOUND) if minor else {}
+            block_shapes_all = [sh for b in self.blocks for sh in b.shapes]
+            pr.randomise_all_poses(w, [*self.sensors, self.robot], [-1, 1, -1, 1], self.rng, rand_rot=[False] * n + [True],
+                                   ignore_shapes=block_shapes_all, **lim)
+            for block, sensor in zip(self.blocks, self.sensors):      # blocks onto their regions ...
+                pr.shift_bodies(w, block.bodies, self.main_pose(sensor)[:2], self.main_pose(block)[2])
+            for block, sensor, (_, _, sh, sw) in zip(self.blocks, self.sensors, region_xyhws):   # ... then jittered inside them
+                block_pos_limit = max(0, min(sh, sw) / 2 - SHAPE_RAD)
+                if minor:
+                    block_pos_limit = min(JITTER_POS_BOUND, block_pos_limit)
+                pr.randomise_pose(w, block, [-1, 1, -1, 1], self.rng, rel_pos_linf_limit=block_pos_limit,
+                                  rel_rot_limit=JITTER_ROT_BOUND if minor else None, ignore=set(sensor.shapes))
+            self.choices['poses'] = {'sensors': [self.main_pose(s_) for s_ in self.sensors], 'robot': self.main_pose(self.robot),
+                                     'blocks': [self.main_pose(b) for b in self.blocks]}
 
     def score_on_end_of_traj(self):
         for sensor, tgt in zip(self.sensors, self.target_blocks):
