@@ -75,10 +75,13 @@ template <int LAYOUT> __device__ __forceinline__ void store_pre(uint8_t *frame, 
     }
     px[0] = d0; px[1] = d1; px[2] = d2;
 }
-template <int LAYOUT> __device__ __forceinline__ void store_rmw(uint8_t *frame, int X, int Y, int c, bool fill) {
-    OldPx o{0, 0, 0};
-    if (layout_needs_old<LAYOUT>(fill)) o = load_old<LAYOUT>(frame, X, Y);
-    store_pre<LAYOUT>(frame, X, Y, c, fill, o);
+// phases Q / E: the pixel has already been shifted by phase T; write only the bytes that hold the new frame
+template <int LAYOUT> __device__ __forceinline__ void store_patch(uint8_t *frame, int X, int Y, int c, bool fill) {
+    uint8_t *px = frame + (long)(Y * LORES + X) * 12;
+    const uint8_t r = c & 0xFF, g = (c >> 8) & 0xFF, b = (c >> 16) & 0xFF;
+    const int first = LAYOUT == LAY_SLOT0 ? 0 : (fill ? (LAYOUT == LAY_STACK4 ? 0 : 3) : 9);   // after a reset every frame of the stack
+    const int last = LAYOUT == LAY_SLOT0 ? 3 : 12;
+    for (int k = first; k < last; k += 3) { px[k] = r; px[k + 1] = g; px[k + 2] = b; }
 }
 __device__ __forceinline__ void store_frame_px(uint8_t *frame, int X, int Y, int c) {
     uint8_t *q = frame + (long)(Y * LORES + X) * 3;
@@ -321,21 +324,20 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
             int col[G];
 #pragma unroll
             for (int v = 0; v < G; v++) col[v] = 0;
-            uint32_t qbits = 0;
 #pragma unroll 1
             for (int u = 0; u < G; u++) {
                 const int tile = seq_tile(g + u);
                 bool queued;
                 const int c = do_tile(tile, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty, queued);
-                if (queued) qbits |= 1u << u;
 #pragma unroll
                 for (int v = 0; v < G; v++) col[v] = u == v ? c : col[v];
             }
 #pragma unroll
             for (int u = 0; u < G; u++) {
                 const int tile = seq_tile(g + u);
-                if (!((qbits >> u) & 1u))
-                    store_pre<LAYOUT>(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty, col[u], fill, cur[u]);
+                // queued pixels are shifted here too (with a placeholder for the new frame's bytes) so that phases Q / E
+                // only patch those bytes in, without reading the pixel back
+                store_pre<LAYOUT>(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty, col[u], fill, cur[u]);
             }
         }
     }
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
                 continue;
             }
             const int c = pixel_finish(sums);
-            if (LAYOUT == LAY_FRAME) store_frame_px(frame, X, Y, c); else store_rmw<LAYOUT>(frame, X, Y, c, fill);
+            if (LAYOUT == LAY_FRAME) store_frame_px(frame, X, Y, c); else store_patch<LAYOUT>(frame, X, Y, c, fill);
         }
         __syncthreads();
         // phase E: the few samples whose fp32 result could not be guaranteed, with the fp64 painter
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
             const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;
             const uint64_t rec = e_sums[j];
             const int c = pixel_finish(pixel_add_exact(rs, X, Y, q_mask[i], q_base[i], rec & 0xFFFFFFFFFFull, (uint32_t)(rec >> 40)));
-            if (LAYOUT == LAY_FRAME) store_frame_px(frame, X, Y, c); else store_rmw<LAYOUT>(frame, X, Y, c, fill);
+            if (LAYOUT == LAY_FRAME) store_frame_px(frame, X, Y, c); else store_patch<LAYOUT>(frame, X, Y, c, fill);
         }
         __syncthreads();
         if (!more) break;
