@@ -1,0 +1,31 @@
+/* mgx_debug.h -- development / test hooks of libmagical_hip.so.  NOT part of the drop-in boundary (include/mgx.h):
+ * nothing in magical_amd/ calls these; tests/ and tools/ do.
+ *
+ * All return MGX_OK.  Defaults restore the shipped behaviour. */
+#ifndef MGX_DEBUG_H
+#define MGX_DEBUG_H
+#include "mgx.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* k_raster: entries of the undecided-pixel queue / of the uncertain-sample record list actually used (<= the compiled
+ * capacities, clamped).  tests/test_gpu_parity.py shrinks them to 1 to force the overflow rounds. */
+int mgx_engine_debug_raster_qcap(mgx_engine *e, int n);
+int mgx_engine_debug_raster_ecap(mgx_engine *e, int n);
+/* k_raster: DEVICE u64 [N][16] written by lane 0 of every workgroup at the end of each phase (100 MHz wall clock since
+ * kernel start; [5] = queued pixels); NULL = off.  tools/raster_probe.py */
+int mgx_engine_debug_raster_clocks(mgx_engine *e, void *buf);
+/* k_raster, -DMGX_RASTER_PROBE builds only: return after phase `phase` (1 S, 2 C, 3 T, 4 Q+E; 9 = no per-pixel
+ * classification), 0 = run everything.  tools/raster_phase_probe.py */
+int mgx_engine_debug_raster_stop(mgx_engine *e, int phase);
+/* k_step, -DMGX_STEP_PROBE builds only: DEVICE u64 [workgroups][32] shader cycles per phase; NULL = off.
+ * tools/step_phase_probe.py */
+int mgx_engine_debug_step_clocks(mgx_engine *e, void *buf);
+/* k_step: override the solver iteration count (-1 = the reference's 10).  tools/step_probe.py */
+int mgx_engine_debug_iterations(mgx_engine *e, int it);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
