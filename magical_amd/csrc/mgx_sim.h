@@ -624,12 +624,27 @@ template <typename R, typename P> MGX_HD void joint_apply_impulse(Env<R, P> &e, 
     }
 }
 
-// cpArbiterApplyImpulse for one contact point
-template <typename R, typename P> MGX_HD void contact_apply_impulse(Env<R, P> &e, int k) {
-    int ab = E_I(kab, k), a = ab & 0xFF, b = ab >> 8;
-    R nx = E_R(knx, k), ny = E_R(kny, k);
-    R r1x = E_R(kr1x, k), r1y = E_R(kr1y, k), r2x = E_R(kr2x, k), r2y = E_R(kr2y, k);
-    R ma = T_R(body_minv, a), ia = T_R(body_iinv, a), mb = T_R(body_minv, b), ib = T_R(body_iinv, b);
+// cpArbiterApplyImpulse for one contact point, split so that the constants of contact k + 1 can be fetched from LDS
+// while contact k is being computed (they never alias the velocities contact k writes): ContactK = everything that does
+// not depend on the bodies' current velocities.
+template <typename R> struct ContactK {
+    int a, b;
+    R nx, ny, r1x, r1y, r2x, r2y, ma, ia, mb, ib, n_mass, t_mass, bias, mu, jb, jn, jt;
+};
+template <typename R, typename P> MGX_HD ContactK<R> contact_load(const Env<R, P> &e, int k) {
+    ContactK<R> c;
+    int ab = E_I(kab, k);
+    c.a = ab & 0xFF; c.b = ab >> 8;
+    c.nx = E_R(knx, k); c.ny = E_R(kny, k);
+    c.r1x = E_R(kr1x, k); c.r1y = E_R(kr1y, k); c.r2x = E_R(kr2x, k); c.r2y = E_R(kr2y, k);
+    c.ma = T_R(body_minv, c.a); c.ia = T_R(body_iinv, c.a); c.mb = T_R(body_minv, c.b); c.ib = T_R(body_iinv, c.b);
+    c.n_mass = E_R(knm, k); c.t_mass = E_R(ktm, k); c.bias = E_R(kbias, k); c.mu = E_R(kmu, k);
+    c.jb = E_R(kjb, k); c.jn = E_R(kjn, k); c.jt = E_R(kjt, k);
+    return c;
+}
+template <typename R, typename P> MGX_HD void contact_apply_loaded(Env<R, P> &e, int k, const ContactK<R> &c) {
+    const int a = c.a, b = c.b;
+    const R nx = c.nx, ny = c.ny, r1x = c.r1x, r1y = c.r1y, r2x = c.r2x, r2y = c.r2y, ma = c.ma, ia = c.ia, mb = c.mb, ib = c.ib;
     Vel<R> va = LOADV(a), vb = LOADV(b);
     R vbax = E_R(vbx, a), vbay = E_R(vby, a), wba = E_R(wb, a);
     R vbbx = E_R(vbx, b), vbby = E_R(vby, b), wbb = E_R(wb, b);
@@ -640,18 +655,18 @@ template <typename R, typename P> MGX_HD void contact_apply_impulse(Env<R, P> &e
     R vrx = (vb.vx - r2y * vb.w) - (va.vx - r1y * va.w), vry = (vb.vy + r2x * vb.w) - (va.vy + r1x * va.w);
     R vrn = vrx * nx + vry * ny;
     R vrt = -vrx * ny + vry * nx;                           // dot(vr, perp(n))
-    R n_mass = E_R(knm, k);
-    R jbn = (E_R(kbias, k) - vbn) * n_mass;
-    R jbn_old = E_R(kjb, k);
+    R n_mass = c.n_mass;
+    R jbn = (c.bias - vbn) * n_mass;
+    R jbn_old = c.jb;
     R jb_new = r_max(jbn_old + jbn, R(0));
     E_R(kjb, k) = jb_new;
     R jn = -vrn * n_mass;                                   // bounce = 0 (elasticity 0 everywhere)
-    R jn_old = E_R(kjn, k);
+    R jn_old = c.jn;
     R jn_new = r_max(jn_old + jn, R(0));
     E_R(kjn, k) = jn_new;
-    R jt_max = E_R(kmu, k) * jn_new;
-    R jt = -vrt * E_R(ktm, k);
-    R jt_old = E_R(kjt, k);
+    R jt_max = c.mu * jn_new;
+    R jt = -vrt * c.t_mass;
+    R jt_old = c.jt;
     R jt_new = r_clamp(jt_old + jt, -jt_max, jt_max);
     E_R(kjt, k) = jt_new;
     R jbx = nx * (jb_new - jbn_old), jby = ny * (jb_new - jbn_old);
@@ -662,6 +677,9 @@ template <typename R, typename P> MGX_HD void contact_apply_impulse(Env<R, P> &e
     va.vx -= jx * ma; va.vy -= jy * ma; va.w -= ia * (r1x * jy - r1y * jx);
     vb.vx += jx * mb; vb.vy += jy * mb; vb.w += ib * (r2x * jy - r2y * jx);
     STOREV(a, va); STOREV(b, vb);
+}
+template <typename R, typename P> MGX_HD void contact_apply_impulse(Env<R, P> &e, int k) {
+    contact_apply_loaded(e, k, contact_load(e, k));
 }
 
 // ---------------------------------------------------------------- solve
@@ -943,7 +961,14 @@ template <typename R, typename P> MGX_HD void solve_iter_publish(Env<R, P> &e, S
 template <typename R, typename P> MGX_HD void solve_iter_contacts(Env<R, P> &e, SolveCtx<R> &c, int lane) {
     if (!c.has_contacts || lane != 0) return;
     int nk = E_I(misc, M_NK);
-    for (int k = 0; k < nk; k++) contact_apply_impulse(e, k);
+    if (nk == 0) return;
+    ContactK<R> cur = contact_load(e, 0);
+    for (int k = 0; k < nk; k++) {
+        // the next contact's constants are in flight while this one's dependent chain runs
+        const ContactK<R> nxt = contact_load(e, k + 1 < nk ? k + 1 : k);
+        contact_apply_loaded(e, k, cur);
+        cur = nxt;
+    }
 }
 template <typename R, typename P> MGX_HD void solve_iter_joints(Env<R, P> &e, SolveCtx<R> &c, int lane, int nl) {
     if (c.has_contacts) { if (lane == 0) ri_load_vel(e, c); bi_load_vel(e, c); }
