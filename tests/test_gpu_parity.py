@@ -130,6 +130,42 @@ def test_determinism_and_lockstep():
     assert torch.equal(sp, sp[:, :1].expand_as(sp))
 
 
+def _variant_names():
+    import magical_amd
+    magical_amd.register_envs()
+    return [n for n in magical_amd.ALL_REGISTERED_ENVS if n.count('-') == 2 and 'DebugReward' not in n]   # <Task>-<Variant>-v0
+
+
+@pytest.mark.parametrize('env_name', _variant_names())
+def test_rollouts(env_name):
+    """The reference's own test (tests/test_rollout_preproc.py:17-36) for every task variant: seeded envs roll out
+    trajectories of the registered length, twice, with sampled actions.  Variants that need per-env collision
+    geometry are registered but not built: they must say so."""
+    import magical_amd
+    built = not any(v in env_name for v in ('TestShape', 'TestCountPlus', 'TestAll')) or env_name.startswith('MoveToRegion')
+    if not built:
+        with pytest.raises(NotImplementedError):
+            magical_amd.make(env_name, n_envs=2, device='cuda:0')
+        return
+    env = magical_amd.make(env_name, n_envs=3, device='cuda:0', auto_reset=False)
+    try:
+        env.seed(7)
+        rng = np.random.RandomState(42)
+        env.reset()
+        for _ in range(2):
+            done = np.zeros(3, dtype=bool)
+            traj_len = 0
+            while not done.any():
+                action = np.array([env.action_space.sample(rng) for _ in range(3)], dtype=np.int32)
+                obs, rew, done, info = env.step(action)
+                traj_len += 1
+            assert done.all() and traj_len == env.max_episode_steps
+            assert np.all((info['eval_score'] >= 0) & (info['eval_score'] <= 1)) and float(rew.sum()) == 0.0
+            env.reset()
+    finally:
+        env.close()
+
+
 @pytest.mark.parametrize('n', [1, 5, 67, 2049])
 def test_ragged_batch_sizes(n):
     """Batch sizes that do not fill a wavefront / a multiple of 8 workgroups: every env equals env k of a big batch
