@@ -386,7 +386,7 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
         int off_tiles = even(2 * ro.n_d + ro.n_i);
         e->rdev.off_tiles = off_tiles;
         // per-tile (u64 mask + i32 base) + queue (u64 mask + 2 x i32) + counters + overflow bitmap + phase E records (u64 sums, u16 entry)
-        int extra = N_TILES * 3 + QCAP * 4 + 4 + OVF_WORDS + ECAP * 2 + ECAP / 2;
+        int extra = N_TILES * 3 + QCAP * 4 + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2;
         e->rdev.qcap = QCAP; e->rdev.ecap = ECAP;
         e->lds_raster = (size_t)(total + off_tiles + extra) * 4;
         // as many workgroups per CU as LDS allows (512 B allocation slack), between 3 and 5

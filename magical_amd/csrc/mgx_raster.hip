@@ -194,11 +194,19 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
     uint64_t *q_mask = reinterpret_cast<uint64_t *>(tile_base + N_TILES);
     int32_t *q_pix = reinterpret_cast<int32_t *>(q_mask + QCAP);
     int32_t *q_base = q_pix + QCAP;
-    int32_t *q_count = q_base + QCAP;              // [0] entries pushed, [1] "some pixel did not fit" flag, [2] entries for phase E
-    uint32_t *q_ovf = reinterpret_cast<uint32_t *>(q_count + 4);   // bitmap of the pixels that did not fit
+    // [0] entries pushed, [1] "some pixel did not fit" flag, [2] entries for phase E, [3] / [4] entries with / without a
+    // line loop among their prims (filled from the two ends of the queue so that a wavefront mostly runs one kind),
+    // [6..7] bit mask of the line-loop prims
+    int32_t *q_count = q_base + QCAP;
+    uint32_t *q_ovf = reinterpret_cast<uint32_t *>(q_count + 8);   // bitmap of the pixels that did not fit
     uint64_t *e_sums = reinterpret_cast<uint64_t *>(q_ovf + OVF_WORDS);   // phase E: partial sums | uncertain samples << 40
     uint16_t *e_list = reinterpret_cast<uint16_t *>(e_sums + ECAP);       // phase E: queue entry of each record
-    if (tid == 0) { q_count[0] = 0; q_count[1] = 0; q_count[2] = 0; }
+    if (tid == 0) {
+        q_count[0] = 0; q_count[1] = 0; q_count[2] = 0; q_count[3] = 0; q_count[4] = 0;
+        uint64_t lm = 0;
+        for (int k = 0; k < h->n_prims; k++) if (rs.prim_kind(k) == PR_LINELOOP) lm |= 1ull << k;
+        *reinterpret_cast<uint64_t *>(q_count + 6) = lm;
+    }
     for (int i = tid; i < OVF_WORDS; i += 256) q_ovf[i] = 0;
     // phase S: screen-space setup (lane per body, lane per primitive, lane per primitive again for the item list)
     raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
@@ -244,6 +252,10 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
     static_assert(N_TILES % 4 == 0, "tiles per wave");
     const int qcap = t.qcap, ecap = t.ecap;
     PROBE(unsigned long long pr_gather = 0, pr_class = 0, pr_items = 0, pr_tiles = 0; const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();)
+    // a free queue entry (capacity already checked): pixels with a line loop among their prims from the front, the others
+    // from the back
+    const uint64_t line_mask = *reinterpret_cast<const uint64_t *>(q_count + 6);
+    auto queue_slot = [&](uint64_t mixed) { return (mixed & line_mask) ? atomicAdd(&q_count[3], 1) : qcap - 1 - atomicAdd(&q_count[4], 1); };
     // classify the pixels of one tile: returns the colour; `queued` when the pixel must wait for phase Q
     auto do_tile = [&](int tile, int X, int Y, bool &queued) -> int {
         const uint64_t tmixed = tile_mixed[tile];
@@ -271,8 +283,8 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
         if (st.mixed != 0) {
             // undecided pixel: queue it for phase Q so that finished lanes do not wait for it
             queued = true;
-            const int slot = atomicAdd(&q_count[0], 1);
-            if (slot < qcap) {
+            if (atomicAdd(&q_count[0], 1) < qcap) {
+                const int slot = queue_slot(st.mixed);
                 q_mask[slot] = st.mixed; q_pix[slot] = X | (Y << 8); q_base[slot] = st.base;
             } else {
                 const int p = Y * LORES + X;
@@ -350,9 +362,10 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
     // their tile's prim set (a superset of the pixel's, same result) for another round.
     int nq_total = 0;
     for (;;) {
-        const int nq = q_count[0] < qcap ? q_count[0] : qcap;
+        const int n_line = q_count[3], nq = n_line + q_count[4];
         nq_total += nq;
-        for (int i = tid; i < nq; i += 256) {
+        for (int j = tid; j < nq; j += 256) {
+            const int i = j < n_line ? j : qcap - 1 - (j - n_line);
             const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;
             uint32_t unc;
             const uint64_t sums = pixel_resolve_fast(rs, X, Y, q_mask[i], q_base[i], unc);
@@ -383,16 +396,16 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
         }
         __syncthreads();
         if (!more) break;
-        if (tid == 0) { q_count[0] = 0; q_count[1] = 0; q_count[2] = 0; }
+        if (tid == 0) { q_count[0] = 0; q_count[1] = 0; q_count[2] = 0; q_count[3] = 0; q_count[4] = 0; }
         __syncthreads();
         for (int w = tid; w < OVF_WORDS; w += 256) {
             uint32_t bits = q_ovf[w];
             while (bits) {
                 const int b = __ffs(bits) - 1;
-                const int slot = atomicAdd(&q_count[0], 1);
-                if (slot >= qcap) { q_count[1] = 1; break; }
+                if (atomicAdd(&q_count[0], 1) >= qcap) { q_count[1] = 1; break; }
                 const int p = w * 32 + b, X = p % LORES, Y = p / LORES;
                 const int tile = (Y / TILE_H) * TILES_X + X / TILE_W;
+                const int slot = queue_slot(tile_mixed[tile]);
                 q_mask[slot] = tile_mixed[tile]; q_pix[slot] = X | (Y << 8); q_base[slot] = tile_base[tile];
                 bits &= bits - 1;
             }
