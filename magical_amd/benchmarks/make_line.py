@@ -40,6 +40,38 @@ def longest_line(points, inlier_dist, max_separation):
     return best
 
 
+def longest_line_batch(points, inlier_dist, max_separation):
+    """longest_line() for M envs at once: points float64[M, n, 2] -> int[M].  Every arithmetic step is the same numpy
+    primitive on the same operands as in the per-env code (1-D norm through row_norm = BLAS ddot, the projection through
+    np.matmul's small-matrix kernel, the point-line distances elementwise), so the results are bit-identical
+    (tests/test_host_api.py checks that against longest_line on random and degenerate inputs)."""
+    M, npts = points.shape[0], points.shape[1]
+    best = np.full(M, min(1, npts), dtype=np.int64)
+    for i in range(npts - 1):
+        for j in range(i + 1, npts):
+            offs = points - points[:, i, None, :]                               # [M, n, 2]
+            pj_off = offs[:, j]                                                 # [M, 2]
+            with np.errstate(divide='ignore', invalid='ignore'):
+                pj_unit = pj_off / row_norm(pj_off)[:, None]
+                proj_lens = np.squeeze(offs @ pj_unit[:, :, None], axis=2)      # [M, n]
+                dists = np.linalg.norm(offs - proj_lens[:, :, None] * pj_unit[:, None, :], axis=2)
+                inlier = dists <= inlier_dist                                   # NaN (coincident points) -> no inliers
+            # sorted projections of the inliers, the others pushed to the end
+            lens = np.sort(np.where(inlier, proj_lens, np.inf), axis=1)
+            n_in = inlier.sum(axis=1)
+            with np.errstate(invalid='ignore'):
+                close = np.abs(np.diff(lens, axis=1)) <= max_separation         # inf - inf = NaN -> False
+            close &= np.arange(1, npts)[None, :] < n_in[:, None]                # only gaps between two inliers
+            run = np.zeros(M, dtype=np.int64)
+            longest = np.zeros(M, dtype=np.int64)
+            for k in range(npts - 1):
+                run = np.where(close[:, k], run + 1, 0)
+                longest = np.maximum(longest, run)
+            cand = np.where(n_in > best, longest + 1, 0)
+            best = np.maximum(best, cand)
+    return best
+
+
 class MakeLineEnv(BaseEnv):
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
@@ -73,11 +105,8 @@ class MakeLineEnv(BaseEnv):
 
     def score_on_end_of_traj(self, poses):   # make_line.py:142-152
         bodies = [b.body for b in self._blocks]
-        out = np.empty(poses.shape[0], dtype=np.float64)
         max_line_len = len(bodies)
         min_line_len = max(max_line_len - 2, 2)
-        for m in range(poses.shape[0]):
-            points = np.ascontiguousarray(poses[m, bodies, :2], dtype='float64')
-            line_len = longest_line(points, self.inlier_dist, self.max_sep)
-            out[m] = max(line_len - min_line_len, 0) / (max_line_len - min_line_len)
-        return out
+        points = np.ascontiguousarray(poses[:, bodies, :2], dtype='float64')
+        line_len = longest_line_batch(points, self.inlier_dist, self.max_sep)
+        return np.maximum(line_len - min_line_len, 0) / (max_line_len - min_line_len)

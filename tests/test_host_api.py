@@ -197,3 +197,24 @@ def test_native_pose_sampler_matches_python_and_numpy_stream():
         for e in ents:
             assert not geom.placement_collides(Shim, e.ent_id, p1, en_all)
     L.mgx_world_destroy(w)
+
+
+def test_make_line_batched_score_is_bit_identical():
+    """longest_line_batch == longest_line (the per-env mirror of make_line.py:31-71) on random layouts, near-collinear
+    layouts around the inlier threshold, and degenerate ones (coincident points)."""
+    from magical_amd.benchmarks.make_line import longest_line, longest_line_batch
+    rs = np.random.RandomState(0)
+    inlier, sep = 0.12 * 1.5, 0.12 * 3.5
+    pts = [rs.uniform(-1, 1, size=(4000, 4, 2))]
+    base = rs.uniform(-0.8, 0.8, size=(4000, 1, 2)); d = rs.uniform(-1, 1, size=(4000, 1, 2)); d /= np.linalg.norm(d, axis=2, keepdims=True)
+    t = np.sort(rs.uniform(0, 1.2, size=(4000, 4, 1)), axis=1)
+    near = base + t * d + rs.normal(0, 0.12, size=(4000, 4, 2)) * rs.choice([0.0, 0.5, 1.0, 1.5], size=(4000, 1, 1))
+    pts.append(near)
+    deg = rs.uniform(-1, 1, size=(200, 4, 2)); deg[:, 1] = deg[:, 0]; deg[:100, 3] = deg[:100, 2]
+    pts.append(deg)
+    for p in pts:
+        got = longest_line_batch(np.ascontiguousarray(p), inlier, sep)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            want = np.array([longest_line(np.ascontiguousarray(q), inlier, sep) for q in p])
+        assert np.array_equal(got, want), np.nonzero(got != want)[0][:5]
+        assert len(np.unique(want)) >= 2
