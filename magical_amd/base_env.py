@@ -226,7 +226,9 @@ class BaseEnv(abc.ABC):
         if not self._warm:
             # the first pose read-back loads torch's gather / copy kernels (tens of ms, once per process); pay for it
             # here rather than in the middle of the first rollout
-            self.get_poses(np.arange(self.n_envs))
+            idx = np.arange(self.n_envs)
+            self._scoring_envs = idx
+            self.score_on_end_of_traj(self.get_poses(idx))      # likewise the scoring path (numpy / BLAS / shape-table set-up)
             self._warm = True
         return self._observe(fill_all=True)
 

@@ -76,10 +76,16 @@ def overlapping_ents(env, goal, ents, poses):
     for k, ent in enumerate(ents):
         pose = poses[:, ent.body, :]
         inside = (l <= pose[:, 0]) & (r >= pose[:, 0]) & (b <= pose[:, 1]) & (t >= pose[:, 1])
-        ok = inside.copy()
         if not hasattr(ent, '_shapes_cache'):
             ent._shapes_cache = entity_shapes(env, ent)
+        # the shape tests only matter where the body position is inside the box: evaluate them on those envs alone
+        sel = np.nonzero(inside)[0]
+        if len(sel) == 0:
+            continue
+        sub_pose = pose[sel]
+        sub_bb = tuple(v[sel] if isinstance(v, np.ndarray) and v.ndim else v for v in bb)
+        ok = np.ones(len(sel), dtype=bool)
         for kind, radius, verts in ent._shapes_cache:
-            ok &= _shape_hits_box(kind, radius, verts, pose, bb)
-        out[:, k] = ok
+            ok &= _shape_hits_box(kind, radius, verts, sub_pose, sub_bb)
+        out[sel, k] = ok
     return out
