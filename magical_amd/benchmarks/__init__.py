@@ -175,7 +175,8 @@ def register_envs():
         if parsed.is_test:
             train_to_test.setdefault(parsed.demo_env_name, []).append(parsed.env_name)
     DEMO_ENVS_TO_TEST_ENVS_MAP.update(sorted((k, tuple(v)) for k, v in train_to_test.items()))
-    # MoveToCorner-Demo-DebugReward[-<preproc>]-v0 (benchmarks/__init__.py:1021-1047): names only
+    # MoveToCorner-Demo-DebugReward[-<preproc>]-v0 (benchmarks/__init__.py:1021-1047).  As in the reference, the
+    # preprocessor-suffixed names point at the plain env class too (its registration loop never applies the wrapper)
     for name in ['MoveToCorner-Demo-DebugReward-v0'] + [f'MoveToCorner-Demo-DebugReward-{p}-v0' for p in AVAILABLE_PREPROCESSORS]:
         ALL_REGISTERED_ENVS.append(name)
         _SPECS[name] = dict(module='move_to_corner', cls='MoveToCornerEnv', ep_len=80, flags=(), debug_reward=True, preproc=None)
@@ -202,8 +203,6 @@ def make(name, n_envs=1, device='cuda:0', **kwargs):
     if name not in _SPECS:
         raise KeyError(f"unknown MAGICAL env '{name}' (see magical_amd.ALL_REGISTERED_ENVS)")
     spec = _SPECS[name]
-    if spec['debug_reward']:
-        raise NotImplementedError('DebugReward envs are an RL-debugging aid of the reference and are not built')
     preproc = spec['preproc']
     if preproc is not None and preproc not in _BUILT_PREPROCESSORS:
         raise NotImplementedError(f"preprocessor '{preproc}' is registered but not built yet (built: {_BUILT_PREPROCESSORS})")
@@ -212,6 +211,8 @@ def make(name, n_envs=1, device='cuda:0', **kwargs):
     from .preproc import wrap_preproc
     cls = wrap_preproc(env_cls, preproc)
     env_kwargs = dict(COMMON_KWARGS, max_episode_steps=spec['ep_len'], **{f: True for f in spec['flags']})
+    if spec['debug_reward']:
+        env_kwargs['debug_reward'] = True
     env_kwargs.update(kwargs)
     env = cls(n_envs=n_envs, device=device, **env_kwargs)
     env.spec_name = name

@@ -1,5 +1,6 @@
 """MoveToCorner (mirror of magical/benchmarks/move_to_corner.py: Demo, TestColour and TestDynamics branches)."""
 import math
+import warnings
 
 import numpy as np
 
@@ -10,10 +11,36 @@ from ._scoring import row_norm
 
 class MoveToCornerEnv(BaseEnv):
     def __init__(self, rand_shape_colour=False, rand_shape_type=False, rand_poses=False, debug_reward=False, **kwargs):
-        if rand_shape_type or debug_reward:
-            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestDynamics (shape types need per-env geometry: SURVEY.md §8f)')
-        self.rand_shape_colour, self.rand_poses = rand_shape_colour, rand_poses
+        if rand_shape_type:
+            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestDynamics, DebugReward (shape types need per-env geometry: SURVEY.md §8f)')
+        self.rand_shape_colour, self.rand_poses, self.debug_reward = rand_shape_colour, rand_poses, debug_reward
+        if debug_reward:     # move_to_corner.py:25-29
+            warnings.warn('DEBUG REWARD ENABLED IN MOVE-TO-CORNER ENV! This reward is ONLY intended for training RL algorithms '
+                          "during debugging, so don't forget to disable it when benchmarking IL")
         super().__init__(**kwargs)
+
+    def step(self, actions):   # move_to_corner.py:77-98: a dense, heavily shaped reward instead of 0, computed on the device
+        obs, rew, done, info = super().step(actions)
+        if self.debug_reward:
+            rew = self.debug_shaped_reward()
+        return obs, rew, done, info
+
+    def debug_shaped_reward(self):
+        """float64[N] on the device, from the poses after this step (for envs that were just auto-reset: of the new
+        episode's initial state, the closest batched reading of a reward handed out together with `done`)."""
+        import torch
+        rows = self._pose_rows
+        sx, sy = self.state_p[rows[self.__shape_ref.body, 0]], self.state_p[rows[self.__shape_ref.body, 1]]
+        rx, ry = self.state_p[rows[self._robot.body, 0]], self.state_p[rows[self._robot.body, 1]]
+        sx, sy, rx, ry = (v.to(torch.float64) for v in (sx, sy, rx, ry))
+        shape_to_corner_dist = torch.sqrt((sx - 0.0) ** 2 + (sy - 1.0) ** 2)          # (sic) target (0, 1), :89-91
+        robot_to_shape_dist = torch.sqrt((rx - sx) ** 2 + (ry - sy) ** 2)
+        shaping = -shape_to_corner_dist / 5 - torch.clamp(robot_to_shape_dist, min=0.2) / 20
+        # + score_on_end_of_traj() of the same poses (:66-75)
+        dist = torch.sqrt((-1.0 - sx) ** 2 + (1.0 - sy) ** 2)
+        furthest, succeed = 2.0 ** 0.5, 2.0 ** 0.5 / 2
+        score = torch.clamp(torch.clamp(furthest - dist, min=0.0) / (furthest - succeed), max=1.0)
+        return shaping + score
 
     def sample_variation(self, rng, k):   # move_to_corner.py:42-63, in the reference's order: colour, then poses
         if not (self.rand_shape_colour or self.rand_poses):

@@ -108,6 +108,15 @@ class MoveToCornerRef(TaskRef):
         score = min(1.0, max(0.0, furthest_dist - dist) / drange)
         return score
 
+    def debug_shaped_reward(self):
+        """move_to_corner.py:84-98."""
+        shape_pos = np.asarray(self.block_pos(self.shape))
+        shape_to_corner_dist = np.linalg.norm(shape_pos - np.array((0, 1)))
+        robot_pos = np.asarray(self.world_pose(self.robot.robot_body)[:2])
+        robot_to_shape_dist = np.linalg.norm(robot_pos - shape_pos)
+        shaping = -shape_to_corner_dist / 5 - max(robot_to_shape_dist, 0.2) / 20
+        return shaping + self.score_on_end_of_traj()
+
 
 class MoveToRegionRef(TaskRef):
     """benchmarks/move_to_region.py:9-11,30-94."""

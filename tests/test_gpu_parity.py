@@ -133,7 +133,7 @@ def test_determinism_and_lockstep():
 def _variant_names():
     import magical_amd
     magical_amd.register_envs()
-    return [n for n in magical_amd.ALL_REGISTERED_ENVS if n.count('-') == 2 and 'DebugReward' not in n]   # <Task>-<Variant>-v0
+    return [n for n in magical_amd.ALL_REGISTERED_ENVS if n.count('-') == 2]   # <Task>-<Variant>-v0
 
 
 @pytest.mark.parametrize('env_name', _variant_names())
@@ -483,6 +483,31 @@ def test_pose_randomisation_matches_oracle(task, variant, flags):
             # first step: rounding only; afterwards the reference dynamics amplify it, more so in
             # random layouts where the robot may start next to a block
             assert err < (1e-8 if s % ep == 0 else 3e-2), (task, s, k, err)
+    env.close()
+
+
+def test_debug_reward_env():
+    """MoveToCorner-Demo-DebugReward-v0 (move_to_corner.py:77-98): the shaped reward on the device equals the oracle's
+    restatement on the same poses; the preprocessor-suffixed names build the plain env, as in the reference."""
+    import warnings
+    import magical_amd
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        env = magical_amd.make('MoveToCorner-Demo-DebugReward-v0', n_envs=4, device='cuda:0', dtype='f64')
+        env2 = magical_amd.make('MoveToCorner-Demo-DebugReward-LoRes4E-v0', n_envs=1, device='cuda:0')
+    assert env.debug_reward and type(env2) is type(env)
+    env2.close()
+    env.reset()
+    refs = [new_ref('MoveToCorner') for _ in range(4)]
+    idx = ref_body_index(refs[0])
+    tape = _tape(53, 10, 4)
+    for s in range(10):
+        _, rew, done, _ = env.step(tape[s])
+        poses = env.get_poses()
+        for k, r in enumerate(refs):
+            b = r.bodies(); b[idx, :3] = poses[k, 1:, :]; r.set_bodies(b)
+            assert abs(float(rew[k]) - r.task.debug_shaped_reward()) < 1e-12, (s, k)
+    assert float(rew.abs().max()) > 0.01
     env.close()
 
 
