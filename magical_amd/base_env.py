@@ -289,17 +289,17 @@ class BaseEnv(abc.ABC):
             if var is not None and 'colours' in var:
                 row = self._default_colours.copy()
                 for ent, name in var['colours'].items():
-                    row[self._entities.index(ent)] = en.COLOUR_ID[name]
+                    row[ent.ent_id] = en.COLOUR_ID[name]
                 colour_rows.append(row)
             if var is not None and 'poses' in var:
                 row = self._default_poses.copy()
                 for ent, pose in var['poses'].items():
-                    row[self._entities.index(ent)] = pose
+                    row[ent.ent_id] = pose
                 pose_rows.append(row)
             if var is not None and 'randomise_poses' in var:
                 pose_spec = var['randomise_poses']       # the same for every env of a task: one native call below
             if var is not None and 'goal_hw' in var:
-                hw_rows[int(k)] = {self._entities.index(g): hw for g, hw in var['goal_hw'].items()}
+                hw_rows[int(k)] = {g.ent_id: hw for g, hw in var['goal_hw'].items()}
         ent_hw = None
         if hw_rows:
             # resized goal regions keep their top-left corner (GoalRegion(x, y, h, w), entities.py:769-797): new centre

@@ -47,7 +47,7 @@ class MoveToCornerEnv(BaseEnv):
             return None
         var = {}
         if self.rand_shape_colour:
-            var['colours'] = {self.__shape_ref: rng.choice(np.asarray(en.SHAPE_COLOURS, dtype='object'))}
+            var['colours'] = {self.__shape_ref: rng.choice(en.shape_colours_obj())}
         if self.rand_poses:
             var['randomise_poses'] = ((self._robot, self.__shape_ref), dict(
                 rand_pos=True, rand_rot=True, rel_pos_linf_limits=self.JITTER_POS_BOUND, rel_rot_limits=self.JITTER_ROT_BOUND))

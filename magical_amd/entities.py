@@ -63,6 +63,15 @@ COLOUR_ID = {c: i for i, c in enumerate(ShapeColour)}
 # plain-str view of SHAPE_COLOURS for rng.choice: numpy stringifies str-Enum members by their repr on this Python /
 # numpy pair, the reference's environment by their value; the draws (one randint per element) are the same either way
 SHAPE_COLOUR_NAMES = tuple(c.value for c in SHAPE_COLOURS)
+SHAPE_COLOURS_OBJ = None     # np.asarray(SHAPE_COLOURS, dtype='object'), built on first use (rng.choice argument of two tasks)
+
+
+def shape_colours_obj():
+    global SHAPE_COLOURS_OBJ
+    if SHAPE_COLOURS_OBJ is None:
+        import numpy as np
+        SHAPE_COLOURS_OBJ = np.asarray(SHAPE_COLOURS, dtype='object')
+    return SHAPE_COLOURS_OBJ
 
 
 class Entity:

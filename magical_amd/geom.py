@@ -159,14 +159,16 @@ def pm_randomise_all_poses_batch(env, poses, entities, arena_lrbt, rngs, rand_po
 
 
 def randomise_hw(min_side, max_side, rng, current_hw=None, linf_bound=None):
-    """geom.py:344-360: height and width of a goal region, two draws (h, then w)."""
+    """geom.py:344-360: height and width of a goal region, two draws (h, then w).  The reference draws both with one
+    rng.uniform(minima, maxima) on length-2 arrays, which numpy evaluates element by element as
+    low + (high - low) * random_sample() -- the two scalar calls below (this runs once per env and reset)."""
     assert min_side <= max_side
-    minima = np.asarray((min_side, min_side))
-    maxima = np.asarray((max_side, max_side))
+    lo_h = lo_w = float(min_side)
+    hi_h = hi_w = float(max_side)
     if linf_bound is not None:
         assert linf_bound == float(linf_bound) and current_hw is not None and len(current_hw) == 2
-        current_hw = np.asarray(current_hw)
-        minima = np.maximum(minima, current_hw - linf_bound)
-        maxima = np.minimum(maxima, current_hw + linf_bound)
-    h, w = rng.uniform(minima, maxima)
+        lo_h, hi_h = max(lo_h, current_hw[0] - linf_bound), min(hi_h, current_hw[0] + linf_bound)
+        lo_w, hi_w = max(lo_w, current_hw[1] - linf_bound), min(hi_w, current_hw[1] + linf_bound)
+    h = rng.uniform(lo_h, hi_h)
+    w = rng.uniform(lo_w, hi_w)
     return h, w
