@@ -92,3 +92,43 @@ def test_allo_reset_frame_vs_reference_png(task):
     d = np.abs(half - ref).max(axis=2)
     assert d.mean() < 1.0                  # same layout, palette and draw order
     assert (d > 24).mean() < 0.02          # only edge pixels differ (AA / resampling differences)
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.mark.parametrize('task', ['MoveToCorner', 'MoveToRegion', 'MatchRegions', 'MakeLine',
+                                  'FindDupe', 'FixColour', 'ClusterColour', 'ClusterShape'])
+def test_allo_reset_frame_vs_golden_reference_frames(task):
+    """The same weak pin as above, from the committed fixture (tests/golden/static_frames_48.npz = the reference's PNGs
+    box-averaged to 48x48 by tests/golden/make_static_frames.py): runs wherever the repo is, no /root/reference needed."""
+    gold = np.load(os.path.join(GOLDEN, 'static_frames_48.npz'))[task].astype(int)
+    e = RefEnv(task)
+    e.reset()
+    small = area_downsample(e.render('allo'), 8).astype(int)
+    d = np.abs(small - gold).max(axis=2)
+    assert d.mean() < 1.5                  # same layout, palette and draw order
+    assert (d > 24).mean() < 0.03          # only edge pixels differ (AA / resampling differences)
+
+
+def test_oracle_reproduces_golden_vectors():
+    """tests/golden/oracle_vectors.json (made by make_oracle_vectors.py): the oracle still renders byte-identical reset
+    observations and, after the recorded tapes, reaches the recorded poses (to 1e-9: a different libm may move the last
+    bit of a sin / cos, which six env-steps can amplify) and -- when the poses agree exactly -- the recorded frames."""
+    import hashlib
+    import json
+    from oracle.env_ref import LoRes4ERef
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    gold = json.load(open(os.path.join(GOLDEN, 'oracle_vectors.json')))
+    for task, rec in gold.items():
+        env = LoRes4ERef(RefEnv(task))
+        obs = env.reset()
+        assert sha(obs) == rec['reset']['lores4e'] and sha(env.env.render_lores('ego')) == rec['reset']['ego']
+        assert sha(env.env.render_lores('allo')) == rec['reset']['allo']
+        assert np.array_equal(env.env.bodies()[:, :3], np.asarray(rec['reset']['bodies']))
+        for a in rec['tape']:
+            obs, _, _, _ = env.step(a)
+        want = np.asarray(rec['final']['bodies'])
+        assert np.abs(env.env.bodies() - want).max() < 1e-9, task
+        if np.array_equal(env.env.bodies(), want):
+            assert sha(obs) == rec['final']['lores4e'] and sha(env.env.render_lores('ego')) == rec['final']['ego']
