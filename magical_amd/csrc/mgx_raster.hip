@@ -53,14 +53,14 @@ constexpr int LAY_FRAME = 0, LAY_STACK4 = 1, LAY_STACK3HI = 2, LAY_SLOT0 = 3;
 struct OldPx { uint32_t o0, o1, o2; };
 template <int LAYOUT> __device__ __forceinline__ bool layout_needs_old(bool fill) { return LAYOUT == LAY_STACK4 ? !fill : true; }
 template <int LAYOUT> __device__ __forceinline__ OldPx load_old(const uint8_t *frame, int X, int Y) {
-    const uint32_t *px = reinterpret_cast<const uint32_t *>(frame + (long)(Y * LORES + X) * 12);
+    const uint32_t *px = reinterpret_cast<const uint32_t *>(frame + (uint32_t)((Y * LORES + X) * 12));     // uniform base + 32-bit offset
     OldPx o; o.o0 = px[0];
     if (LAYOUT == LAY_SLOT0) { o.o1 = 0; o.o2 = 0; } else { o.o1 = px[1]; o.o2 = px[2]; }
     return o;
 }
 // the pixel update with the old pixel already in registers (loaded a tile ahead so its latency hides behind classification)
 template <int LAYOUT> __device__ __forceinline__ void store_pre(uint8_t *frame, int X, int Y, int c, bool fill, const OldPx &o) {
-    uint32_t *px = reinterpret_cast<uint32_t *>(frame + (long)(Y * LORES + X) * 12);
+    uint32_t *px = reinterpret_cast<uint32_t *>(frame + (uint32_t)((Y * LORES + X) * 12));
     const uint32_t r = c & 0xFF, g = (c >> 8) & 0xFF, b = (c >> 16) & 0xFF;
     if (LAYOUT == LAY_SLOT0) { px[0] = (o.o0 & 0xFF000000u) | ((uint32_t)c & 0xFFFFFFu); return; }
     uint32_t d0, d1, d2;
@@ -86,6 +86,23 @@ template <int LAYOUT> __device__ __forceinline__ void store_patch(uint8_t *frame
 __device__ __forceinline__ void store_frame_px(uint8_t *frame, int X, int Y, int c) {
     uint8_t *q = frame + (long)(Y * LORES + X) * 3;
     q[0] = c & 0xFF; q[1] = (c >> 8) & 0xFF; q[2] = (c >> 16) & 0xFF;
+}
+
+// masked_item_index for a prim set that is the same in every lane (a tile's): the walk over the set runs on the scalar
+// unit, each lane only compares its slot against the running item count
+__device__ __forceinline__ int masked_item_index_uniform(const Raster &rs, uint64_t mask_v, int slot, int &n_total) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)mask_v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(mask_v >> 32));
+    uint64_t mask = ((uint64_t)hi << 32) | lo;
+    int acc = 0, found = -1;
+    while (mask) {
+        const int k = 63 - __builtin_clzll(mask);
+        mask &= ~(1ull << k);
+        const int pi = __builtin_amdgcn_readfirstlane(RI(pitem, k)), start = pi & 0xFFFF, cnt = pi >> 16;
+        if (slot >= acc && slot < acc + cnt) found = start + (slot - acc);
+        acc += cnt;
+    }
+    n_total = acc;
+    return found;
 }
 
 // one Item per lane; get(i) broadcasts lane i's record to the whole wave as scalar operands
@@ -271,7 +288,7 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
         int n_total = 0;
         for (int c0 = 0;; c0 += 64) {
             RegItems src;
-            const int idx = masked_item_index(rs, tmixed, c0 + lane, n_total);
+            const int idx = masked_item_index_uniform(rs, tmixed, c0 + lane, n_total);
             src.my = load_item(rs, idx >= 0 ? idx : 0);
             const int n = n_total - c0 < 64 ? n_total - c0 : 64;
             PROBE(const unsigned long long pt1 = __builtin_amdgcn_s_memtime(); pr_gather += pt1 - pt0;)
