@@ -68,6 +68,7 @@ struct Raster {
     MGX_HD int prim_rgb_template(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 4]; }
     MGX_HD int prim_stipple(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 5] & 0xFFFF; }
     MGX_HD int prim_goal(int k) const { return (ti[to.prim_i + k * PRIM_IWORDS + 5] >> 16) - 1; }   // goal region ordinal, -1: none
+    MGX_HD uint32_t prim_ends(int k) const { return (uint32_t)ti[to.prim_i + k * PRIM_IWORDS + 6]; }    // bit i: vertex i ends a convex part
     // tq layout: [n_prims * PRIM_RWORDS][pvx n_pverts][pvy n_pverts]
     MGX_HD double prim_r(int k, int j) const { return tq[k * PRIM_RWORDS + j]; }
     MGX_HD double pvx(int v) const { return tq[h->n_prims * PRIM_RWORDS + v]; }
@@ -120,7 +121,29 @@ MGX_HD void raster_camera(const Raster &rs, double *cam) {
     }
 }
 
-// ---- setup phase 2: screen-space vertices (lane per vertex) and n-gon records (lane per prim)
+// ---------------------------------------------------------------- fp32 classification items
+// The conservative ALL / NONE / MIXED classification runs in fp32 on a flat list of ITEMS -- one per polygon
+// edge, per n-gon, per line-loop segment -- stored front-to-back.  A wavefront loads up to 64 items (one per
+// lane) and every lane (a tile in phase C, an output pixel in phase T) consumes them through v_readlane
+// broadcasts: the item fields become scalar operands, the loop is wave-uniform and touches no LDS.
+enum { IT_EDGE = 0, IT_NGON = 1, IT_SEG = 2 };
+// A polygon made of several convex parts (a star) is classified part by part, each part like a primitive of its own
+// with the same index: the union touches the block when a part does (bit k of `mixed`) and covers it when a part does.
+// A block covered only by several parts together counts as MIXED, which costs time, not correctness.
+constexpr int IT_LAST = 4;      // meta bit: last item of its convex part
+// meta = kind | IT_LAST | (items left in the part, this one included) << 3 | prim << 12
+constexpr int IT_REM_SHIFT = 3, IT_REM_MASK = 0x1FF, IT_K_SHIFT = 12;
+struct Item {
+    float a, b, c;              // EDGE/SEG: normalised line a x + b y + c;  NGON: centre x, y, apothem
+    float g0, g1, g2, g3;       // EDGE: g0 / g1 = extent over a 4x4 block / a tile;  SEG: start x, y, length, half width;  NGON: g0 = circumradius
+    int meta;                   // kind | IT_LAST | prim << 8
+};
+constexpr int TILE_W = 16, TILE_H = 4, TILES_X = LORES / TILE_W, TILES_Y = LORES / TILE_H;
+constexpr float TILE_HX = 2.0f * TILE_W - 0.5f, TILE_HY = 2.0f * TILE_H - 0.5f;
+
+
+// ---- setup phase 2: per-primitive records (lane per prim) and screen-space vertices (lane per prim vertex)
+MGX_HD int prim_item_count(const Raster &rs, int k) { return rs.prim_kind(k) == PR_NGON ? 1 : rs.prim_nv(k); }
 MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_rgb = nullptr, long stride = 0, long env = 0,
                                const double *env_goal = nullptr) {
     const TmplHeader &h = *rs.h;
@@ -128,9 +151,16 @@ MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_
     raster_camera(rs, cam);
     for (int k = lane; k < h.n_prims; k += nl) {
         RI(prgb, k) = env_rgb ? env_rgb[(long)k * stride + env] : rs.prim_rgb_template(k);
-        int kind = rs.prim_kind(k), xfw = rs.prim_xf(k);
+        // the prim's slice of the item list: front (top) prims first
+        int start = 0;
+        for (int kk = h.n_prims - 1; kk > k; kk--) start += prim_item_count(rs, kk);
+        RI(pitem, k) = start | (prim_item_count(rs, k) << 16);
+        const int kind = rs.prim_kind(k);
+        if (kind == PR_LINELOOP) RD(prad, k) = rs.prim_r(k, 4);
+        if (kind != PR_NGON) continue;
+        int xfw = rs.prim_xf(k);
         int xf = xfw & 0xFF, body = (xfw >> 8) & 0xFF, eye_body = ((xfw >> 16) & 0xFF) - 1;
-        int nv = rs.prim_nv(k), vo = rs.prim_voff(k);
+        int nv = rs.prim_nv(k);
         double bx = RD(bx, body), by = RD(by, body), bc = RD(bc, body), bs = RD(bs, body);
         double ebx = rs.prim_r(k, 0), eby = rs.prim_r(k, 1), epx = rs.prim_r(k, 2), epy = rs.prim_r(k, 3);
         double da = 0.0, dc = 1.0, ds = 0.0;
@@ -138,75 +168,114 @@ MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_
             da = RD(ba, eye_body) - RD(ba, body);
             r_sincos<double>(da, ds, dc);
         }
-        if (kind == PR_NGON) {
-            // centre = image of the local origin; phase = world angle of vertex 0 minus camera rotation
-            double lx = 0.0, ly = 0.0;
-            if (xf == XF_EYE) { double qx = lx + epx, qy = ly + epy; lx = (dc * qx - ds * qy) + ebx; ly = (ds * qx + dc * qy) + eby; }
-            double wx = lx, wy = ly;
-            if (xf != XF_WORLD) { wx = bx + (bc * lx - bs * ly); wy = by + (bc * ly + bs * lx); }
-            RD(pcx, k) = cam[0] * wx + cam[1] * wy + cam[4];
-            RD(pcy, k) = cam[2] * wx + cam[3] * wy + cam[5];
-            double sc = (double)NATIVE_RES / 2.04;
-            double rad = rs.prim_r(k, 5) * sc;
-            RD(prad, k) = rad;
-            RD(papo, k) = rad * cos(3.14159265358979323846 / nv);
-            double phi = 0.0;
-            if (xf != XF_WORLD) phi += RD(ba, body);
-            if (xf == XF_EYE) phi += da;
-            if (rs.view == 0) phi -= RD(ba, rs.h->robot_body);
-            RD(pphi, k) = phi;
-            continue;
-        }
+        // centre = image of the local origin; phase = world angle of vertex 0 minus camera rotation
+        double lx = 0.0, ly = 0.0;
+        if (xf == XF_EYE) { double qx = lx + epx, qy = ly + epy; lx = (dc * qx - ds * qy) + ebx; ly = (ds * qx + dc * qy) + eby; }
+        double wx = lx, wy = ly;
+        if (xf != XF_WORLD) { wx = bx + (bc * lx - bs * ly); wy = by + (bc * ly + bs * lx); }
+        const double pcx = cam[0] * wx + cam[1] * wy + cam[4], pcy = cam[2] * wx + cam[3] * wy + cam[5];
+        RD(pcx, k) = pcx; RD(pcy, k) = pcy;
+        double sc = (double)NATIVE_RES / 2.04;
+        double rad = rs.prim_r(k, 5) * sc, apo = rad * cos(3.14159265358979323846 / nv);
+        RD(prad, k) = rad;
+        RD(papo, k) = apo;
+        double phi = 0.0;
+        if (xf != XF_WORLD) phi += RD(ba, body);
+        if (xf == XF_EYE) phi += da;
+        if (rs.view == 0) phi -= RD(ba, rs.h->robot_body);
+        RD(pphi, k) = phi;
+        Item *it = reinterpret_cast<Item *>(&RI(items, 8 * start));
+        it[0].a = (float)pcx; it[0].b = (float)pcy; it[0].c = (float)apo; it[0].g0 = (float)rad;
+        it[0].g1 = it[0].g2 = it[0].g3 = 0.0f;
+        it[0].meta = IT_NGON | IT_LAST | (1 << IT_REM_SHIFT) | (k << IT_K_SHIFT);
+    }
+    for (int v = lane; v < h.n_pverts; v += nl) {
+        const int k = rs.ti[rs.to.pv_prim + v], i = v - rs.prim_voff(k);
+        const int xfw = rs.prim_xf(k), xf = xfw & 0xFF, body = (xfw >> 8) & 0xFF;
+        double lx = rs.pvx(v), ly = rs.pvy(v);
         // goal regions whose rectangle differs per env (x, y = top-left corner, then h, w): rebuild the four corners
         // the way the world builder does (gym_render.py:449-453 order around the box centre, entities.py:794-797)
         const int goal = env_goal ? rs.prim_goal(k) : -1;
-        double gx = 0, gy = 0, gh = 0, gw = 0, gcx = 0, gcy = 0;
         if (goal >= 0) {
-            gx = env_goal[(long)(4 * goal) * stride + env]; gy = env_goal[(long)(4 * goal + 1) * stride + env];
-            gh = env_goal[(long)(4 * goal + 2) * stride + env]; gw = env_goal[(long)(4 * goal + 3) * stride + env];
-            gcx = gx + gw / 2; gcy = gy - gh / 2;
+            const double gx = env_goal[(long)(4 * goal) * stride + env], gy = env_goal[(long)(4 * goal + 1) * stride + env];
+            const double gh = env_goal[(long)(4 * goal + 2) * stride + env], gw = env_goal[(long)(4 * goal + 3) * stride + env];
+            const double gcx = gx + gw / 2, gcy = gy - gh / 2;
+            lx = ((i == 1 || i == 2) ? gw / 2 : -gw / 2) + gcx; ly = ((i < 2) ? gh / 2 : -gh / 2) + gcy;
         }
-        for (int i = 0; i < nv; i++) {
-            double lx = rs.pvx(vo + i), ly = rs.pvy(vo + i);
-            if (goal >= 0) { lx = ((i == 1 || i == 2) ? gw / 2 : -gw / 2) + gcx; ly = ((i < 2) ? gh / 2 : -gh / 2) + gcy; }
-            double wx = lx, wy = ly;
-            if (xf != XF_WORLD) { wx = bx + (bc * lx - bs * ly); wy = by + (bc * ly + bs * lx); }
-            double sx = cam[0] * wx + cam[1] * wy + cam[4], sy = cam[2] * wx + cam[3] * wy + cam[5];
-            RD(svx, vo + i) = sx; RD(svy, vo + i) = sy;
+        double wx = lx, wy = ly;
+        if (xf != XF_WORLD) {
+            const double bx = RD(bx, body), by = RD(by, body), bc = RD(bc, body), bs = RD(bs, body);
+            wx = bx + (bc * lx - bs * ly); wy = by + (bc * ly + bs * lx);
         }
-        if (kind == PR_LINELOOP) RD(prad, k) = rs.prim_r(k, 4);
-        {
-            // normalised edge functions E(p) = sgn * cross(e, p - a) / |e|: >= 0 inside a polygon; for a line
-            // loop |E| is the distance to the segment's carrier line and (eb, -ea) is its unit direction
-            double sgn = 1.0;
-            if (kind == PR_POLY) {
-                double area2 = 0.0;
-                for (int i = 0; i < nv; i++) {
-                    int j = (i + 1) % nv;
-                    area2 += RD(svx, vo + i) * RD(svy, vo + j) - RD(svy, vo + i) * RD(svx, vo + j);
-                }
-                sgn = area2 >= 0.0 ? 1.0 : -1.0;
+        RD(svx, v) = cam[0] * wx + cam[1] * wy + cam[4];
+        RD(svy, v) = cam[2] * wx + cam[3] * wy + cam[5];
+    }
+}
+
+// ---- setup phase 3 (after a barrier): lane per prim vertex = per polygon edge / line segment (vertex i -> its successor):
+// normalised edge function E(p) = sgn * cross(e, p - a) / |e| (>= 0 inside a polygon; for a line loop |E| is the
+// distance to the segment's carrier line and (eb, -ea) is its unit direction) and the edge's classification item.
+// A polygon's convex parts are closed loops of their own: the edge after a part's last vertex returns to its first.
+MGX_HD void raster_setup_edges(Raster &rs, int lane, int nl) {
+    const TmplHeader &h = *rs.h;
+    for (int v = lane; v < h.n_pverts; v += nl) {
+        const int k = rs.ti[rs.to.pv_prim + v], vo = rs.prim_voff(k), nv = rs.prim_nv(k), i = v - vo;
+        const int kind = rs.prim_kind(k);
+        const uint32_t ends = rs.prim_ends(k);
+        const int p1 = i + __builtin_ctz(ends >> i);                                              // last vertex of this part
+        const uint32_t before = ends & ((1u << i) - 1u);
+        const int p0 = before ? 32 - __builtin_clz(before) : 0;                                  // first vertex of this part
+        double sgn = 1.0;
+        if (kind == PR_POLY) {
+            double area2 = 0.0;
+            for (int a = p0; a <= p1; a++) {
+                int b = a == p1 ? p0 : a + 1;
+                area2 += RD(svx, vo + a) * RD(svy, vo + b) - RD(svy, vo + a) * RD(svx, vo + b);
             }
+            sgn = area2 >= 0.0 ? 1.0 : -1.0;
+        }
+        const int j = i == p1 ? p0 : i + 1;
+        const double ax = RD(svx, vo + i), ay = RD(svy, vo + i), ex = RD(svx, vo + j) - ax, ey = RD(svy, vo + j) - ay;
+        const double len = sqrt(ex * ex + ey * ey);
+        const double inv = sgn / len;
+        const double ea = -ey * inv, eb = ex * inv, ec = (ey * ax - ex * ay) * inv;
+        RD(ea, v) = ea; RD(eb, v) = eb; RD(ec, v) = ec; RD(elen, v) = len;
+        Item *it = reinterpret_cast<Item *>(&RI(items, 8 * ((RI(pitem, k) & 0xFFFF) + i)));
+        it->a = (float)ea; it->b = (float)eb; it->c = (float)ec;
+        if (kind == PR_LINELOOP) {
+            // arclength at the segment's start: the lengths of the loop's earlier segments, summed in order
             double arc = 0.0;
-            for (int i = 0; i < nv; i++) {
-                int j = (i + 1) % nv;
-                double ax = RD(svx, vo + i), ay = RD(svy, vo + i), ex = RD(svx, vo + j) - ax, ey = RD(svy, vo + j) - ay;
-                double len = sqrt(ex * ex + ey * ey);
-                double inv = sgn / len;
-                RD(ea, vo + i) = -ey * inv; RD(eb, vo + i) = ex * inv; RD(ec, vo + i) = (ey * ax - ex * ay) * inv;
-                RD(elen, vo + i) = len; RD(earc, vo + i) = arc;
-                arc += len;
+            for (int a = 0; a < i; a++) {
+                const double dx = RD(svx, vo + a + 1) - RD(svx, vo + a), dy = RD(svy, vo + a + 1) - RD(svy, vo + a);
+                arc += sqrt(dx * dx + dy * dy);
             }
+            RD(earc, v) = arc;
+            it->g0 = (float)ax; it->g1 = (float)ay; it->g2 = (float)len; it->g3 = (float)RD(prad, k);
+        } else {
+            RD(earc, v) = 0.0;
+            // edge function divided by its conservative half-extent over a 4x4 sample block (g0..g2: the block is
+            // entirely inside / outside this edge when the scaled value at its centre is > 1 / < -1), and the
+            // reciprocal half-extent over a whole tile (g3)
+            const float fa = r_abs(it->a), fb = r_abs(it->b);
+            const float ip = 1.0f / (1.5f * (fa + fb) + CLASS_EPS_F);
+            it->g0 = it->a * ip; it->g1 = it->b * ip; it->g2 = it->c * ip;
+            it->g3 = 1.0f / (TILE_HX * fa + TILE_HY * fb + CLASS_EPS_F);
         }
+        it->meta = (kind == PR_POLY ? IT_EDGE : IT_SEG) | (i == p1 ? IT_LAST : 0) | ((p1 - i + 1) << IT_REM_SHIFT) | (k << IT_K_SHIFT);
+        (void)nv;
     }
 }
 
 // ---- exact sample tests (fp64)
 MGX_HD bool poly_contains(const Raster &rs, int k, double x, double y) {
     int nv = rs.prim_nv(k), vo = rs.prim_voff(k);
-    for (int i = 0; i < nv; i++)
-        if (RD(ea, vo + i) * x + RD(eb, vo + i) * y + RD(ec, vo + i) < 0.0) return false;
-    return true;
+    const uint32_t ends = rs.prim_ends(k);
+    bool in = true;                                 // inside the part being walked; the polygon is the union of its parts
+    for (int i = 0; i < nv; i++) {
+        if (RD(ea, vo + i) * x + RD(eb, vo + i) * y + RD(ec, vo + i) < 0.0) in = false;
+        if ((ends >> i) & 1u) { if (in) return true; in = true; }
+    }
+    return false;
 }
 MGX_HD bool ngon_contains(const Raster &rs, int k, double x, double y) {
     double qx = x - RD(pcx, k), qy = y - RD(pcy, k);
@@ -288,58 +357,6 @@ MGX_HD int raster_sample(const Raster &rs, double x, double y, uint64_t mask, in
     return r | (g << 8) | (b << 16);
 }
 
-// ---------------------------------------------------------------- fp32 classification items
-// The conservative ALL / NONE / MIXED classification runs in fp32 on a flat list of ITEMS -- one per polygon
-// edge, per n-gon, per line-loop segment -- stored front-to-back.  A wavefront loads up to 64 items (one per
-// lane) and every lane (a tile in phase C, an output pixel in phase T) consumes them through v_readlane
-// broadcasts: the item fields become scalar operands, the loop is wave-uniform and touches no LDS.
-enum { IT_EDGE = 0, IT_NGON = 1, IT_SEG = 2 };
-constexpr int IT_LAST = 4;      // meta bit: last item of its primitive
-// meta = kind | IT_LAST | (items left in the prim, this one included) << 3 | prim << 12
-constexpr int IT_REM_SHIFT = 3, IT_REM_MASK = 0x1FF, IT_K_SHIFT = 12;
-struct Item {
-    float a, b, c;              // EDGE/SEG: normalised line a x + b y + c;  NGON: centre x, y, apothem
-    float g0, g1, g2, g3;       // EDGE: g0 / g1 = extent over a 4x4 block / a tile;  SEG: start x, y, length, half width;  NGON: g0 = circumradius
-    int meta;                   // kind | IT_LAST | prim << 8
-};
-constexpr int TILE_W = 16, TILE_H = 4, TILES_X = LORES / TILE_W, TILES_Y = LORES / TILE_H;
-constexpr float TILE_HX = 2.0f * TILE_W - 0.5f, TILE_HY = 2.0f * TILE_H - 0.5f;
-
-MGX_HD int prim_item_count(const Raster &rs, int k) { return rs.prim_kind(k) == PR_NGON ? 1 : rs.prim_nv(k); }
-
-// setup phase 3 (lane per prim, after raster_setup_prims + barrier): write the prim's items
-MGX_HD void raster_setup_items(Raster &rs, int lane, int nl) {
-    const TmplHeader &h = *rs.h;
-    for (int k = lane; k < h.n_prims; k += nl) {
-        int start = 0;
-        for (int kk = h.n_prims - 1; kk > k; kk--) start += prim_item_count(rs, kk);     // front (top) prims first
-        int kind = rs.prim_kind(k), nv = rs.prim_nv(k), vo = rs.prim_voff(k), cnt = prim_item_count(rs, k);
-        RI(pitem, k) = start | (cnt << 16);
-        Item *it = reinterpret_cast<Item *>(&RI(items, 8 * start));
-        if (kind == PR_NGON) {
-            it[0].a = (float)RD(pcx, k); it[0].b = (float)RD(pcy, k); it[0].c = (float)RD(papo, k); it[0].g0 = (float)RD(prad, k);
-            it[0].g1 = it[0].g2 = it[0].g3 = 0.0f;
-            it[0].meta = IT_NGON | IT_LAST | (1 << IT_REM_SHIFT) | (k << IT_K_SHIFT);
-        } else {
-            for (int i = 0; i < nv; i++) {
-                it[i].a = (float)RD(ea, vo + i); it[i].b = (float)RD(eb, vo + i); it[i].c = (float)RD(ec, vo + i);
-                if (kind == PR_LINELOOP) {
-                    it[i].g0 = (float)RD(svx, vo + i); it[i].g1 = (float)RD(svy, vo + i); it[i].g2 = (float)RD(elen, vo + i);
-                    it[i].g3 = (float)RD(prad, k);
-                } else {
-                    // edge function divided by its conservative half-extent over a 4x4 sample block (g0..g2: the block is
-                    // entirely inside / outside this edge when the scaled value at its centre is > 1 / < -1), and the
-                    // reciprocal half-extent over a whole tile (g3)
-                    float fa = r_abs(it[i].a), fb = r_abs(it[i].b);
-                    float ip = 1.0f / (1.5f * (fa + fb) + CLASS_EPS_F);
-                    it[i].g0 = it[i].a * ip; it[i].g1 = it[i].b * ip; it[i].g2 = it[i].c * ip;
-                    it[i].g3 = 1.0f / (TILE_HX * fa + TILE_HY * fb + CLASS_EPS_F);
-                }
-                it[i].meta = (kind == PR_POLY ? IT_EDGE : IT_SEG) | (i == nv - 1 ? IT_LAST : 0) | ((nv - i) << IT_REM_SHIFT) | (k << IT_K_SHIFT);
-            }
-        }
-    }
-}
 MGX_HD int raster_total_items(const Raster &rs) {
     int pi = RI(pitem, 0);                      // prim 0 is the rearmost: its items end the list
     return (pi & 0xFFFF) + (pi >> 16);
@@ -426,29 +443,40 @@ MGX_HD void tile_centre(int tile, float &xc, float &yc) {
 // against the fp64 edge function -- the result equals the all-fp64 test.
 MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, int X, int Y, uint32_t &unc) {
     const int nv = rs.prim_nv(k), i0 = RI(pitem, k) & 0xFFFF;
+    const uint32_t ends = rs.prim_ends(k);                                  // bit e: edge e closes a convex part
     const float x0 = 4.0f * X + 0.5f, y0 = (float)NATIVE_RES - 0.5f - 4.0f * Y;
     const Item *items = reinterpret_cast<const Item *>(&RI(items, 0)) + i0;
-    uint32_t cov = 0xFFFFu;
-    for (int e = 0; e < nv && cov; e++) {
-        const float a = items[e].a, b = items[e].b;
-        float row = a * x0 + b * y0 + items[e].c;
-        // block spans x0..x0+3, y0-3..y0: worst / best corner value of this edge function
-        const float lo = row + r_min(0.0f, 3.0f * a) - r_max(0.0f, 3.0f * b);
-        if (lo >= CLASS_EPS_F) continue;                                   // whole block inside this edge
-        const float hi = row + r_max(0.0f, 3.0f * a) - r_min(0.0f, 3.0f * b);
-        if (hi < -CLASS_EPS_F) return 0u;                                  // whole block outside
-        uint32_t in = 0, amb = 0;
-        for (int j = 0; j < 4; j++) {
-            float v = row;
-            for (int i = 0; i < 4; i++) {
-                in |= (v >= CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
-                amb |= (r_abs(v) < CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
-                v += a;
+    // `part` = samples inside every edge of the convex part being walked; the polygon is the union of its parts (a sample
+    // that is ambiguous for one part stays flagged even when another part holds it: the exact painter then decides it)
+    uint32_t cov = 0, part = 0xFFFFu;
+    for (int e = 0; e < nv; e++) {
+        if (part) {
+            const float a = items[e].a, b = items[e].b;
+            float row = a * x0 + b * y0 + items[e].c;
+            // block spans x0..x0+3, y0-3..y0: worst / best corner value of this edge function
+            const float lo = row + r_min(0.0f, 3.0f * a) - r_max(0.0f, 3.0f * b);
+            const float hi = row + r_max(0.0f, 3.0f * a) - r_min(0.0f, 3.0f * b);
+            if (hi < -CLASS_EPS_F) part = 0;                               // whole block outside this edge
+            else if (lo < CLASS_EPS_F) {                                   // (else: whole block inside it)
+                uint32_t in = 0, amb = 0;
+                for (int j = 0; j < 4; j++) {
+                    float v = row;
+                    for (int i = 0; i < 4; i++) {
+                        in |= (v >= CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
+                        amb |= (r_abs(v) < CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
+                        v += a;
+                    }
+                    row -= b;
+                }
+                unc |= amb & part;                                         // samples too close to call in fp32
+                part &= in;
             }
-            row -= b;
         }
-        unc |= amb & cov;                                                  // samples too close to call in fp32
-        cov &= in;
+        if ((ends >> e) & 1u) {
+            cov |= part;
+            if (e == nv - 1 || cov == 0xFFFFu) break;
+            part = 0xFFFFu;
+        }
     }
     return cov;
 }

@@ -163,7 +163,7 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
         }
         i += run;
         if (run == rem) {
-            // the primitive is complete: verdict for this lane's block
+            // the primitive (or one convex part of it) is complete: verdict for this lane's block
             const bool open = !st.decided;
             const bool touch = kind == IT_SEG ? lo >= 0.0f : !(lo < -1.0f);
             const bool all = kind != IT_SEG && lo > 1.0f;
@@ -225,12 +225,12 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
         *reinterpret_cast<uint64_t *>(q_count + 6) = lm;
     }
     for (int i = tid; i < OVF_WORDS; i += 256) q_ovf[i] = 0;
-    // phase S: screen-space setup (lane per body, lane per primitive, lane per primitive again for the item list)
+    // phase S: screen-space setup (lane per body; lane per primitive + lane per vertex; lane per edge for the item list)
     raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
     __syncthreads();
     raster_setup_prims(rs, tid, 256, t.prim_rgb_env, (long)n_envs, env, t.goal_xyhw_env);
     __syncthreads();
-    raster_setup_items(rs, tid, 256);
+    raster_setup_edges(rs, tid, 256);
     __syncthreads();
     CLK(1)
     const int wave = tid >> 6, lane = tid & 63;
@@ -451,6 +451,8 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster_native(RasterD
     raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
     __syncthreads();
     raster_setup_prims(rs, tid, 256, t.prim_rgb_env, (long)n_envs, env, t.goal_xyhw_env);
+    __syncthreads();
+    raster_setup_edges(rs, tid, 256);
     __syncthreads();
     const int pix = blockIdx.x * 256 + tid;
     if (pix >= NATIVE_RES * NATIVE_RES) return;

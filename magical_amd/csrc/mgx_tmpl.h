@@ -34,7 +34,10 @@ constexpr int CAP_PVERTS = 320;
 
 constexpr int N_PHYS_VARS = 5;    // robot_pos, robot_rot, finger, shape_trans, shape_rot joint max forces (phys_vars.py)
 constexpr int JOINT_PARAMS = 10;   // ax ay bx by p0 p1 p2 bias_rate max_bias max_impulse
-constexpr int PRIM_IWORDS = 6;     // kind, nverts, voff, xform|body<<8|eye_body<<16, rgb(packed), stipple
+constexpr int PRIM_IWORDS = 7;     // kind, nverts, voff, xform|body<<8|eye_body<<16, rgb(packed), stipple, part ends
+// A PR_POLY primitive is a union of convex parts drawn in one colour (a star: five triangles + a pentagon, entities.py:
+// 723-734): its vertices are the parts' vertices back to back and bit i of the `part ends` word marks vertex i as the
+// last one of its part (a plain convex polygon has the single bit nverts - 1) -- hence at most 32 vertices per primitive.
 constexpr int PRIM_RWORDS = 6;     // eye_base(2) eye_pre(2) line_halfwidth radius
 
 struct TmplHeader {
@@ -58,7 +61,7 @@ enum ConstIdx {
 struct TmplOff {
     // ints
     int body_type, body_parent, body_ent, shape_kind, shape_body, shape_voff, shape_nv;
-    int joint_kind, joint_a, joint_b, joint_acc, joint_pv, pair, state_map, prim_i, body_prow, island_j, n_i;
+    int joint_kind, joint_a, joint_b, joint_acc, joint_pv, pair, state_map, prim_i, pv_prim, body_prow, island_j, n_i;
     // reals
     int body_minv, body_iinv, body_init, body_anchor, shape_r, shape_u, lvx, lvy, lnx, lny;
     int joint_p, prim_r, pvx, pvy, consts, n_r;
@@ -81,6 +84,7 @@ struct TmplOff {
         pair = o; o += h.n_pairs;
         state_map = o; o += h.n_state;
         prim_i = o; o += h.n_prims * PRIM_IWORDS;
+        pv_prim = o; o += h.n_pverts;         // primitive of every draw-list vertex (the rasteriser sets vertices up one per lane)
         body_prow = o; o += h.n_bodies * 3;   // pose-blob row of (x, y, angle) per body, -1 if not persistent
         island_j = o; o += h.n_islands;
         n_i = o;

@@ -466,8 +466,16 @@ int World::finalize(int max_steps, std::string &err) {
                 PrimDef o = prim(PR_NGON, dark, XF_BODY, body); o.ngon = 100; o.radius = size; o.ent = (int)ei; o.role = 0; prims.push_back(o);
                 PrimDef i = prim(PR_NGON, col, XF_BODY, body); i.ngon = 100; i.radius = size - SHAPE_LINE; i.ent = (int)ei; i.role = 1; prims.push_back(i);
             } else {
-                for (auto &g : draw_outer) { PrimDef o = prim(PR_POLY, dark, XF_BODY, body); o.verts = g; o.ent = (int)ei; o.role = 0; prims.push_back(o); }
-                for (auto &g : draw_inner) { PrimDef i = prim(PR_POLY, col, XF_BODY, body); i.verts = g; i.ent = (int)ei; i.role = 1; prims.push_back(i); }
+                // the convex parts of one compound are painted back to back in one opaque colour (entities.py:750-757), so
+                // each compound is a single multi-part primitive: the union of its parts
+                auto compound = [&](const std::vector<std::vector<Vec2>> &geoms, Rgb c, int role) {
+                    PrimDef q = prim(PR_POLY, c, XF_BODY, body);
+                    for (auto &g : geoms) { q.verts.insert(q.verts.end(), g.begin(), g.end()); q.parts.push_back((int)g.size()); }
+                    q.ent = (int)ei; q.role = role;
+                    prims.push_back(q);
+                };
+                compound(draw_outer, dark, 0);
+                compound(draw_inner, col, 1);
             }
         } else {
             // ---------------- GoalRegion (entities.py:790-819): static sensor, drawn only
@@ -522,6 +530,7 @@ int World::finalize(int max_steps, std::string &err) {
     int nverts = 0, npv = 0;
     for (auto &s : shapes) nverts += (s.kind == SH_CIRCLE) ? 1 : (int)s.verts.size();
     for (auto &p : prims) npv += (int)p.verts.size();
+    for (auto &p : prims) if (p.verts.size() > 32) { err = "primitive with more than 32 vertices"; return -2; }
     if ((int)bodies.size() > CAP_BODIES || (int)shapes.size() > CAP_SHAPES || nverts > CAP_VERTS ||
         (int)joints.size() > CAP_JOINTS || (int)pairs.size() > CAP_PAIRS || (int)prims.size() > CAP_PRIMS ||
         npv > CAP_PVERTS) {
@@ -644,10 +653,17 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
         pi[3] = P.xform | (P.body << 8) | ((P.eye_body + 1) << 16);
         pi[4] = P.rgb[0] | (P.rgb[1] << 8) | (P.rgb[2] << 16);
         pi[5] = P.stipple | ((P.goal + 1) << 16);      // low 16 bits: line stipple; high: 1 + goal ordinal
+        {
+            uint32_t ends = 0; int at = 0;
+            for (int n : P.parts) { at += n; ends |= 1u << (at - 1); }
+            if (P.parts.empty() && nv > 0 && P.kind != PR_NGON) ends = 1u << (nv - 1);
+            pi[6] = (int32_t)ends;
+        }
         pr[0] = P.eye_base[0]; pr[1] = P.eye_base[1]; pr[2] = P.eye_pre[0]; pr[3] = P.eye_pre[1];
         pr[4] = 0.5 * (P.line_width + 1.0);
         pr[5] = P.radius;
         for (size_t i = 0; i < P.verts.size(); i++) { rw[o.pvx + pvoff + i] = P.verts[i].x; rw[o.pvy + pvoff + i] = P.verts[i].y; }
+        for (size_t i = 0; i < P.verts.size(); i++) iw[o.pv_prim + pvoff + i] = k;
         pvoff += (int)P.verts.size();
     }
     double *c = &rw[o.consts];

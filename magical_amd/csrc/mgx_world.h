@@ -40,6 +40,7 @@ struct JointDef {
 struct PrimDef {
     int kind, xform, body, eye_body;
     std::vector<Vec2> verts;
+    std::vector<int> parts;    // PR_POLY made of several convex parts: their vertex counts (empty: one part)
     int rgb[3];
     double eye_base[2], eye_pre[2];
     double line_width; int stipple;

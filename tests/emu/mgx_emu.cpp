@@ -93,7 +93,7 @@ static void emu_raster(const World &w, const P *sp, int n_envs, int env, int vie
     const int nl = 7;   // odd lane count on purpose
     for (int lane = 0; lane < nl; lane++) raster_setup_bodies<P>(rs, sp, (long)n_envs, (long)env, lane, nl);
     for (int lane = 0; lane < nl; lane++) raster_setup_prims(rs, lane, nl);
-    for (int lane = 0; lane < nl; lane++) raster_setup_items(rs, lane, nl);
+    for (int lane = 0; lane < nl; lane++) raster_setup_edges(rs, lane, nl);
     const int bg = 231 | (231 << 8) | (234 << 16);
     const uint64_t all = h.n_prims >= 64 ? ~0ull : ((1ull << h.n_prims) - 1ull);
     if (native) {
