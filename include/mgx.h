@@ -68,6 +68,10 @@ int mgx_world_add_shape(mgx_world *w, int shape_type, int colour, double x, doub
 int mgx_world_add_goal(mgx_world *w, double x, double y, double h, double w_, int colour);
 /* freeze the entity list and build bodies / shapes / joints / collision pairs / draw list */
 int mgx_world_finalize(mgx_world *w, int max_episode_steps);
+/* a finalized copy of `w` with other per-episode choices (Test*Shape / CountPlus / All): entity k present iff
+ * enabled[k] (NULL: all as in w), blocks of shape type shape_types[k] (NULL or < 0: as in w).  The robot cannot be
+ * absent.  Entity and body indices are those of `w`. */
+int mgx_world_variant(const mgx_world *w, const uint8_t *enabled, const int32_t *shape_types, mgx_world **out);
 
 /* introspection (used by the host for scoring and by the parity tests) */
 enum mgx_info_key {
@@ -153,9 +157,32 @@ int mgx_engine_substeps(mgx_engine *e, void *state_p, void *state_f, int32_t *st
  * (base_env.py:309-338, benchmarks/__init__.py:80-136,219-256).  out: DEVICE u8, layout per `layout`;
  * env_stride in bytes (multiple of 4).  fill_mask (DEVICE u8[N] or NULL): envs whose stack is (re)filled
  * with 4 copies of the new frame (FlattenFrameStack.reset). */
-/* Test*Colour variants: primitive colours per env, DEVICE int32 [n_prims][N] owned by the caller and read by every
- * later render call (NULL = the world's own colours again) */
-int mgx_engine_set_prim_colours(mgx_engine *e, const int32_t *prim_rgb);
+/* Test*Colour variants: the colour (mgx_colour) of every entity per env, DEVICE int32 [n_entities][N] owned by the
+ * caller and read by every later render call (NULL = the world's own colours again); rows of the robot are ignored.
+ * A shape is painted base colour + darkened outline, a goal region lightened interior + base outline
+ * (entities.py:750-753,807-819; style.py:28-37) */
+int mgx_engine_set_entity_colours(mgx_engine *e, const int32_t *ent_colour);
+/* ---- per-env worlds: Test*Shape / TestCountPlus / TestAll variants draw the blocks' shape types and the number of
+ * entities anew every episode (e.g. cluster.py:81-110, match_regions.py:101-128).  The engine then keeps one world
+ * per env: same entity list as the engine's world (which lists every entity an episode can have), each entity
+ * present or absent and each block with its own shape type.  Body indices, entity indices and the state rows the
+ * host addresses (poses, velocities, force limits) are the same in every variant; an absent block has an inert body.
+ *
+ * enable: once, right after mgx_engine_create and before mgx_engine_state_shape; capacity_world = the largest world
+ * an episode can have (all entities present, all blocks stars) - it sizes the per-env template tables and LDS. */
+int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world);
+/* the worlds of the m envs env_idx[k] (HOST arrays): enabled[m][n_entities] (NULL: as in the engine's world),
+ * shape_types[m][n_entities] (mgx_shape_type; NULL or < 0: as in the engine's world; ignored for non-blocks).
+ * Builds / shares the variants, uploads their templates in stream order; call before the reset of those envs.
+ * Returns the number of distinct worlds in the call (>= 0). */
+int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, const uint8_t *enabled, const int32_t *shape_types, void *stream);
+/* mgx_world_randomise_all_poses_batch with env env_idx[k] placed in ITS world */
+int mgx_engine_env_randomise_all_poses_batch(const mgx_engine *e, int m, const int32_t *env_idx, double *poses, const int *ents, int n,
+                                             const uint8_t *ignore, const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
+                                             const double *pos_limits, const double *rot_limits, int limits_per_env,
+                                             const uint64_t *mt_state_addr, const double *ent_hw);
+/* mgx_world_info of env's current world */
+int mgx_engine_env_world_info(const mgx_engine *e, int env, int key, int *out);
 /* Test*Jitter / TestLayout variants with goal regions: the regions' rectangles per env, DEVICE double [n_goals * 4][N]
  * = x, y (top-left corner), h, w per goal in entity order (entities.py:769-819), caller-owned, read by every later
  * render call (NULL = the world's own rectangles again).  Goal regions are sensors: physics never sees them */

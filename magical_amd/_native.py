@@ -85,7 +85,13 @@ def lib():
         'mgx_world_placement_collides': [vp, i32, dp, C.POINTER(C.c_uint8), dp],
         'mgx_world_randomise_all_poses': [vp, dp, ip, i32, C.POINTER(C.c_uint8), dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), dp, dp,
                                           C.POINTER(C.c_uint32), ip, dp],
-        'mgx_engine_set_prim_colours': [vp, vp],
+        'mgx_engine_set_entity_colours': [vp, vp],
+        'mgx_world_variant': [vp, C.POINTER(C.c_uint8), ip, C.POINTER(vp)],
+        'mgx_engine_enable_env_worlds': [vp, vp],
+        'mgx_engine_set_env_variants': [vp, i32, ip, C.POINTER(C.c_uint8), ip, vp],
+        'mgx_engine_env_randomise_all_poses_batch': [vp, i32, ip, dp, ip, i32, C.POINTER(C.c_uint8), dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8),
+                                                     dp, dp, i32, C.POINTER(C.c_uint64), dp],
+        'mgx_engine_env_world_info': [vp, i32, i32, ip],
         'mgx_engine_set_goal_rects': [vp, vp],
         'mgx_engine_create': [vp, i32, i32, i32, i32, C.POINTER(vp)],
         'mgx_engine_state_shape': [vp, ip, ip, ip, ip, ip],
@@ -123,7 +129,8 @@ EXPORTED_SYMBOLS = [
     'mgx_world_add_robot', 'mgx_world_add_shape', 'mgx_world_add_goal', 'mgx_world_finalize', 'mgx_world_info',
     'mgx_world_entity', 'mgx_world_body_table', 'mgx_world_n_state_entries', 'mgx_world_state_entry',
     'mgx_world_goal_bb', 'mgx_world_entity_shapes', 'mgx_world_prim_table', 'mgx_world_palette', 'mgx_world_placement_collides', 'mgx_world_randomise_all_poses', 'mgx_world_randomise_all_poses_batch',
-    'mgx_engine_create', 'mgx_engine_destroy', 'mgx_engine_set_prim_colours', 'mgx_engine_set_goal_rects',
+    'mgx_engine_create', 'mgx_engine_destroy', 'mgx_engine_set_entity_colours', 'mgx_engine_set_goal_rects',
+    'mgx_world_variant', 'mgx_engine_enable_env_worlds', 'mgx_engine_set_env_variants', 'mgx_engine_env_randomise_all_poses_batch', 'mgx_engine_env_world_info',
     'mgx_engine_state_shape', 'mgx_engine_lanes_per_env', 'mgx_engine_lds_bytes', 'mgx_engine_reset', 'mgx_engine_reset_poses',
     'mgx_engine_step', 'mgx_engine_substeps', 'mgx_engine_render', 'mgx_engine_render_native',
     'mgx_engine_set_timing', 'mgx_engine_timing_read',

@@ -59,6 +59,11 @@ class BaseEnv(abc.ABC):
     JITTER_ROT_BOUND = JITTER_PCT * np.pi
     JITTER_TARGET_BOUND = JITTER_PCT * RAND_GOAL_SIZE_RANGE / 2
 
+    # True in tasks whose episodes differ in the blocks' shape types or in the number of entities (Test*Shape /
+    # TestCountPlus / TestAll): on_reset() then lists every entity an episode can have, sample_variation() says which
+    # are present ('enabled') and of what type ('shape_types'), and the engine keeps one world per env
+    variable_worlds = False
+
     def __init__(self, *, n_envs=1, device='cuda:0', res_hw=(384, 384), fps=8, phys_steps=10, phys_iter=10,
                  max_episode_steps=None, rand_dynamics=False, ego_view=True, allo_view=True,
                  dtype='f32', lanes_per_env=0, auto_reset=True):
@@ -164,6 +169,19 @@ class BaseEnv(abc.ABC):
         eng = C.c_void_p()
         nat.check(L.mgx_engine_create(w, self.n_envs, self.device.index or 0, self._dtype, self._lanes, C.byref(eng)))
         self._engine = eng
+        ne = len(self._entities)
+        self._default_shape_types = np.array([en.SHAPE_TYPE_ID[e.shape_type] if isinstance(e, en.Shape) else -1 for e in self._entities], dtype=np.int32)
+        self.entity_shape_types = np.tile(self._default_shape_types, (self.n_envs, 1))          # per env
+        self.entity_enabled = np.ones((self.n_envs, ne), dtype=bool)                              # per env
+        if self.variable_worlds:
+            # the largest world an episode can have sizes the engine's per-env tables: everything present, every block a star
+            cap_types = np.where(self._default_shape_types >= 0, en.SHAPE_TYPE_ID[en.ShapeType.STAR], -1).astype(np.int32)
+            cap = C.c_void_p()
+            nat.check(L.mgx_world_variant(w, None, cap_types.ctypes.data_as(C.POINTER(C.c_int)), C.byref(cap)))
+            try:
+                nat.check(L.mgx_engine_enable_env_worlds(eng, cap))
+            finally:
+                L.mgx_world_destroy(cap)
         rp, rf, ri, szp, szf = (C.c_int() for _ in range(5))
         nat.check(L.mgx_engine_state_shape(eng, C.byref(rp), C.byref(rf), C.byref(ri), C.byref(szp), C.byref(szf)))
         tp = torch.float64 if szp.value == 8 else torch.float32
@@ -175,13 +193,7 @@ class BaseEnv(abc.ABC):
         self._reward = torch.zeros(self.n_envs, dtype=torch.float32, device=self.device)
         self._steps = np.zeros(self.n_envs, dtype=np.int64)
         self.phys_vars = np.tile(np.asarray(PhysicsVariables.defaults(), dtype=np.float64), (self.n_envs, 1))   # per env
-        # draw list bookkeeping for per-env colours: template colour, painting entity and role of every primitive
-        n_prims = self._info('n_prims')
-        rgb0, pent, prole = ((C.c_int * n_prims)() for _ in range(3))
-        nat.check(L.mgx_world_prim_table(w, rgb0, pent, prole))
-        self._prim_rgb0, self._prim_ent, self._prim_role = (np.asarray(a[:], dtype=np.int64) for a in (rgb0, pent, prole))
-        self._palette = np.array([[nat.check(L.mgx_world_palette(c, r)) for c in range(4)] for r in range(3)], dtype=np.int64)
-        self._prim_rgb = None        # device int32[n_prims, N], allocated when an env first deviates from the template
+        self._ent_colour = None      # device int32[n_entities, N], allocated when an env first deviates from the template
         self._default_colours = np.array([en.COLOUR_ID[e.colour_name] if hasattr(e, 'colour_name') else -1 for e in self._entities], dtype=np.int64)
         self.entity_colours = np.tile(self._default_colours, (self.n_envs, 1))          # per env
         # initial (x, y, angle) of every entity's main body, per env
@@ -280,7 +292,7 @@ class BaseEnv(abc.ABC):
         its own stream self.rngs[k], in the reference's order: physics variables, then the task's on_reset choices), then
         the reset kernel -- with the drawn entity poses if any -- then the drawn force limits and colours."""
         import torch
-        pvs, colour_rows, pose_rows, pose_spec, hw_rows = [], [], [], None, {}
+        pvs, colour_rows, pose_rows, pose_spec, hw_rows, world_rows = [], [], [], None, {}, []
         for k in env_idx:
             rng = self.rngs[k]
             if self.rand_dynamics:
@@ -291,6 +303,13 @@ class BaseEnv(abc.ABC):
                 for ent, name in var['colours'].items():
                     row[ent.ent_id] = en.COLOUR_ID[name]
                 colour_rows.append(row)
+            if self.variable_worlds:
+                trow, erow = self._default_shape_types.copy(), np.ones(len(self._entities), dtype=bool)
+                for ent, t in (var or {}).get('shape_types', {}).items():
+                    trow[ent.ent_id] = en.SHAPE_TYPE_ID[en.ShapeType(t)]
+                for ent, on in (var or {}).get('enabled', {}).items():
+                    erow[ent.ent_id] = bool(on)
+                world_rows.append((trow, erow))
             if var is not None and 'poses' in var:
                 row = self._default_poses.copy()
                 for ent, pose in var['poses'].items():
@@ -300,6 +319,15 @@ class BaseEnv(abc.ABC):
                 pose_spec = var['randomise_poses']       # the same for every env of a task: one native call below
             if var is not None and 'goal_hw' in var:
                 hw_rows[int(k)] = {g.ent_id: hw for g, hw in var['goal_hw'].items()}
+        if world_rows:
+            # this episode's world of every env being reset, before anything is placed in it
+            idx32 = np.ascontiguousarray(env_idx, dtype=np.int32)
+            types = np.ascontiguousarray(np.stack([t for t, _ in world_rows]), dtype=np.int32)
+            enabled = np.ascontiguousarray(np.stack([e for _, e in world_rows]), dtype=np.uint8)
+            self.entity_shape_types[env_idx], self.entity_enabled[env_idx] = types, enabled.astype(bool)
+            nat.check(self._lib.mgx_engine_set_env_variants(self._engine, len(idx32), idx32.ctypes.data_as(C.POINTER(C.c_int)),
+                                                            enabled.ctypes.data_as(C.POINTER(C.c_uint8)), types.ctypes.data_as(C.POINTER(C.c_int)),
+                                                            self._stream()))
         ent_hw = None
         if hw_rows:
             # resized goal regions keep their top-left corner (GoalRegion(x, y, h, w), entities.py:769-797): new centre
@@ -324,10 +352,10 @@ class BaseEnv(abc.ABC):
                         # task-specific step between placements (e.g. move a block onto its region), or a placement whose
                         # limits depend on the env; gets the poses so far, the envs' goal sizes and a runner for placements
                         stage(batch, ent_hw, lambda ents, **kw: geom.pm_randomise_all_poses_batch(
-                            self, batch, ents, self.ARENA_BOUNDS_LRBT, rngs, ent_hw=ent_hw, **kw))
+                            self, batch, ents, self.ARENA_BOUNDS_LRBT, rngs, ent_hw=ent_hw, env_idx=env_idx, **kw))
                     else:
                         ents, kwargs = stage
-                        geom.pm_randomise_all_poses_batch(self, batch, ents, self.ARENA_BOUNDS_LRBT, rngs, ent_hw=ent_hw, **kwargs)
+                        geom.pm_randomise_all_poses_batch(self, batch, ents, self.ARENA_BOUNDS_LRBT, rngs, ent_hw=ent_hw, env_idx=env_idx, **kwargs)
             pose_rows = list(batch)
             if len(self._goal_ent_idx):
                 # the goal regions' rectangles of these envs, back in GoalRegion(x, y, h, w) form: x, y = top-left corner
@@ -361,13 +389,11 @@ class BaseEnv(abc.ABC):
         idx = np.arange(self.n_envs) if env_idx is None else np.asarray(env_idx)
         colour_ids = np.asarray(colour_ids, dtype=np.int64).reshape(len(idx), len(self._entities))
         self.entity_colours[idx] = colour_ids
-        rgb = np.tile(self._prim_rgb0[:, None], (1, len(idx)))                       # [n_prims, M]
-        for k in np.nonzero(self._prim_role >= 0)[0]:
-            rgb[k] = self._palette[self._prim_role[k], colour_ids[:, self._prim_ent[k]]]
-        if self._prim_rgb is None:
-            self._prim_rgb = torch.as_tensor(np.tile(self._prim_rgb0[:, None], (1, self.n_envs)).astype(np.int32), device=self.device).contiguous()
-            nat.check(self._lib.mgx_engine_set_prim_colours(self._engine, self._prim_rgb.data_ptr()))
-        self._prim_rgb[:, torch.as_tensor(idx, device=self.device)] = torch.as_tensor(rgb.astype(np.int32), device=self.device)
+        if self._ent_colour is None:
+            self._ent_colour = torch.as_tensor(np.maximum(self.entity_colours, 0).T.astype(np.int32), device=self.device).contiguous()   # [n_ent, N]
+            nat.check(self._lib.mgx_engine_set_entity_colours(self._engine, self._ent_colour.data_ptr()))
+        else:
+            self._ent_colour[:, torch.as_tensor(idx, device=self.device)] = torch.as_tensor(np.maximum(colour_ids, 0).T.astype(np.int32), device=self.device)
 
     def set_goal_rects(self, xyhw, env_idx=None):
         """xyhw: float64[M, n_goals, 4] = GoalRegion(x, y, h, w) of every goal region for the envs `env_idx`: what the

@@ -66,26 +66,51 @@ def _shape_hits_box(kind, radius, verts, pose, bb):
     return sep <= radius
 
 
+def shapes_of_type(env, type_id):
+    """[(kind, radius, local_verts)] of a block of native shape type `type_id` (the same for every block: SHAPE_RAD)."""
+    cache = env.__dict__.setdefault('_shape_library', {})
+    if type_id not in cache:
+        L = env._lib
+        ent = next(e for e in env._entities if isinstance(e, en.Shape))
+        types = np.where(env._default_shape_types >= 0, type_id, -1).astype(np.int32)
+        v = C.c_void_p()
+        nat.check(L.mgx_world_variant(env._world, None, types.ctypes.data_as(C.POINTER(C.c_int)), C.byref(v)))
+        try:
+            world, env._world = env._world, v           # entity_shapes() reads env._world
+            cache[type_id] = entity_shapes(env, ent)
+        finally:
+            env._world = world
+            L.mgx_world_destroy(v)
+    return cache[type_id]
+
+
 def overlapping_ents(env, goal, ents, poses):
     """GoalRegion.get_overlapping_ents(com_overlap=True) (entities.py:821-881), batched:
     bool[M, len(ents)] -- an entity counts iff EVERY one of its shapes overlaps the sensor AND its
-    body position lies inside the sensor's bounding box."""
+    body position lies inside the sensor's bounding box.  In tasks with per-env worlds a block has the shape type of
+    its env's episode, and blocks the episode does not have never count."""
     bb = env.goal_bb(goal)
     l, b, r, t = bb
     out = np.zeros((poses.shape[0], len(ents)), dtype=bool)
     for k, ent in enumerate(ents):
         pose = poses[:, ent.body, :]
         inside = (l <= pose[:, 0]) & (r >= pose[:, 0]) & (b <= pose[:, 1]) & (t >= pose[:, 1])
-        if not hasattr(ent, '_shapes_cache'):
-            ent._shapes_cache = entity_shapes(env, ent)
-        # the shape tests only matter where the body position is inside the box: evaluate them on those envs alone
-        sel = np.nonzero(inside)[0]
-        if len(sel) == 0:
-            continue
-        sub_pose = pose[sel]
-        sub_bb = tuple(v[sel] if isinstance(v, np.ndarray) and v.ndim else v for v in bb)
-        ok = np.ones(len(sel), dtype=bool)
-        for kind, radius, verts in ent._shapes_cache:
-            ok &= _shape_hits_box(kind, radius, verts, sub_pose, sub_bb)
-        out[sel, k] = ok
+        if env.variable_worlds:
+            inside &= env.entity_enabled[env._scoring_envs, ent.ent_id]
+            types = env.entity_shape_types[env._scoring_envs, ent.ent_id]
+            groups = [(shapes_of_type(env, int(ty)), np.nonzero(inside & (types == ty))[0]) for ty in np.unique(types[inside])]
+        else:
+            if not hasattr(ent, '_shapes_cache'):
+                ent._shapes_cache = entity_shapes(env, ent)
+            # the shape tests only matter where the body position is inside the box: evaluate them on those envs alone
+            groups = [(ent._shapes_cache, np.nonzero(inside)[0])]
+        for shapes, sel in groups:
+            if len(sel) == 0:
+                continue
+            sub_pose = pose[sel]
+            sub_bb = tuple(v[sel] if isinstance(v, np.ndarray) and v.ndim else v for v in bb)
+            ok = np.ones(len(sel), dtype=bool)
+            for kind, radius, verts in shapes:
+                ok &= _shape_hits_box(kind, radius, verts, sub_pose, sub_bb)
+            out[sel, k] = ok
     return out

@@ -1,4 +1,4 @@
-"""ClusterColour / ClusterShape (mirror of magical/benchmarks/cluster.py: Demo, TestColour, TestJitter, TestLayout and TestDynamics branches)."""
+"""ClusterColour / ClusterShape (mirror of magical/benchmarks/cluster.py, every rand_* branch)."""
 import abc
 import enum
 
@@ -15,32 +15,54 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
 
     def __init__(self, rand_shape_colour=False, rand_shape_type=False, rand_layout_minor=False, rand_layout_full=False,
                  rand_shape_count=False, cluster_by=ClusterBy.COLOUR, **kwargs):
-        if rand_shape_type or rand_shape_count:
-            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestLayout, TestDynamics (shape types / counts need per-env geometry: SURVEY.md §8f)')
         assert not (rand_layout_minor and rand_layout_full)
+        if rand_shape_count:     # cluster.py:56-63
+            assert rand_layout_full, 'if shape count is randomised then layout must also be fully randomised'
+            assert rand_shape_type, 'if shape count is randomised then shape type must also be randomised'
+            assert rand_shape_colour, 'if shape count is randomised then colour must be randomised too'
         self.rand_layout_minor, self.rand_layout_full = rand_layout_minor, rand_layout_full
         self.cluster_by = cluster_by
-        self.rand_shape_colour = rand_shape_colour
+        self.rand_shape_colour, self.rand_shape_type, self.rand_shape_count = rand_shape_colour, rand_shape_type, rand_shape_count
+        self.variable_worlds = bool(rand_shape_type or rand_shape_count)
         self._class_env = None
         super().__init__(**kwargs)
 
-    def sample_variation(self, rng, k):   # cluster.py:91-100 (colours), :148-161 (poses: robot first, then the blocks)
-        if not (self.rand_shape_colour or self.rand_layout_minor or self.rand_layout_full):
+    def sample_variation(self, rng, k):   # cluster.py:81-110 (count, colours, types), :148-161 (poses: robot first, then the blocks)
+        if not (self.rand_shape_colour or self.rand_shape_type or self.rand_layout_minor or self.rand_layout_full):
             return None
         var = {}
+        ents = self.__shape_ents
+        n_shapes = len(ents)
+        if self.rand_shape_count:                 # the first n of the (up to 10) blocks
+            n_shapes = rng.randint(7, 10 + 1)
+            var['enabled'] = {b: i < n_shapes for i, b in enumerate(ents)}
+        values = None
         if self.rand_shape_colour:
             # at least one block of each colour, the rest drawn, then shuffled
             names = en.SHAPE_COLOUR_NAMES
             colours = list(names)
-            colours.extend([rng.choice(names) for _ in range(len(self.__shape_ents) - len(colours))])
+            colours.extend([rng.choice(names) for _ in range(n_shapes - len(colours))])
             rng.shuffle(colours)
+            var['colours'] = dict(zip(ents, colours))
             if self.cluster_by == self.ClusterBy.COLOUR:
-                # class of a block = rank of its colour among the colours present (np.unique sorts them; all four are present)
-                if self._class_env is None:
-                    self._class_env = np.tile(self.__class_of_block, (self.n_envs, 1))
-                order = {c: i for i, c in enumerate(sorted(set(colours)))}
-                self._class_env[k] = [order[c] for c in colours]
-            var['colours'] = dict(zip(self.__shape_ents, colours))
+                values = colours
+        if self.rand_shape_type:
+            # likewise one of each type
+            names = en.SHAPE_TYPE_NAMES
+            shape_types = list(names)
+            shape_types.extend([rng.choice(names) for _ in range(n_shapes - len(shape_types))])
+            rng.shuffle(shape_types)
+            var['shape_types'] = dict(zip(ents, shape_types))
+            if self.cluster_by == self.ClusterBy.TYPE:
+                values = shape_types
+        if values is not None or self.rand_shape_count:
+            # class of a block = rank of its colour / type among the values present (np.unique sorts them; all four are present)
+            if self._class_env is None:
+                self._class_env = np.tile(np.concatenate([self.__class_of_block, np.zeros(len(ents) - len(self.__class_of_block), dtype=np.int64)]), (self.n_envs, 1))
+            if values is not None:
+                order = {c: i for i, c in enumerate(sorted(set(str(v) for v in values)))}
+                row = [order[str(c)] for c in values]
+                self._class_env[k] = row + [0] * (len(ents) - len(row))
         if self.rand_layout_minor or self.rand_layout_full:
             all_ents = [self._robot, *self.__shape_ents]
             pos_limit, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if self.rand_layout_minor else (None, None)
@@ -52,9 +74,14 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
         colours, shape_types, poses = self.DEFAULT_BLOCK_COLOURS, self.DEFAULT_BLOCK_SHAPES, self.DEFAULT_BLOCK_POSES
         shape_ents = [self._make_shape(shape_type=st, colour_name=c, init_pos=(x, y), init_angle=a)
                       for ((x, y), a), c, st in zip(poses, colours, shape_types)]
+        if self.rand_shape_count:
+            # every block an episode can have (cluster.py:81-85: 7 to 10); which exist, their colours, types and poses are
+            # drawn per episode
+            shape_ents = [self._make_shape(shape_type=en.ShapeType.SQUARE, colour_name=en.ShapeColour.RED, init_pos=(0, 0), init_angle=0)
+                          for _ in range(10)]
         self.add_entities(shape_ents)
         values = colours if self.cluster_by == self.ClusterBy.COLOUR else shape_types
-        c_values_list = np.asarray([v.value for v in values], dtype='object')
+        c_values_list = np.asarray([v.value for v in values], dtype='object')     # (of the Demo layout; per env where drawn)
         self.__characteristic_values = np.unique(c_values_list)          # sorted, like the reference
         self.__shape_ents = shape_ents
         self.__members = [[k for k, v in enumerate(c_values_list) if v == c_value]
@@ -72,9 +99,12 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
         sums = np.zeros((M, nvals, 2))
         counts = np.zeros((M, nvals))
         rows = np.arange(M)
+        # blocks the env's episode does not have (rand_shape_count) take no part
+        present = self.entity_enabled[self._scoring_envs][:, [e.ent_id for e in self.__shape_ents]] if self.variable_worlds else np.ones((M, n_blocks), dtype=bool)
         for k in range(n_blocks):
-            sums[rows, cls[:, k]] += pos[:, k]
-            counts[rows, cls[:, k]] += 1.0
+            on = present[:, k]
+            sums[rows[on], cls[on, k]] += pos[on, k]
+            counts[rows[on], cls[on, k]] += 1.0
         centroids = sums / counts[:, :, None]
         min_margin = 2.0
         n_correct = np.zeros(M, dtype=np.int64)
@@ -84,8 +114,8 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
             others = np.where(np.arange(nvals)[None, :] == cls[:, k, None], np.inf, centroid_sses)
             nearest_bad_centroid = np.min(others, axis=1)
             margin = min_margin * true_sse        # squared distance as margin: reference quirk (cluster.py:203-206)
-            n_correct += (np.sqrt(true_sse) < np.sqrt(nearest_bad_centroid) - margin).astype(np.int64)
-        frac_correct = n_correct.astype(np.float64) / max(n_blocks, 1)
+            n_correct += ((np.sqrt(true_sse) < np.sqrt(nearest_bad_centroid) - margin) & present[:, k]).astype(np.int64)
+        frac_correct = n_correct.astype(np.float64) / np.maximum(present.sum(axis=1), 1)
         thresh = 0.75
         return np.maximum(frac_correct - thresh, 0) / (1 - thresh)
 

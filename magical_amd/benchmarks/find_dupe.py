@@ -1,4 +1,4 @@
-"""FindDupe (mirror of magical/benchmarks/find_dupe.py: Demo, TestColour, TestJitter, TestLayout and TestDynamics branches)."""
+"""FindDupe (mirror of magical/benchmarks/find_dupe.py, every rand_* branch)."""
 import numpy as np
 
 from .. import entities as en
@@ -22,30 +22,49 @@ DEFAULT_QUERY_BLOCK_POSE = ((-0.33, -0.49), -0.51)
 class FindDupeEnv(BaseEnv):
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
-        if rand_shapes or rand_count:
-            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestLayout, TestDynamics (shape types / counts need per-env geometry: SURVEY.md §8f)')
         assert not (rand_layout_minor and rand_layout_full)
+        if rand_count:       # find_dupe.py:67-70
+            assert rand_layout_full and rand_shapes and rand_colours, 'if count is randomised then layout, shapes and colours must be too'
         self.rand_colours, self.rand_layout_minor, self.rand_layout_full = rand_colours, rand_layout_minor, rand_layout_full
+        self.rand_shapes, self.rand_count = rand_shapes, rand_count
+        self.variable_worlds = bool(rand_shapes or rand_count)
         self._is_target_env = None
         super().__init__(**kwargs)
 
-    def sample_variation(self, rng, k):   # find_dupe.py:90-95 (colours), :101-112 (region size), :157-196 (poses)
-        if not (self.rand_colours or self.rand_layout_minor or self.rand_layout_full):
+    def sample_variation(self, rng, k):   # find_dupe.py:84-100 (count, colours, shapes), :101-112 (region size), :157-196 (poses)
+        if not (self.rand_colours or self.rand_shapes or self.rand_layout_minor or self.rand_layout_full):
             return None
         var = {}
+        outside = self.__outside_blocks
+        n_out_blocks = len(outside)
+        if self.rand_count:
+            # 1..5 random blocks plus one that always matches the query: the first n of the six outside blocks
+            n_out_blocks = rng.randint(1, 5 + 1) + 1
+            var['enabled'] = {b: i < n_out_blocks for i, b in enumerate(outside)}
+        n_distractors = n_out_blocks - 1
+        query_colour, query_shape = DEFAULT_QUERY_COLOUR.value, DEFAULT_QUERY_SHAPE.value
+        out_block_colours = [c.value for c in DEFAULT_OUT_BLOCK_COLOURS]
+        out_block_shapes = [t.value for t in DEFAULT_OUT_BLOCK_SHAPES]
         if self.rand_colours:
             names = en.SHAPE_COLOUR_NAMES
             query_colour = rng.choice(names)
-            out_block_colours = rng.choice(names, size=len(self.__outside_blocks) - 1).tolist()
+            out_block_colours = rng.choice(names, size=n_distractors).tolist()
             out_block_colours.append(query_colour)               # the last outside block always matches the query
+            colours = {self.__sensor_ref: query_colour, self.__all_blocks[0]: query_colour}
+            colours.update(zip(outside, out_block_colours))
+            var['colours'] = colours
+        if self.rand_shapes:
+            query_shape = rng.choice(en.SHAPE_TYPE_NAMES)
+            out_block_shapes = rng.choice(en.SHAPE_TYPE_NAMES, size=n_distractors).tolist()
+            out_block_shapes.append(query_shape)
+            var['shape_types'] = {self.__all_blocks[0]: query_shape}
+            var['shape_types'].update(zip(outside, out_block_shapes))
+        if self.rand_colours or self.rand_shapes:
             if self._is_target_env is None:
                 self._is_target_env = np.tile(self.__is_target, (self.n_envs, 1))
             # __all_blocks = [query block, *outside blocks]; a block is a target iff it has the query's colour and shape
-            self._is_target_env[k] = [True] + [c == query_colour and s == DEFAULT_QUERY_SHAPE
-                                               for c, s in zip(out_block_colours, DEFAULT_OUT_BLOCK_SHAPES)]
-            colours = {self.__sensor_ref: query_colour, self.__all_blocks[0]: query_colour}
-            colours.update(zip(self.__outside_blocks, out_block_colours))
-            var['colours'] = colours
+            row = [True] + [c == query_colour and t == query_shape for c, t in zip(out_block_colours, out_block_shapes)]
+            self._is_target_env[k] = row + [False] * (len(self.__all_blocks) - len(row))
         if self.rand_layout_minor or self.rand_layout_full:
             minor = self.rand_layout_minor
             var['goal_hw'] = {self.__sensor_ref: geom.randomise_hw(self.RAND_GOAL_MIN_SIZE, self.RAND_GOAL_MAX_SIZE, rng,
@@ -75,6 +94,7 @@ class FindDupeEnv(BaseEnv):
         self.add_entities([sensor])
         self.__sensor_ref = sensor
         outside_blocks, targets = [], []
+        # (with rand_count the six outside blocks are the most an episode can have: find_dupe.py:84-87)
         for bshape, bcol, (bpos, bangle) in zip(DEFAULT_OUT_BLOCK_SHAPES, DEFAULT_OUT_BLOCK_COLOURS, DEFAULT_OUT_BLOCK_POSES):
             blk = self._make_shape(shape_type=bshape, colour_name=bcol, init_pos=bpos, init_angle=bangle)
             outside_blocks.append(blk)

@@ -1,4 +1,4 @@
-"""FixColour (mirror of magical/benchmarks/fix_colour.py: Demo, TestColour, TestJitter, TestLayout and TestDynamics branches)."""
+"""FixColour (mirror of magical/benchmarks/fix_colour.py, every rand_* branch)."""
 import numpy as np
 
 from .. import entities as en
@@ -13,25 +13,32 @@ DEFAULT_BLOCK_POSES = [((0.289, 0.030), 0.307), ((0.133, -0.561), 1.699), ((-0.3
 DEFAULT_REGION_XYHWS = [(-0.032, 0.348, 0.427, 0.468), (0.019, -0.391, 0.460, 0.458), (-0.681, 0.196, 0.498, 0.418)]
 DEFAULT_REGION_COLOURS = [en.ShapeColour.GREEN, en.ShapeColour.GREEN, en.ShapeColour.RED]
 MIN_GOAL_SIZE, MAX_GOAL_SIZE = 0.4, 0.5      # fix_colour.py:13-14
+MIN_REGIONS, MAX_REGIONS = 2, 3             # fix_colour.py:9-10
 
 
 class FixColourEnv(BaseEnv):
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
-        if rand_shapes or rand_count:
-            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestLayout, TestDynamics (shape types / counts need per-env geometry: SURVEY.md §8f)')
         assert not (rand_layout_minor and rand_layout_full)
+        if rand_count:       # fix_colour.py:62-65
+            assert rand_layout_full and rand_shapes and rand_colours, 'if count is randomised then layout, shapes and colours must be too'
         self.rand_colours, self.rand_layout_minor, self.rand_layout_full = rand_colours, rand_layout_minor, rand_layout_full
+        self.rand_shapes, self.rand_count = rand_shapes, rand_count
+        self.variable_worlds = bool(rand_shapes or rand_count)
         self._keep_env = None
         super().__init__(**kwargs)
 
     def sample_variation(self, rng, k):   # fix_colour.py:84-94 (colours), :102-113 (region sizes), :143-187 (poses)
-        if not (self.rand_colours or self.rand_layout_minor or self.rand_layout_full):
+        if not (self.rand_colours or self.rand_shapes or self.rand_layout_minor or self.rand_layout_full):
             return None
         var = {}
+        n_regions = len(self._sensors)
+        if self.rand_count:                       # fix_colour.py:78-82: the first n of the (up to MAX_REGIONS = 3) region + block pairs
+            n_regions = rng.randint(MIN_REGIONS, MAX_REGIONS + 1)
+            var['enabled'] = {e: i < n_regions for ents in (self._sensors, self._blocks) for i, e in enumerate(ents)}
         if self.rand_colours:
             names = en.SHAPE_COLOUR_NAMES
-            region_colours = rng.choice(names, size=len(self._blocks)).tolist()
+            region_colours = rng.choice(names, size=n_regions).tolist()
             block_colours = list(region_colours)
             odd_idx = rng.randint(len(block_colours))            # one block gets a colour that is not its region's
             new_col_idx = rng.randint(len(names) - 1)
@@ -40,15 +47,18 @@ class FixColourEnv(BaseEnv):
             block_colours[odd_idx] = names[new_col_idx]
             if self._keep_env is None:
                 self._keep_env = np.tile(np.asarray(self._keep, dtype=bool), (self.n_envs, 1))
-            self._keep_env[k] = [b == t for b, t in zip(block_colours, region_colours)]
+            keep = [b == t for b, t in zip(block_colours, region_colours)]
+            self._keep_env[k] = keep + [False] * (len(self._sensors) - n_regions)
             colours = dict(zip(self._sensors, region_colours))
             colours.update(zip(self._blocks, block_colours))
             var['colours'] = colours
+        if self.rand_shapes:                      # fix_colour.py:97-99
+            var['shape_types'] = dict(zip(self._blocks, rng.choice(en.SHAPE_TYPE_NAMES, size=n_regions).tolist()))
         if self.rand_layout_minor or self.rand_layout_full:
             minor = self.rand_layout_minor
             hw_bound = self.JITTER_TARGET_BOUND if minor else None
             var['goal_hw'] = {s: geom.randomise_hw(MIN_GOAL_SIZE, MAX_GOAL_SIZE, rng, current_hw=xyhw[2:], linf_bound=hw_bound)
-                              for s, xyhw in zip(self._sensors, DEFAULT_REGION_XYHWS)}
+                              for s, xyhw in zip(self._sensors[:n_regions], DEFAULT_REGION_XYHWS)}
             sensors, blocks, robot = self._sensors, self._blocks, self._robot
             pos_limits, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if minor else (None, None)
 
@@ -87,5 +97,8 @@ class FixColourEnv(BaseEnv):
             ov = overlapping_ents(self, sensor, self._blocks, poses)
             expected = np.zeros((poses.shape[0], len(self._blocks)), dtype=bool)
             expected[:, k] = keep[:, k]
-            complete &= (ov == expected).all(axis=1)
+            ok = (ov == expected).all(axis=1)
+            if self.variable_worlds:              # a region the episode does not have asks for nothing
+                ok |= ~self.entity_enabled[self._scoring_envs, sensor.ent_id]
+            complete &= ok
         return np.where(complete, 1.0, 0.0)

@@ -1,4 +1,4 @@
-"""MakeLine (mirror of magical/benchmarks/make_line.py: Demo, TestColour, TestJitter, TestLayout and TestDynamics branches)."""
+"""MakeLine (mirror of magical/benchmarks/make_line.py, every rand_* branch)."""
 import numpy as np
 
 from .. import entities as en
@@ -7,6 +7,7 @@ from ._scoring import row_norm
 
 INLIER_RAD_MULT = 1.5
 MAX_SEP_RADS = 3.5
+MIN_BLOCKS, MAX_BLOCKS = 3, 4      # make_line.py:12-13
 DEFAULT_ROBOT_POSE = ((0.702, -0.255), 0.347)
 DEFAULT_BLOCK_COLOURS = [en.ShapeColour.BLUE, en.ShapeColour.YELLOW, en.ShapeColour.RED, en.ShapeColour.GREEN]
 DEFAULT_BLOCK_SHAPES = [en.ShapeType.STAR, en.ShapeType.CIRCLE, en.ShapeType.STAR, en.ShapeType.PENTAGON]
@@ -75,10 +76,12 @@ def longest_line_batch(points, inlier_dist, max_separation):
 class MakeLineEnv(BaseEnv):
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
-        if rand_shapes or rand_count:
-            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestLayout, TestDynamics (shape types / counts need per-env geometry: SURVEY.md §8f)')
         assert not (rand_layout_minor and rand_layout_full)
+        if rand_count:       # make_line.py:86-89
+            assert rand_layout_full and rand_shapes and rand_colours, 'if count is randomised then layout, shapes and colours must be too'
         self.rand_colours, self.rand_layout_minor, self.rand_layout_full = rand_colours, rand_layout_minor, rand_layout_full
+        self.rand_shapes, self.rand_count = rand_shapes, rand_count
+        self.variable_worlds = bool(rand_shapes or rand_count)
         super().__init__(**kwargs)
         self.inlier_dist = self.SHAPE_RAD * INLIER_RAD_MULT
         self.max_sep = self.SHAPE_RAD * MAX_SEP_RADS
@@ -91,12 +94,18 @@ class MakeLineEnv(BaseEnv):
         self.add_entities([robot])
 
     def sample_variation(self, rng, k):   # make_line.py:105-107 (colours), :124-139 (poses: robot first, then the blocks)
-        if not (self.rand_colours or self.rand_layout_minor or self.rand_layout_full):
+        if not (self.rand_colours or self.rand_shapes or self.rand_layout_minor or self.rand_layout_full):
             return None
         var = {}
+        n_blocks = len(self._blocks)
+        if self.rand_count:                       # make_line.py:100-102: the first n of the (up to MAX_BLOCKS = 4) blocks
+            n_blocks = rng.randint(MIN_BLOCKS, MAX_BLOCKS + 1)
+            var['enabled'] = {b: i < n_blocks for i, b in enumerate(self._blocks)}
         if self.rand_colours:
-            block_colours = rng.choice(en.SHAPE_COLOUR_NAMES, size=len(self._blocks)).tolist()
+            block_colours = rng.choice(en.SHAPE_COLOUR_NAMES, size=n_blocks).tolist()
             var['colours'] = dict(zip(self._blocks, block_colours))
+        if self.rand_shapes:                      # make_line.py:108-110
+            var['shape_types'] = dict(zip(self._blocks, rng.choice(en.SHAPE_TYPE_NAMES, size=n_blocks).tolist()))
         if self.rand_layout_minor or self.rand_layout_full:
             all_ents = (self._robot, *self._blocks)
             pos_limits, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if self.rand_layout_minor else (None, None)
@@ -105,6 +114,17 @@ class MakeLineEnv(BaseEnv):
 
     def score_on_end_of_traj(self, poses):   # make_line.py:142-152
         bodies = [b.body for b in self._blocks]
+        if not self.variable_worlds:
+            return self._line_score(poses, bodies)
+        # the episode's blocks are the first n of the list: score the envs count by count
+        n_env = self.entity_enabled[self._scoring_envs][:, [b.ent_id for b in self._blocks]].sum(axis=1)
+        score = np.zeros(poses.shape[0], dtype=np.float64)
+        for n in np.unique(n_env):
+            sel = np.nonzero(n_env == n)[0]
+            score[sel] = self._line_score(poses[sel], bodies[:int(n)])
+        return score
+
+    def _line_score(self, poses, bodies):
         max_line_len = len(bodies)
         min_line_len = max(max_line_len - 2, 2)
         points = np.ascontiguousarray(poses[:, bodies, :2], dtype='float64')

@@ -1,4 +1,4 @@
-"""MatchRegions (mirror of magical/benchmarks/match_regions.py: Demo, TestColour, TestJitter, TestLayout and TestDynamics branches)."""
+"""MatchRegions (mirror of magical/benchmarks/match_regions.py, every rand_* branch)."""
 import math
 
 import numpy as np
@@ -12,14 +12,17 @@ from ._scoring import overlapping_ents
 class MatchRegionsEnv(BaseEnv):
     def __init__(self, rand_target_colour=False, rand_shape_type=False, rand_shape_count=False,
                  rand_layout_minor=False, rand_layout_full=False, **kwargs):
-        if rand_shape_type or rand_shape_count:
-            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestLayout, TestDynamics (shape types / counts need per-env geometry: SURVEY.md §8f)')
         assert not (rand_layout_minor and rand_layout_full)
+        if rand_shape_count:     # match_regions.py:33-40
+            assert rand_layout_full, 'if shape count is randomised then layout must also be fully randomised'
+            assert rand_shape_type, 'if shape count is randomised then shape type must also be randomised'
         self.rand_target_colour, self.rand_layout_minor, self.rand_layout_full = rand_target_colour, rand_layout_minor, rand_layout_full
+        self.rand_shape_type, self.rand_shape_count = rand_shape_type, rand_shape_count
+        self.variable_worlds = bool(rand_shape_type or rand_shape_count)
         super().__init__(**kwargs)
 
     def sample_variation(self, rng, k):   # match_regions.py:51-72 (colour, then the region's size), :166-188 (poses)
-        if not (self.rand_target_colour or self.rand_layout_minor or self.rand_layout_full):
+        if not (self.rand_target_colour or self.rand_layout_minor or self.rand_layout_full or self.rand_shape_type):
             return None
         var = {}
         if self.rand_target_colour:
@@ -34,6 +37,21 @@ class MatchRegionsEnv(BaseEnv):
             hw_bound = self.JITTER_TARGET_BOUND if self.rand_layout_minor else None
             var['goal_hw'] = {self.__sensor_ref: geom.randomise_hw(self.RAND_GOAL_MIN_SIZE, self.RAND_GOAL_MAX_SIZE, rng,
                                                                    current_hw=(0.7, 0.6), linf_bound=hw_bound)}
+        # match_regions.py:101-117: how many blocks (targets, then per distractor colour), then their types in the same order
+        targets, groups = self.__target_shapes, self.__distractor_by_group
+        target_count, distractor_counts = len(targets), [len(g) for g in groups]
+        if self.rand_shape_count:
+            target_count = rng.randint(1, 2 + 1)
+            distractor_counts = [rng.randint(0, 2 + 1) for _ in groups]
+            var['enabled'] = {s: i < target_count for i, s in enumerate(targets)}
+            for g, n in zip(groups, distractor_counts):
+                var['enabled'].update({s: i < n for i, s in enumerate(g)})
+        if self.rand_shape_type:
+            types_np = en.shape_types_obj()
+            var['shape_types'] = {s: rng.choice(types_np) for s in targets[:target_count]}
+            for g, n in zip(groups, distractor_counts):
+                var['shape_types'].update({s: rng.choice(types_np) for s in g[:n]})
+        if self.rand_layout_minor or self.rand_layout_full:
             all_ents = (self.__sensor_ref, self._robot, *self.__target_shapes, *self.__distractor_shapes)
             pos_limits, rot_limits = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if self.rand_layout_minor else (None, None)
             var['randomise_poses'] = (all_ents, dict(rand_pos=True, rand_rot=[False] + [True] * (len(all_ents) - 1),
@@ -51,14 +69,21 @@ class MatchRegionsEnv(BaseEnv):
         distractor_types = [[], [en.ShapeType.PENTAGON], [en.ShapeType.CIRCLE, en.ShapeType.PENTAGON]]
         target_poses = [(0.8, -0.7, 2.37), (-0.68, 0.72, 1.28)]
         distractor_poses = [[], [(-0.05, -0.2, -1.09)], [(-0.75, -0.55, 2.78), (0.3, -0.82, -1.15)]]
+        if self.rand_shape_count:
+            # every block an episode can have (match_regions.py:101-105: up to 2 targets and 2 distractors per colour);
+            # which of them exist, their types and their poses are drawn per episode
+            distractor_types = [[en.ShapeType.SQUARE] * 2 for _ in distractor_colours]
+            distractor_poses = [[(0, 0, 0)] * 2 for _ in distractor_colours]
         self.__target_shapes = [
             self._make_shape(shape_type=st, colour_name=target_colour, init_pos=(x, y), init_angle=a)
             for st, (x, y, a) in zip(target_types, target_poses)]
-        self.__distractor_shapes, self.__distractor_group = [], []
+        self.__distractor_shapes, self.__distractor_group, self.__distractor_by_group = [], [], []
         for group, (colour, types, poses) in enumerate(zip(distractor_colours, distractor_types, distractor_poses)):
+            self.__distractor_by_group.append([])
             for st, (x, y, a) in zip(types, poses):
                 self.__distractor_group.append(group)
                 self.__distractor_shapes.append(self._make_shape(shape_type=st, colour_name=colour, init_pos=(x, y), init_angle=a))
+                self.__distractor_by_group[-1].append(self.__distractor_shapes[-1])
         self.add_entities(self.__target_shapes + self.__distractor_shapes)
         self.add_entities([robot])    # last, so it is drawn on top
 
@@ -69,6 +94,8 @@ class MatchRegionsEnv(BaseEnv):
         n_overlap_targets = ov[:, :nt].sum(axis=1)
         n_overlap_distractors = ov[:, nt:].sum(axis=1)
         n_overlap = ov.sum(axis=1)
-        target_frac_done = n_overlap_targets / nt
+        # len(self.__target_shapes) of the env's own episode
+        n_targets = self.entity_enabled[self._scoring_envs][:, [s.ent_id for s in self.__target_shapes]].sum(axis=1) if self.variable_worlds else nt
+        target_frac_done = n_overlap_targets / n_targets
         contamination_rate = np.where(n_overlap == 0, 0.0, n_overlap_distractors / np.maximum(n_overlap, 1))
         return target_frac_done * (1 - contamination_rate)

@@ -1,4 +1,4 @@
-"""MoveToCorner (mirror of magical/benchmarks/move_to_corner.py: Demo, TestColour and TestDynamics branches)."""
+"""MoveToCorner (mirror of magical/benchmarks/move_to_corner.py, every rand_* branch)."""
 import math
 import warnings
 
@@ -11,9 +11,8 @@ from ._scoring import row_norm
 
 class MoveToCornerEnv(BaseEnv):
     def __init__(self, rand_shape_colour=False, rand_shape_type=False, rand_poses=False, debug_reward=False, **kwargs):
-        if rand_shape_type:
-            raise NotImplementedError('built: Demo, TestColour, TestJitter, TestDynamics, DebugReward (shape types need per-env geometry: SURVEY.md §8f)')
-        self.rand_shape_colour, self.rand_poses, self.debug_reward = rand_shape_colour, rand_poses, debug_reward
+        self.rand_shape_colour, self.rand_shape_type, self.rand_poses, self.debug_reward = rand_shape_colour, rand_shape_type, rand_poses, debug_reward
+        self.variable_worlds = bool(rand_shape_type)      # the block's shape type is drawn per episode
         if debug_reward:     # move_to_corner.py:25-29
             warnings.warn('DEBUG REWARD ENABLED IN MOVE-TO-CORNER ENV! This reward is ONLY intended for training RL algorithms '
                           "during debugging, so don't forget to disable it when benchmarking IL")
@@ -43,11 +42,13 @@ class MoveToCornerEnv(BaseEnv):
         return shaping + score
 
     def sample_variation(self, rng, k):   # move_to_corner.py:42-63, in the reference's order: colour, then poses
-        if not (self.rand_shape_colour or self.rand_poses):
+        if not (self.rand_shape_colour or self.rand_shape_type or self.rand_poses):
             return None
         var = {}
         if self.rand_shape_colour:
             var['colours'] = {self.__shape_ref: rng.choice(en.shape_colours_obj())}
+        if self.rand_shape_type:
+            var['shape_types'] = {self.__shape_ref: rng.choice(en.shape_types_obj())}
         if self.rand_poses:
             var['randomise_poses'] = ((self._robot, self.__shape_ref), dict(
                 rand_pos=True, rand_rot=True, rel_pos_linf_limits=self.JITTER_POS_BOUND, rel_rot_limits=self.JITTER_ROT_BOUND))

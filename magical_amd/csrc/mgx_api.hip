@@ -2,12 +2,16 @@
 // kernel launches.  Device state blobs and output tensors are owned by the caller (PyTorch);
 // the engine owns only its small constant template buffers and timing events.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <iterator>
 #include <thread>
 #include <type_traits>
 
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/mgx.h"
@@ -33,15 +37,33 @@ constexpr int TIMING_RING = 4096;
 
 struct mgx_world { World w; };
 
+// host copy of one world's two device blobs
+struct WorldBlobs {
+    TmplHeader h;                    // full header (with the draw list)
+    std::vector<uint32_t> step;      // [header without prims][ints][R words][P words]
+    std::vector<uint32_t> raster;    // [header][ints][prim reals + prim verts, fp64]
+    int step_env_stride = 0;         // LDS words of the per-env working set
+    int raster_scratch_d = 0, raster_off_tiles = 0;
+};
+
 struct mgx_engine {
     World w;
-    TmplHeader h;
-    int n_envs = 0, device = 0, dtype = 0, L = 0;
+    TmplHeader h;               // of the default world (capacity world once per-env worlds are enabled: sizes only)
+    int n_envs = 0, device = 0, dtype = 0, L = 0, L_request = 0;
     uint32_t *d_step = nullptr, *d_raster = nullptr;
+    int32_t *d_palette = nullptr;
     TmplDev tdev{};
     RasterDev rdev{};
     int raster_waves = 4;       // k_raster variant: workgroups per CU its register cap is set for (3, 4 or 5)
     size_t lds_step = 0, lds_raster = 0;
+    int rows_p = 0, rows_f = 0, rows_i = 0;
+    // per-env worlds (tasks whose episodes differ in shape types / entity counts)
+    bool env_worlds = false;
+    std::vector<std::shared_ptr<World>> env_world;                       // [n_envs]; empty pointer = the default world
+    std::unordered_map<std::string, std::weak_ptr<World>> world_by_sig;  // live variants, shared between envs
+    int step_stride = 0, raster_stride = 0;                             // words per env in the two blob tables
+    uint32_t *d_stage = nullptr; size_t stage_words = 0;                 // upload staging (device)
+    int32_t *d_stage_idx = nullptr; size_t stage_idx_n = 0;
     int timing = 0;             // 0 = off, n = bracket every n-th launch of each kind with HIP events
     int launch_count[2] = {0, 0};
     int dbg_iterations = -1;    // development probe: override the solver iteration count
@@ -98,6 +120,18 @@ int mgx_world_finalize(mgx_world *w, int max_episode_steps) {
     std::string err;
     int rc = w->w.finalize(max_episode_steps, err);
     if (rc) return fail(rc == -2 ? MGX_ERR_CAPACITY : (rc == -3 ? MGX_ERR_STATE : MGX_ERR_ARG), err);
+    return MGX_OK;
+}
+int mgx_world_variant(const mgx_world *w, const uint8_t *enabled, const int32_t *shape_types, mgx_world **out) {
+    if (!w || !out) return fail(MGX_ERR_ARG, "NULL argument");
+    if (!w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
+    mgx_world *v = new mgx_world();
+    std::string err;
+    std::vector<int> st;
+    if (shape_types) st.assign(shape_types, shape_types + w->w.entities.size());
+    int rc = w->w.variant(enabled, shape_types ? st.data() : nullptr, v->w, err);
+    if (rc) { delete v; return fail(rc == -2 ? MGX_ERR_CAPACITY : MGX_ERR_ARG, err); }
+    *out = v;
     return MGX_OK;
 }
 int mgx_world_info(const mgx_world *w, int key, int *out) {
@@ -193,16 +227,15 @@ int mgx_world_randomise_all_poses(const mgx_world *w, double *poses, const int *
     if (rc < 0) return fail(MGX_ERR_CAPACITY, "could not place the entities (PlacementError after 10 retries)");
     return rc;
 }
-int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses, const int *ents, int n, const uint8_t *ignore,
-                                        const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
-                                        const double *pos_limits, const double *rot_limits, int limits_per_env,
-                                        const uint64_t *mt_state_addr, const double *ent_hw) {
-    if (!w || !w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
-    if (m < 0 || !poses || !ents || n < 1 || !arena_lrbt || !rand_pos || !rand_rot || !pos_limits || !rot_limits || !mt_state_addr)
-        return fail(MGX_ERR_ARG, "NULL argument");
-    const int ne = (int)w->w.entities.size();
-    for (int i = 0; i < n; i++) if (ents[i] < 0 || ents[i] >= ne) return fail(MGX_ERR_ARG, "entity index out of range");
-    // envs are independent (own stream, own poses): spread them over a few host threads
+}  // extern "C"
+
+// pm_randomise_all_poses for m envs, env k in the world world_of(k): envs are independent (own stream, own poses), so
+// they are spread over a few host threads
+template <typename WorldOf>
+static int randomise_batch(WorldOf world_of, int ne, int m, double *poses, const int *ents, int n, const uint8_t *ignore,
+                           const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
+                           const double *pos_limits, const double *rot_limits, int limits_per_env,
+                           const uint64_t *mt_state_addr, const double *ent_hw) {
     int n_threads = (int)std::thread::hardware_concurrency();
     n_threads = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
     if (m < 64) n_threads = 1;
@@ -215,8 +248,8 @@ int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses
             int *pos = reinterpret_cast<int *>((uintptr_t)mt_state_addr[k] + 624 * sizeof(uint32_t));
             if (!key || *pos < 0 || *pos > 624) { bad[t] = 1; return; }
             const size_t lo = limits_per_env ? (size_t)k * n : 0;
-            int rc = w->w.randomise_all_poses(poses + (size_t)k * ne * 3, ents, n, ignore, arena_lrbt, rand_pos, rand_rot, pos_limits + lo, rot_limits + lo, key, pos,
-                                              ent_hw ? ent_hw + (size_t)k * ne * 2 : nullptr);
+            int rc = world_of(k).randomise_all_poses(poses + (size_t)k * ne * 3, ents, n, ignore, arena_lrbt, rand_pos, rand_rot, pos_limits + lo, rot_limits + lo, key, pos,
+                                                     ent_hw ? ent_hw + (size_t)k * ne * 2 : nullptr);
             if (rc < 0) { bad[t] = 2; return; }
             rej[t] += rc;
         }
@@ -234,6 +267,21 @@ int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses
         rejected += rej[t];
     }
     return (int)(rejected > 0x7fffffff ? 0x7fffffff : rejected);
+}
+
+extern "C" {
+
+int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses, const int *ents, int n, const uint8_t *ignore,
+                                        const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
+                                        const double *pos_limits, const double *rot_limits, int limits_per_env,
+                                        const uint64_t *mt_state_addr, const double *ent_hw) {
+    if (!w || !w->w.finalized) return fail(MGX_ERR_STATE, "world not finalized");
+    if (m < 0 || !poses || !ents || n < 1 || !arena_lrbt || !rand_pos || !rand_rot || !pos_limits || !rot_limits || !mt_state_addr)
+        return fail(MGX_ERR_ARG, "NULL argument");
+    const int ne = (int)w->w.entities.size();
+    for (int i = 0; i < n; i++) if (ents[i] < 0 || ents[i] >= ne) return fail(MGX_ERR_ARG, "entity index out of range");
+    return randomise_batch([&](int) -> const World & { return w->w; }, ne, m, poses, ents, n, ignore, arena_lrbt, rand_pos, rand_rot,
+                           pos_limits, rot_limits, limits_per_env, mt_state_addr, ent_hw);
 }
 int mgx_world_palette(int colour, int role) {
     if (colour < 0 || colour > 3 || role < 0 || role > 2) return fail(MGX_ERR_ARG, "colour 0..3, role 0..2");
@@ -259,44 +307,86 @@ int mgx_world_entity_shapes(const mgx_world *w, int ent, int max_shapes, int *ki
 }  // extern "C"
 
 // ------------------------------------------------------------------ engine
+static int even(int x) { return (x + 1) & ~1; }
+static const int HDR_WORDS = even((int)sizeof(TmplHeader) / 4);
+
+// serialise a world into the two device blobs (host side) for the engine's precision
 template <typename R, typename P>
-static int build_step_template(mgx_engine *e, const std::vector<int32_t> &iw, const std::vector<double> &rw, const std::vector<double> &pw) {
-    const TmplHeader &h = e->h;
-    auto even = [](int x) { return (x + 1) & ~1; };
-    int hw = even((int)sizeof(TmplHeader) / 4);
-    int off_i = hw, off_r = even(off_i + (int)iw.size());
-    int rwords = (int)rw.size() * (int)(sizeof(R) / 4), pwords = (int)pw.size() * (int)(sizeof(P) / 4);
-    int off_p = even(off_r + rwords);
-    int total = even(off_p + pwords);
-    std::vector<uint32_t> blob(total, 0);
-    std::memcpy(blob.data(), &h, sizeof(TmplHeader));
-    std::memcpy(blob.data() + off_i, iw.data(), iw.size() * 4);
-    { R *d = reinterpret_cast<R *>(blob.data() + off_r); for (size_t i = 0; i < rw.size(); i++) d[i] = (R)rw[i]; }
-    { P *d = reinterpret_cast<P *>(blob.data() + off_p); for (size_t i = 0; i < pw.size(); i++) d[i] = (P)pw[i]; }
-    HIP_OK(hipMalloc(&e->d_step, blob.size() * 4));
-    HIP_OK(hipMemcpy(e->d_step, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
-    WorkOff wo(h);
-    int words_p = even(wo.n_p * (int)(sizeof(P) / 4)), words_r = even(wo.n_r * (int)(sizeof(R) / 4)), words_i = even(wo.n_i);
-    int stride = words_p + words_r + words_i;
-    while (stride % 32 != 2) stride += 2;     // envs of one wave start on distinct LDS banks
-    e->tdev.words = e->d_step; e->tdev.n_words = total;
-    e->tdev.off_i = off_i; e->tdev.off_r = off_r; e->tdev.off_p = off_p;
-    e->tdev.env_stride_words = stride; e->tdev.env_off_r = words_p; e->tdev.env_off_i = words_p + words_r;
-    e->tdev.lds_tmpl_words = total;
-    return MGX_OK;
+static void make_blobs_t(const World &w, WorldBlobs &b) {
+    std::vector<int32_t> iw; std::vector<double> rw, pw;
+    {
+        TmplHeader hs;
+        w.serialise(hs, iw, rw, pw, /*strip_prims=*/true);
+        const int off_i = HDR_WORDS, off_r = tmpl_off_r<R>(hs, off_i), off_p = tmpl_off_p<R, P>(hs, off_i), total = tmpl_total_words<R, P>(hs, off_i);
+        b.step.assign(total, 0);
+        std::memcpy(b.step.data(), &hs, sizeof(TmplHeader));
+        std::memcpy(b.step.data() + off_i, iw.data(), iw.size() * 4);
+        { R *d = reinterpret_cast<R *>(b.step.data() + off_r); for (size_t i = 0; i < rw.size(); i++) d[i] = (R)rw[i]; }
+        { P *d = reinterpret_cast<P *>(b.step.data() + off_p); for (size_t i = 0; i < pw.size(); i++) d[i] = (P)pw[i]; }
+        WorkOff wo(hs);
+        int stride = even(wo.n_p * (int)(sizeof(P) / 4)) + even(wo.n_r * (int)(sizeof(R) / 4)) + even(wo.n_i);
+        while (stride % 32 != 2) stride += 2;     // envs of one wave start on distinct LDS banks
+        b.step_env_stride = stride;
+    }
+    {
+        w.serialise(b.h, iw, rw, pw);
+        TmplOff o(b.h);
+        const int off_i = HDR_WORDS, off_q = raster_off_q(b.h, off_i), nq = b.h.n_prims * PRIM_RWORDS + 2 * b.h.n_pverts;
+        b.raster.assign(raster_blob_words(b.h, off_i), 0);
+        std::memcpy(b.raster.data(), &b.h, sizeof(TmplHeader));
+        std::memcpy(b.raster.data() + off_i, iw.data(), iw.size() * 4);
+        std::memcpy(b.raster.data() + off_q, rw.data() + o.prim_r, (size_t)nq * 8);
+        RasterOff ro(b.h);
+        b.raster_scratch_d = ro.n_d;
+        b.raster_off_tiles = even(2 * ro.n_d + ro.n_i);
+    }
+}
+static void make_blobs(int dtype, const World &w, WorldBlobs &b) {
+    if (dtype == MGX_F32) make_blobs_t<float, double>(w, b);
+    else if (dtype == MGX_F64) make_blobs_t<double, double>(w, b);
+    else make_blobs_t<float, float>(w, b);
 }
 
-static size_t step_lds_bytes(const mgx_engine *e, int L) { return (size_t)(e->tdev.lds_tmpl_words + (64 / L) * e->tdev.env_stride_words) * 4; }
+static size_t step_lds_bytes(const mgx_engine *e, int L) {
+    const int epb = 64 / L;
+    return (size_t)((e->env_worlds ? epb : 1) * e->tdev.lds_tmpl_words + epb * e->tdev.env_stride_words) * 4;
+}
+// size the launch geometry (lanes per env, LDS, raster variant) for blobs of the given sizes
+static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, int raster_words, int scratch_d, int off_tiles) {
+    e->tdev.off_i = HDR_WORDS; e->tdev.lds_tmpl_words = even(step_words); e->tdev.env_stride_words = step_env_stride;
+    // lanes per env: caller's choice, else the widest group (most narrowphase parallelism) that still lets
+    // two workgroups share a CU's LDS; worlds too big for that take the narrowest group that fits at all
+    int L = e->L_request;
+    if (L == 0) {
+        L = 16;
+        while (L < 64 && step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES / 2) L *= 2;
+        if (step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES / 2) {
+            L = 16;
+            while (L < 64 && step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES) L *= 2;
+        }
+    }
+    if (L != 4 && L != 8 && L != 16 && L != 32 && L != 64) return fail(MGX_ERR_ARG, "lanes_per_env must be 0, 4, 8, 16, 32 or 64");
+    if (step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "world working set does not fit LDS at this lanes_per_env");
+    e->L = L; e->lds_step = step_lds_bytes(e, L);
+    e->rdev.off_i = HDR_WORDS; e->rdev.lds_tmpl_words = even(raster_words); e->rdev.scratch_d = scratch_d; e->rdev.off_tiles = off_tiles;
+    // per-tile (u64 mask + i32 base) + queue (u64 mask + 2 x i32) + counters + overflow bitmap + phase E records (u64 sums, u16 entry)
+    int extra = N_TILES * 3 + QCAP * 4 + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2;
+    e->lds_raster = (size_t)(e->rdev.lds_tmpl_words + off_tiles + extra) * 4;
+    // as many workgroups per CU as LDS allows (512 B allocation slack), between 3 and 5
+    int fit = (int)((size_t)MAX_LDS_BYTES / (e->lds_raster + 512));
+    e->raster_waves = fit >= 5 ? 5 : (fit == 4 ? 4 : 3);
+    return MGX_OK;
+}
 
 template <typename R, typename P, int L>
 static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const int32_t *actions, uint8_t *done, int n_sub,
                          int count_step, hipStream_t st) {
     auto kern = k_step<R, P, L>;
     size_t lds = step_lds_bytes(e, L);
-    static thread_local const void *configured = nullptr;   // per-instantiation, per-thread
-    if (configured != (const void *)kern) {
+    static thread_local size_t configured = 0;   // per-instantiation, per-thread: the largest LDS size asked for so far
+    if (lds > configured) {
         HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds > 65536 ? (int)lds : 65536));
-        configured = (const void *)kern;
+        configured = lds;
     }
     int epb = 64 / L, blocks = (e->n_envs + epb - 1) / epb;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, st, e->tdev, (P *)sp, (R *)sf, si, actions, done, e->n_envs, n_sub,
@@ -349,50 +439,23 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
     if (device < 0 || device >= ndev) return fail(MGX_ERR_ARG, "device index out of range");
     HIP_OK(hipSetDevice(device));
     mgx_engine *e = new mgx_engine();
-    e->w = w->w; e->n_envs = n_envs; e->device = device; e->dtype = dtype;
-    std::vector<int32_t> iw; std::vector<double> rw, pw;
-    e->w.serialise(e->h, iw, rw, pw);
-    int rc = dtype == MGX_F32 ? build_step_template<float, double>(e, iw, rw, pw)
-           : dtype == MGX_F64 ? build_step_template<double, double>(e, iw, rw, pw)
-                              : build_step_template<float, float>(e, iw, rw, pw);
+    e->w = w->w; e->n_envs = n_envs; e->device = device; e->dtype = dtype; e->L_request = lanes_per_env;
+    WorldBlobs b;
+    make_blobs(dtype, e->w, b);
+    e->h = b.h;
+    e->rows_p = state_rows_p(b.h); e->rows_f = state_rows_f(b.h); e->rows_i = state_rows_i(b.h);
+    int rc = configure_launch(e, (int)b.step.size(), b.step_env_stride, (int)b.raster.size(), b.raster_scratch_d, b.raster_off_tiles);
     if (rc) { delete e; return rc; }
-    // lanes per env: caller's choice, else the widest group (most narrowphase parallelism) that still lets
-    // two workgroups share a CU's LDS
-    int L = lanes_per_env;
-    if (L == 0) {
-        L = 16;
-        while (L < 64 && step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES / 2) L *= 2;
+    int32_t pal[12];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) pal[4 * r + c] = palette_rgb(c, r);
+    if (hipMalloc(&e->d_step, b.step.size() * 4) != hipSuccess || hipMemcpy(e->d_step, b.step.data(), b.step.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(&e->d_raster, b.raster.size() * 4) != hipSuccess || hipMemcpy(e->d_raster, b.raster.data(), b.raster.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(&e->d_palette, sizeof(pal)) != hipSuccess || hipMemcpy(e->d_palette, pal, sizeof(pal), hipMemcpyHostToDevice) != hipSuccess) {
+        mgx_engine_destroy(e); return fail(MGX_ERR_HIP, "template upload failed");
     }
-    if (L != 4 && L != 8 && L != 16 && L != 32 && L != 64) { mgx_engine_destroy(e); return fail(MGX_ERR_ARG, "lanes_per_env must be 0, 4, 8, 16, 32 or 64"); }
-    if (step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES) { mgx_engine_destroy(e); return fail(MGX_ERR_CAPACITY, "world working set does not fit LDS at this lanes_per_env"); }
-    e->L = L; e->lds_step = step_lds_bytes(e, L);
-    // raster template: header + ints + (prim reals, prim verts) in fp64
-    {
-        TmplOff o(e->h);
-        auto even = [](int x) { return (x + 1) & ~1; };
-        int hw = even((int)sizeof(TmplHeader) / 4), off_i = hw, off_q = even(off_i + (int)iw.size());
-        int nq = e->h.n_prims * PRIM_RWORDS + 2 * e->h.n_pverts;
-        int total = off_q + 2 * nq;
-        std::vector<uint32_t> blob(total, 0);
-        std::memcpy(blob.data(), &e->h, sizeof(TmplHeader));
-        std::memcpy(blob.data() + off_i, iw.data(), iw.size() * 4);
-        std::memcpy(blob.data() + off_q, rw.data() + o.prim_r, (size_t)nq * 8);
-        if (hipMalloc(&e->d_raster, blob.size() * 4) != hipSuccess || hipMemcpy(e->d_raster, blob.data(), blob.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-            mgx_engine_destroy(e); return fail(MGX_ERR_HIP, "raster template upload failed");
-        }
-        RasterOff ro(e->h);
-        e->rdev.words = e->d_raster; e->rdev.n_words = total; e->rdev.off_i = off_i; e->rdev.off_q = off_q;
-        e->rdev.lds_tmpl_words = total; e->rdev.scratch_d = ro.n_d; e->rdev.bg_rgb = BG_RGB;
-        int off_tiles = even(2 * ro.n_d + ro.n_i);
-        e->rdev.off_tiles = off_tiles;
-        // per-tile (u64 mask + i32 base) + queue (u64 mask + 2 x i32) + counters + overflow bitmap + phase E records (u64 sums, u16 entry)
-        int extra = N_TILES * 3 + QCAP * 4 + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2;
-        e->rdev.qcap = QCAP; e->rdev.ecap = ECAP;
-        e->lds_raster = (size_t)(total + off_tiles + extra) * 4;
-        // as many workgroups per CU as LDS allows (512 B allocation slack), between 3 and 5
-        int fit = (int)((size_t)MAX_LDS_BYTES / (e->lds_raster + 512));
-        e->raster_waves = fit >= 5 ? 5 : (fit == 4 ? 4 : 3);
-    }
+    e->tdev.words = e->d_step; e->tdev.n_words = (int)b.step.size(); e->tdev.tmpl_stride_words = 0;
+    e->rdev.words = e->d_raster; e->rdev.n_words = (int)b.raster.size(); e->rdev.tmpl_stride_words = 0;
+    e->rdev.bg_rgb = BG_RGB; e->rdev.qcap = QCAP; e->rdev.ecap = ECAP; e->rdev.palette = e->d_palette;
     *out = e;
     return MGX_OK;
 }
@@ -400,14 +463,17 @@ void mgx_engine_destroy(mgx_engine *e) {
     if (!e) return;
     if (e->d_step) (void)hipFree(e->d_step);
     if (e->d_raster) (void)hipFree(e->d_raster);
+    if (e->d_palette) (void)hipFree(e->d_palette);
+    if (e->d_stage) (void)hipFree(e->d_stage);
+    if (e->d_stage_idx) (void)hipFree(e->d_stage_idx);
     for (int k = 0; k < 2; k++) for (auto &ev : e->ev[k]) (void)hipEventDestroy(ev);
     delete e;
 }
 int mgx_engine_state_shape(const mgx_engine *e, int *rows_p, int *rows_f, int *rows_i, int *size_p, int *size_f) {
     if (!e) return fail(MGX_ERR_ARG, "engine is NULL");
-    if (rows_p) *rows_p = state_rows_p(e->h);
-    if (rows_f) *rows_f = state_rows_f(e->h);
-    if (rows_i) *rows_i = state_rows_i(e->h);
+    if (rows_p) *rows_p = e->rows_p;
+    if (rows_f) *rows_f = e->rows_f;
+    if (rows_i) *rows_i = e->rows_i;
     if (size_p) *size_p = e->dtype == MGX_F32_PURE ? 4 : 8;
     if (size_f) *size_f = e->dtype == MGX_F64 ? 8 : 4;
     return MGX_OK;
@@ -418,7 +484,7 @@ int mgx_engine_lds_bytes(const mgx_engine *e, int which) { return e ? (int)(whic
 static int reset_common(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const uint8_t *mask, const void *ent_pose, void *stream) {
     if (!e || !state_p || !state_f || !state_i) return fail(MGX_ERR_ARG, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    size_t lds = (size_t)e->tdev.n_words * 4;
+    size_t lds = e->env_worlds ? 0 : (size_t)e->tdev.n_words * 4;
     int blocks = (e->n_envs + 63) / 64;
     if (e->dtype == MGX_F32) hipLaunchKernelGGL((k_reset<float, double>), dim3(blocks), dim3(64), lds, st, e->tdev, (double *)state_p, (float *)state_f, state_i, mask, (const double *)ent_pose, e->n_envs);
     else if (e->dtype == MGX_F64) hipLaunchKernelGGL((k_reset<double, double>), dim3(blocks), dim3(64), lds, st, e->tdev, (double *)state_p, (double *)state_f, state_i, mask, (const double *)ent_pose, e->n_envs);
@@ -509,9 +575,9 @@ int mgx_engine_debug_raster_stop(mgx_engine *e, int phase) { if (e) e->rdev.dbg_
 int mgx_engine_debug_raster_clocks(mgx_engine *e, void *buf) { if (e) e->rdev.dbg_clk = (unsigned long long *)buf; return MGX_OK; }
 int mgx_engine_debug_step_clocks(mgx_engine *e, void *buf) { if (e) e->tdev.dbg_clk = (unsigned long long *)buf; return MGX_OK; }
 int mgx_engine_debug_iterations(mgx_engine *e, int it) { if (e) e->dbg_iterations = it; return MGX_OK; }
-int mgx_engine_set_prim_colours(mgx_engine *e, const int32_t *prim_rgb) {
+int mgx_engine_set_entity_colours(mgx_engine *e, const int32_t *ent_colour) {
     if (!e) return fail(MGX_ERR_ARG, "engine is NULL");
-    e->rdev.prim_rgb_env = prim_rgb;
+    e->rdev.ent_colour_env = ent_colour;
     return MGX_OK;
 }
 int mgx_engine_set_goal_rects(mgx_engine *e, const double *goal_xyhw) {
@@ -520,6 +586,171 @@ int mgx_engine_set_goal_rects(mgx_engine *e, const double *goal_xyhw) {
     e->rdev.goal_xyhw_env = goal_xyhw;
     return MGX_OK;
 }
+}  // extern "C"
+
+// dst row idx[r] (or r) <- src row r (src_stride 0: the same row for all)
+__global__ void k_scatter_rows(uint32_t *dst, long dst_stride, const uint32_t *src, long src_stride, const int32_t *idx, int n_words) {
+    const long r = blockIdx.x, d = idx ? idx[r] : r;
+    for (int i = threadIdx.x; i < n_words; i += blockDim.x) dst[d * dst_stride + i] = src[r * src_stride + i];
+}
+
+extern "C" {
+
+int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world) {
+    if (!e || !capacity_world) return fail(MGX_ERR_ARG, "NULL argument");
+    if (!capacity_world->w.finalized) return fail(MGX_ERR_STATE, "capacity world not finalized");
+    if (e->env_worlds) return fail(MGX_ERR_STATE, "per-env worlds already enabled");
+    if (capacity_world->w.entities.size() != e->w.entities.size()) return fail(MGX_ERR_ARG, "capacity world must have the engine world's entities");
+    HIP_OK(hipSetDevice(e->device));
+    WorldBlobs cb, db;
+    make_blobs(e->dtype, capacity_world->w, cb);
+    make_blobs(e->dtype, e->w, db);
+    if (db.step.size() > cb.step.size() || db.raster.size() > cb.raster.size() || db.step_env_stride > cb.step_env_stride ||
+        db.raster_scratch_d > cb.raster_scratch_d || db.raster_off_tiles > cb.raster_off_tiles)
+        return fail(MGX_ERR_ARG, "the capacity world must be at least as large as the engine's world");
+    if (cb.h.n_prims > 64) return fail(MGX_ERR_CAPACITY, "draw list longer than 64 primitives");
+    const int step_stride = even((int)cb.step.size()), raster_stride = even((int)cb.raster.size());
+    uint32_t *tab_s = nullptr, *tab_r = nullptr;
+    HIP_OK(hipMalloc(&tab_s, (size_t)e->n_envs * step_stride * 4));
+    if (hipMalloc(&tab_r, (size_t)e->n_envs * raster_stride * 4) != hipSuccess) { (void)hipFree(tab_s); return fail(MGX_ERR_HIP, "per-env draw-list table allocation failed"); }
+    // every env starts in the default world (its blobs are still on the device)
+    hipLaunchKernelGGL(k_scatter_rows, dim3(e->n_envs), dim3(256), 0, 0, tab_s, (long)step_stride, e->d_step, 0L, (const int32_t *)nullptr, (int)db.step.size());
+    hipLaunchKernelGGL(k_scatter_rows, dim3(e->n_envs), dim3(256), 0, 0, tab_r, (long)raster_stride, e->d_raster, 0L, (const int32_t *)nullptr, (int)db.raster.size());
+    HIP_OK(hipDeviceSynchronize());
+    (void)hipFree(e->d_step); (void)hipFree(e->d_raster);
+    e->d_step = tab_s; e->d_raster = tab_r;
+    e->env_worlds = true;
+    e->step_stride = step_stride; e->raster_stride = raster_stride;
+    e->tdev.words = tab_s; e->tdev.tmpl_stride_words = step_stride;
+    e->rdev.words = tab_r; e->rdev.tmpl_stride_words = raster_stride;
+    e->env_world.assign(e->n_envs, std::shared_ptr<World>());
+    int rc = configure_launch(e, (int)cb.step.size(), cb.step_env_stride, (int)cb.raster.size(), cb.raster_scratch_d, cb.raster_off_tiles);
+    if (rc) return rc;
+    e->rows_p = std::max(e->rows_p, state_rows_p(cb.h)); e->rows_f = std::max(e->rows_f, state_rows_f(cb.h)); e->rows_i = std::max(e->rows_i, state_rows_i(cb.h));
+    return MGX_OK;
+}
+
+int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, const uint8_t *enabled, const int32_t *shape_types, void *stream) {
+    if (!e || !env_idx || m < 0) return fail(MGX_ERR_ARG, "bad argument");
+    if (!e->env_worlds) return fail(MGX_ERR_STATE, "call mgx_engine_enable_env_worlds first");
+    if (m == 0) return MGX_OK;
+    HIP_OK(hipSetDevice(e->device));
+    const int ne = (int)e->w.entities.size();
+    for (int k = 0; k < m; k++) if (env_idx[k] < 0 || env_idx[k] >= e->n_envs) return fail(MGX_ERR_ARG, "env index out of range");
+    // unique signatures of this call; worlds that are still alive are reused
+    struct Uniq { std::string sig; int first; std::shared_ptr<World> world; WorldBlobs blobs; std::string err; int rc = 0; };
+    std::vector<Uniq> uniq;
+    std::unordered_map<std::string, int> index;
+    std::vector<int> which(m);
+    for (int k = 0; k < m; k++) {
+        std::string sig((size_t)2 * ne, '\0');
+        for (int i = 0; i < ne; i++) {
+            sig[i] = (char)(enabled ? (enabled[(size_t)k * ne + i] ? 1 : 0) : (e->w.entities[i].enabled ? 1 : 0));
+            int st = shape_types ? shape_types[(size_t)k * ne + i] : -1;
+            sig[ne + i] = (char)((e->w.entities[i].kind == 1 ? (st >= 0 ? st : e->w.entities[i].shape_type) : 0) + 1);
+        }
+        auto it = index.find(sig);
+        if (it == index.end()) {
+            it = index.emplace(sig, (int)uniq.size()).first;
+            Uniq u; u.sig = sig; u.first = k;
+            auto live = e->world_by_sig.find(sig);
+            if (live != e->world_by_sig.end()) u.world = live->second.lock();
+            uniq.push_back(std::move(u));
+        }
+        which[k] = it->second;
+    }
+    // build what is missing and serialise everything, a few host threads wide
+    int n_threads = (int)std::thread::hardware_concurrency();
+    n_threads = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
+    if (uniq.size() < 8) n_threads = 1;
+    auto work = [&](int t) {
+        for (size_t u = t; u < uniq.size(); u += n_threads) {
+            Uniq &U = uniq[u];
+            if (!U.world) {
+                std::vector<uint8_t> en(ne); std::vector<int> st(ne);
+                for (int i = 0; i < ne; i++) { en[i] = (uint8_t)U.sig[i]; st[i] = (int)U.sig[ne + i] - 1; }
+                auto w = std::make_shared<World>();
+                U.rc = e->w.variant(en.data(), st.data(), *w, U.err);
+                if (U.rc) continue;
+                U.world = std::move(w);
+            }
+            make_blobs(e->dtype, *U.world, U.blobs);
+        }
+    };
+    if (n_threads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; t++) pool.emplace_back(work, t);
+        for (auto &th : pool) th.join();
+    }
+    for (auto &U : uniq) {
+        if (U.rc) return fail(U.rc == -2 ? MGX_ERR_CAPACITY : MGX_ERR_ARG, U.err);
+        if ((int)U.blobs.step.size() > e->step_stride || (int)U.blobs.raster.size() > e->raster_stride ||
+            U.blobs.step_env_stride > e->tdev.env_stride_words || U.blobs.raster_scratch_d > e->rdev.scratch_d || U.blobs.raster_off_tiles > e->rdev.off_tiles ||
+            U.blobs.h.n_prims > 64)
+            return fail(MGX_ERR_CAPACITY, "world variant larger than the capacity world");
+        if (state_rows_p(U.blobs.h) > e->rows_p || state_rows_f(U.blobs.h) > e->rows_f || state_rows_i(U.blobs.h) > e->rows_i)
+            return fail(MGX_ERR_CAPACITY, "world variant needs more state rows than the capacity world");
+    }
+    // upload: one staging buffer [m][step_stride | raster_stride], then scatter into the envs' slots
+    const size_t row = (size_t)e->step_stride + e->raster_stride;
+    std::vector<uint32_t> host((size_t)m * row, 0);
+    for (int k = 0; k < m; k++) {
+        const WorldBlobs &B = uniq[which[k]].blobs;
+        std::memcpy(host.data() + (size_t)k * row, B.step.data(), B.step.size() * 4);
+        std::memcpy(host.data() + (size_t)k * row + e->step_stride, B.raster.data(), B.raster.size() * 4);
+    }
+    if (e->stage_words < host.size()) {
+        if (e->d_stage) (void)hipFree(e->d_stage);
+        e->d_stage = nullptr; e->stage_words = 0;
+        HIP_OK(hipMalloc(&e->d_stage, host.size() * 4));
+        e->stage_words = host.size();
+    }
+    if (e->stage_idx_n < (size_t)m) {
+        if (e->d_stage_idx) (void)hipFree(e->d_stage_idx);
+        e->d_stage_idx = nullptr; e->stage_idx_n = 0;
+        HIP_OK(hipMalloc(&e->d_stage_idx, (size_t)m * 4));
+        e->stage_idx_n = m;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(hipMemcpyAsync(e->d_stage, host.data(), host.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->d_stage_idx, env_idx, (size_t)m * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_scatter_rows, dim3(m), dim3(256), 0, st, e->d_step, (long)e->step_stride, e->d_stage, (long)row, e->d_stage_idx, e->step_stride);
+    hipLaunchKernelGGL(k_scatter_rows, dim3(m), dim3(256), 0, st, e->d_raster, (long)e->raster_stride, e->d_stage + e->step_stride, (long)row, e->d_stage_idx, e->raster_stride);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));        // `host` and env_idx are read by the copies above
+    for (int k = 0; k < m; k++) e->env_world[env_idx[k]] = uniq[which[k]].world;
+    for (auto &U : uniq) e->world_by_sig[U.sig] = U.world;
+    if (e->world_by_sig.size() > (size_t)4 * e->n_envs + 64)
+        for (auto it = e->world_by_sig.begin(); it != e->world_by_sig.end();) it = it->second.expired() ? e->world_by_sig.erase(it) : std::next(it);
+    return (int)uniq.size();
+}
+
+int mgx_engine_env_randomise_all_poses_batch(const mgx_engine *e, int m, const int32_t *env_idx, double *poses, const int *ents, int n, const uint8_t *ignore,
+                                             const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
+                                             const double *pos_limits, const double *rot_limits, int limits_per_env,
+                                             const uint64_t *mt_state_addr, const double *ent_hw) {
+    if (!e) return fail(MGX_ERR_ARG, "engine is NULL");
+    if (m < 0 || !env_idx || !poses || !ents || n < 1 || !arena_lrbt || !rand_pos || !rand_rot || !pos_limits || !rot_limits || !mt_state_addr)
+        return fail(MGX_ERR_ARG, "NULL argument");
+    const int ne = (int)e->w.entities.size();
+    for (int i = 0; i < n; i++) if (ents[i] < 0 || ents[i] >= ne) return fail(MGX_ERR_ARG, "entity index out of range");
+    for (int k = 0; k < m; k++) if (env_idx[k] < 0 || env_idx[k] >= e->n_envs) return fail(MGX_ERR_ARG, "env index out of range");
+    auto world_of = [&](int k) -> const World & {
+        if (e->env_worlds && e->env_world[env_idx[k]]) return *e->env_world[env_idx[k]];
+        return e->w;
+    };
+    return randomise_batch(world_of, ne, m, poses, ents, n, ignore, arena_lrbt, rand_pos, rand_rot, pos_limits, rot_limits, limits_per_env, mt_state_addr, ent_hw);
+}
+
+int mgx_engine_env_world_info(const mgx_engine *e, int env, int key, int *out) {
+    if (!e || !out) return fail(MGX_ERR_ARG, "NULL argument");
+    if (env < 0 || env >= e->n_envs) return fail(MGX_ERR_ARG, "env index out of range");
+    mgx_world tmp;
+    tmp.w = (e->env_worlds && e->env_world[env]) ? *e->env_world[env] : e->w;
+    return mgx_world_info(&tmp, key, out);
+}
+
 int mgx_engine_set_timing(mgx_engine *e, int enable) {
     if (!e) return fail(MGX_ERR_ARG, "engine is NULL");
     e->timing = enable < 0 ? 0 : enable;

@@ -144,13 +144,18 @@ constexpr float TILE_HX = 2.0f * TILE_W - 0.5f, TILE_HY = 2.0f * TILE_H - 0.5f;
 
 // ---- setup phase 2: per-primitive records (lane per prim) and screen-space vertices (lane per prim vertex)
 MGX_HD int prim_item_count(const Raster &rs, int k) { return rs.prim_kind(k) == PR_NGON ? 1 : rs.prim_nv(k); }
-MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_rgb = nullptr, long stride = 0, long env = 0,
-                               const double *env_goal = nullptr) {
+// env_col (optional): [n_entities][stride] colour index of every entity in THIS env (Test*Colour variants); a primitive
+// painted by an entity takes palette[4 * role + colour] (role 0 darkened outline, 1 base, 2 lightened interior)
+MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_col = nullptr, long stride = 0, long env = 0,
+                               const double *env_goal = nullptr, const int32_t *palette = nullptr) {
     const TmplHeader &h = *rs.h;
     double cam[6];
     raster_camera(rs, cam);
     for (int k = lane; k < h.n_prims; k += nl) {
-        RI(prgb, k) = env_rgb ? env_rgb[(long)k * stride + env] : rs.prim_rgb_template(k);
+        {
+            const int xw = rs.prim_xf(k), role = ((xw >> 24) & 3) - 1, ent = ((xw >> 26) & 0x3F) - 1;
+            RI(prgb, k) = (env_col && ent >= 0 && role >= 0) ? palette[4 * role + env_col[(long)ent * stride + env]] : rs.prim_rgb_template(k);
+        }
         // the prim's slice of the item list: front (top) prims first
         int start = 0;
         for (int kk = h.n_prims - 1; kk > k; kk--) start += prim_item_count(rs, kk);

@@ -16,21 +16,25 @@
 namespace mgx {
 
 struct RasterDev {
-    const uint32_t *words;   // [TmplHeader][int words][pad][tq doubles]
-    int n_words;
-    int off_i, off_q;        // word offsets of the int array and the double array
+    const uint32_t *words;   // [TmplHeader][int words][pad][tq doubles]; env e's own blob at words + e * tmpl_stride_words
+    long tmpl_stride_words;  // 0: one draw list for all envs
+    int n_words;             // words of the shared blob (per-env blobs: see raster_blob_words)
+    int off_i;               // word offset of the int array (the doubles follow at raster_off_q)
     int lds_tmpl_words;      // reserved words for the template (even)
     int scratch_d;           // doubles of per-env scratch
     int bg_rgb;
     int off_tiles;           // word offset (inside the scratch area) of the per-tile / queue region, 8-byte aligned
     unsigned long long *dbg_clk;   // development probe: per-block phase clocks [n_envs][16] (NULL = off)
     int dbg_stop;                  // development probe: return after phase k (0 = run everything)
-    const int32_t *prim_rgb_env;   // [n_prims][n_envs] per-env primitive colours (NULL: the template's)
+    const int32_t *ent_colour_env; // [n_entities][n_envs] per-env entity colour indices (NULL: the template's colours)
+    const int32_t *palette;        // device int32[12]: RGB8 of colour c in role r at [4 * r + c] (style.py:28-37)
     const double *goal_xyhw_env;   // [n_goals * 4][n_envs] per-env goal rectangles x, y (top-left), h, w (NULL: the template's)
     int qcap;                      // queue entries in use (<= QCAP; tests shrink it to exercise the overflow rounds)
     int ecap;                      // phase E records in use (<= ECAP; likewise)
 };
 
+MGX_HD int raster_off_q(const TmplHeader &h, int off_i) { return (off_i + h.n_words_i + 1) & ~1; }
+MGX_HD int raster_blob_words(const TmplHeader &h, int off_i) { return raster_off_q(h, off_i) + 2 * (h.n_prims * PRIM_RWORDS + 2 * h.n_pverts); }
 constexpr int N_TILES = TILES_X * TILES_Y;
 constexpr int QCAP = 1024;     // LDS queue of undecided pixels per env; what does not fit waits in a bitmap for another round
 constexpr int OVF_WORDS = LORES * LORES / 32;
@@ -197,13 +201,17 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
 #else
 #define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + (i)] = wall_clock64() - clk0;
 #endif
-    for (int i = tid; i < t.n_words; i += 256) lds[i] = t.words[i];
+    const long env = blockIdx.x;
+    {
+        const uint32_t *src = t.words + env * t.tmpl_stride_words;
+        const int n = t.tmpl_stride_words ? raster_blob_words(*reinterpret_cast<const TmplHeader *>(src), t.off_i) : t.n_words;
+        for (int i = tid; i < n; i += 256) lds[i] = src[i];
+    }
     __syncthreads();
     CLK(0)
-    const long env = blockIdx.x;
     const TmplHeader *h = reinterpret_cast<const TmplHeader *>(lds);
     uint32_t *scratch = lds + t.lds_tmpl_words;
-    Raster rs(h, reinterpret_cast<const int32_t *>(lds + t.off_i), reinterpret_cast<const double *>(lds + t.off_q),
+    Raster rs(h, reinterpret_cast<const int32_t *>(lds + t.off_i), reinterpret_cast<const double *>(lds + raster_off_q(*h, t.off_i)),
               reinterpret_cast<double *>(scratch), reinterpret_cast<int32_t *>(scratch + 2 * t.scratch_d), view);
     // phase-local LDS: per-tile results and the queue of undecided pixels
     uint64_t *tile_mixed = reinterpret_cast<uint64_t *>(scratch + t.off_tiles);
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
     // phase S: screen-space setup (lane per body; lane per primitive + lane per vertex; lane per edge for the item list)
     raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
     __syncthreads();
-    raster_setup_prims(rs, tid, 256, t.prim_rgb_env, (long)n_envs, env, t.goal_xyhw_env);
+    raster_setup_prims(rs, tid, 256, t.ent_colour_env, (long)n_envs, env, t.goal_xyhw_env, t.palette);
     __syncthreads();
     raster_setup_edges(rs, tid, 256);
     __syncthreads();
@@ -442,15 +450,19 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster_native(RasterD
                                                        int view, long env, int n_envs) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
-    for (int i = tid; i < t.n_words; i += 256) lds[i] = t.words[i];
+    {
+        const uint32_t *src = t.words + env * t.tmpl_stride_words;
+        const int n = t.tmpl_stride_words ? raster_blob_words(*reinterpret_cast<const TmplHeader *>(src), t.off_i) : t.n_words;
+        for (int i = tid; i < n; i += 256) lds[i] = src[i];
+    }
     __syncthreads();
     const TmplHeader *h = reinterpret_cast<const TmplHeader *>(lds);
-    Raster rs(h, reinterpret_cast<const int32_t *>(lds + t.off_i), reinterpret_cast<const double *>(lds + t.off_q),
+    Raster rs(h, reinterpret_cast<const int32_t *>(lds + t.off_i), reinterpret_cast<const double *>(lds + raster_off_q(*h, t.off_i)),
               reinterpret_cast<double *>(lds + t.lds_tmpl_words),
               reinterpret_cast<int32_t *>(lds + t.lds_tmpl_words + 2 * t.scratch_d), view);
     raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
     __syncthreads();
-    raster_setup_prims(rs, tid, 256, t.prim_rgb_env, (long)n_envs, env, t.goal_xyhw_env);
+    raster_setup_prims(rs, tid, 256, t.ent_colour_env, (long)n_envs, env, t.goal_xyhw_env, t.palette);
     __syncthreads();
     raster_setup_edges(rs, tid, 256);
     __syncthreads();

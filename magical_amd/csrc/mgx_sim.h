@@ -1030,13 +1030,15 @@ template <typename R, typename P> MGX_HD void ph_cache_commit(Env<R, P> &e, int 
 // ---------------------------------------------------------------- state blobs <-> working set
 // pose blob (P)  rows: [0, n_state_p)                 x / y / angle of the persistent bodies
 // vel blob  (R)  rows: [0, n_state - n_state_p)       velocities + bias velocities
-//                      then n_jacc joint accumulators, then 4 * cache_slots contact impulses
+//                      then the env's five force limits, n_jacc joint accumulators, 4 * cache_slots contact impulses
+//                      (the rows the host addresses come first: they are the same for every world of a task)
 // int blob       rows: 0 episode steps, 1 n_cache, 2 overflow count, 3.. cache headers
 // All blobs are [rows][N] (env index fastest) so lane<->env loads coalesce.
 MGX_HD int state_rows_p(const TmplHeader &h) { return h.n_state_p; }
-// velocities | joint accumulators | contact cache impulses | the env's five force limits (max impulse per substep)
-MGX_HD int state_rows_f(const TmplHeader &h) { return (h.n_state - h.n_state_p) + h.n_jacc + 4 * h.cache_slots + N_PHYS_VARS; }
-MGX_HD int state_row_physvar(const TmplHeader &h, int k) { return (h.n_state - h.n_state_p) + h.n_jacc + 4 * h.cache_slots + k; }
+// velocities | the env's five force limits (max impulse per substep) | joint accumulators | contact cache impulses
+MGX_HD int state_rows_f(const TmplHeader &h) { return (h.n_state - h.n_state_p) + N_PHYS_VARS + h.n_jacc + 4 * h.cache_slots; }
+MGX_HD int state_row_physvar(const TmplHeader &h, int k) { return (h.n_state - h.n_state_p) + k; }
+MGX_HD int state_row_jacc0(const TmplHeader &h) { return (h.n_state - h.n_state_p) + N_PHYS_VARS; }
 MGX_HD int state_rows_i(const TmplHeader &h) { return 3 + h.cache_slots; }
 
 template <typename R, typename P>
@@ -1054,7 +1056,7 @@ MGX_HD void ph_init_work(Env<R, P> &e, int lane, int nl) {
 template <typename R, typename P>
 MGX_HD void ph_load_state(Env<R, P> &e, const P *sp, const R *sf, const int32_t *si, long stride, long env, int lane, int nl) {
     const TmplHeader &h = *e.h;
-    int nvel = h.n_state - h.n_state_p;
+    int nvel = state_row_jacc0(h);      // first row after the velocities and force limits
     for (int k = lane; k < h.n_state; k += nl) {
         int m = T_I(state_map, k), comp = m & 15, b = (m >> 4) & 0xFF, row = m >> 12;
         if (comp < 3) {
@@ -1095,7 +1097,7 @@ template <typename R, typename P> MGX_HD void ph_refresh_trig(Env<R, P> &e, int 
 template <typename R, typename P>
 MGX_HD void ph_store_state(Env<R, P> &e, P *sp, R *sf, int32_t *si, long stride, long env, int lane, int nl) {
     const TmplHeader &h = *e.h;
-    int nvel = h.n_state - h.n_state_p;
+    int nvel = state_row_jacc0(h);      // first row after the velocities and force limits
     for (int k = lane; k < h.n_state; k += nl) {
         int m = T_I(state_map, k), comp = m & 15, b = (m >> 4) & 0xFF, row = m >> 12;
         if (comp < 3) {
@@ -1156,7 +1158,7 @@ MGX_HD void reset_env_state(const TmplHeader &h, const int32_t *ti, const R *tr,
         }
         sp[(long)row * stride + env] = v;
     }
-    int nvel = h.n_state - h.n_state_p;
+    int nvel = state_row_jacc0(h);      // first row after the velocities and force limits
     for (int k = 0; k < h.n_jacc + 4 * h.cache_slots; k++) sf[(long)(nvel + k) * stride + env] = R(0);
     for (int k = 0; k < N_PHYS_VARS; k++) sf[(long)state_row_physvar(h, k) * stride + env] = tr[to.consts + C_PV0 + k];
     for (int k = 0; k < 3 + h.cache_slots; k++) si[(long)k * stride + env] = 0;

@@ -15,16 +15,26 @@
 
 namespace mgx {
 
-// template blob in global memory: [TmplHeader][int words][R words][P words], P part 8-byte aligned
+// template blob in global memory: [TmplHeader][int words][R words][P words], P part 8-byte aligned.
+// One blob shared by every env (tmpl_stride_words == 0), or one per env at words + env * tmpl_stride_words (tasks whose
+// episodes differ in shape types / entity counts): then every env of a workgroup stages its own copy into LDS.
 struct TmplDev {
     const uint32_t *words;
-    int n_words;       // total 32-bit words to stage into LDS
-    int off_i, off_r, off_p;   // word offsets of the three arrays
-    int env_stride_words;      // per-env LDS stride in 32-bit words (multiple of 2)
-    int env_off_r, env_off_i;  // word offsets of the R and int regions inside an env's slab (P region first)
-    int lds_tmpl_words;        // words reserved for the template at the start of LDS (multiple of 2)
+    int n_words;       // 32-bit words of the shared blob (per-env blobs carry their sizes in their headers)
+    int off_i;         // word offset of the int array (the R and P arrays follow, see tmpl_off_r / tmpl_off_p)
+    long tmpl_stride_words;    // 0: one template for all envs
+    int env_stride_words;      // per-env LDS stride of the working set in 32-bit words (multiple of 2)
+    int lds_tmpl_words;        // LDS words reserved per template copy (multiple of 2)
     unsigned long long *dbg_clk;   // development probe (MGX_STEP_PROBE builds): per-workgroup phase cycles [blocks][32]
 };
+MGX_HD int even_words(int x) { return (x + 1) & ~1; }
+template <typename R> MGX_HD int tmpl_off_r(const TmplHeader &h, int off_i) { return even_words(off_i + h.n_words_i); }
+template <typename R, typename P> MGX_HD int tmpl_off_p(const TmplHeader &h, int off_i) {
+    return even_words(tmpl_off_r<R>(h, off_i) + h.n_words_r * (int)(sizeof(R) / 4));
+}
+template <typename R, typename P> MGX_HD int tmpl_total_words(const TmplHeader &h, int off_i) {
+    return even_words(tmpl_off_p<R, P>(h, off_i) + h.n_words_p * (int)(sizeof(P) / 4));
+}
 
 #ifdef MGX_STEP_PROBE
 constexpr bool probe_prefix(const char *s, const char *p) { return *p == 0 ? true : (*s == *p && probe_prefix(s + 1, p + 1)); }
@@ -42,13 +52,6 @@ __global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *_
                                              int n_envs, int n_sub, int count_step, int iterations) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
-    for (int i = tid; i < t.n_words; i += 64) lds[i] = t.words[i];
-    __syncthreads();
-    const TmplHeader *h = reinterpret_cast<const TmplHeader *>(lds);
-    const int32_t *ti = reinterpret_cast<const int32_t *>(lds + t.off_i);
-    const R *tr = reinterpret_cast<const R *>(lds + t.off_r);
-    const P *tp = reinterpret_cast<const P *>(lds + t.off_p);
-
     constexpr int EPB = 64 / L;
     const int env_local = tid / L, lane = tid % L, nl = L;
     // consecutive workgroups land on different XCDs (round robin over the 8 L2s); give each XCD a contiguous env
@@ -58,9 +61,29 @@ __global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *_
     long env = (long)wg * EPB + env_local;
     const bool valid = env < n_envs;
     if (!valid) env = n_envs - 1;   // tail lanes shadow the last env (no stores) so barriers stay uniform
-    uint32_t *slab = lds + t.lds_tmpl_words + env_local * t.env_stride_words;
-    Env<R, P> e(h, ti, tr, tp, reinterpret_cast<R *>(slab + t.env_off_r), reinterpret_cast<P *>(slab),
-                reinterpret_cast<int32_t *>(slab + t.env_off_i));
+    uint32_t *tl = lds;             // this env's template in LDS
+    int n_tmpl = 1;
+    if (t.tmpl_stride_words == 0) {
+        for (int i = tid; i < t.n_words; i += 64) lds[i] = t.words[i];
+    } else {
+        const uint32_t *src = t.words + env * t.tmpl_stride_words;
+        const int n = tmpl_total_words<R, P>(*reinterpret_cast<const TmplHeader *>(src), t.off_i);
+        tl = lds + env_local * t.lds_tmpl_words;
+        n_tmpl = EPB;
+        for (int i = lane; i < n; i += L) tl[i] = src[i];
+    }
+    __syncthreads();
+    const TmplHeader *h = reinterpret_cast<const TmplHeader *>(tl);
+    const int32_t *ti = reinterpret_cast<const int32_t *>(tl + t.off_i);
+    const R *tr = reinterpret_cast<const R *>(tl + tmpl_off_r<R>(*h, t.off_i));
+    const P *tp = reinterpret_cast<const P *>(tl + tmpl_off_p<R, P>(*h, t.off_i));
+
+    uint32_t *slab = lds + n_tmpl * t.lds_tmpl_words + env_local * t.env_stride_words;
+    // the working set of THIS env's world inside its slab: pose region, real region, int region
+    const WorkOff wo_(*h);
+    const int slab_off_r = even_words(wo_.n_p * (int)(sizeof(P) / 4)), slab_off_i = slab_off_r + even_words(wo_.n_r * (int)(sizeof(R) / 4));
+    Env<R, P> e(h, ti, tr, tp, reinterpret_cast<R *>(slab + slab_off_r), reinterpret_cast<P *>(slab),
+                reinterpret_cast<int32_t *>(slab + slab_off_i));
     const long stride = n_envs;
     SolveCtx<R> ctx;
 
@@ -100,15 +123,17 @@ template <typename R, typename P>
 __global__ __launch_bounds__(64) void k_reset(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
                                               const uint8_t *__restrict__ mask, const P *__restrict__ ent_pose, int n_envs) {
     extern __shared__ __align__(16) uint32_t lds[];
-    for (int i = threadIdx.x; i < t.n_words; i += 64) lds[i] = t.words[i];
+    if (t.tmpl_stride_words == 0) for (int i = threadIdx.x; i < t.n_words; i += 64) lds[i] = t.words[i];
     __syncthreads();
-    const TmplHeader *h = reinterpret_cast<const TmplHeader *>(lds);
-    const int32_t *ti = reinterpret_cast<const int32_t *>(lds + t.off_i);
-    const R *tr = reinterpret_cast<const R *>(lds + t.off_r);
-    const P *tp = reinterpret_cast<const P *>(lds + t.off_p);
     long env = (long)blockIdx.x * 64 + threadIdx.x;
     if (env >= n_envs) return;
     if (mask && !mask[env]) return;
+    // per-env worlds: each thread reads its env's template straight from HBM (resets are rare)
+    const uint32_t *tl = t.tmpl_stride_words == 0 ? lds : t.words + env * t.tmpl_stride_words;
+    const TmplHeader *h = reinterpret_cast<const TmplHeader *>(tl);
+    const int32_t *ti = reinterpret_cast<const int32_t *>(tl + t.off_i);
+    const R *tr = reinterpret_cast<const R *>(tl + tmpl_off_r<R>(*h, t.off_i));
+    const P *tp = reinterpret_cast<const P *>(tl + tmpl_off_p<R, P>(*h, t.off_i));
     reset_env_state<R, P>(*h, ti, tr, tp, sp, sf, si, (long)n_envs, env, ent_pose);
 }
 

@@ -23,18 +23,20 @@ enum JointKind { J_PIVOT = 0, J_GEAR = 1, J_SPRING = 2, J_PIN = 3, J_LIMIT = 4, 
 enum PrimKind { PR_POLY = 0, PR_NGON = 1, PR_LINELOOP = 2 };
 enum PrimXform { XF_WORLD = 0, XF_BODY = 1, XF_EYE = 2 };
 
-// compile-time capacities (largest Demo world: Cluster* = 14 moving bodies, 27 shapes, 26 joints)
-constexpr int CAP_BODIES = 16;
-constexpr int CAP_SHAPES = 32;
-constexpr int CAP_VERTS = 112;
-constexpr int CAP_JOINTS = 32;
-constexpr int CAP_PAIRS = 448;
-constexpr int CAP_PRIMS = 64;    // rasteriser keeps per-tile primitive sets in one 64-bit ballot mask
-constexpr int CAP_PVERTS = 320;
+// capacities (index fields are 8 bits for bodies / shapes, 12 bits for candidate pairs; the rasteriser keeps per-tile
+// primitive sets in one 64-bit mask).  Largest Demo world: Cluster* = 14 moving bodies, 27 shapes, 26 joints; largest
+// Test world: Cluster*-TestAll with ten stars = 17 bodies, 69 shapes, ~2200 candidate pairs.
+constexpr int CAP_BODIES = 32;
+constexpr int CAP_SHAPES = 128;
+constexpr int CAP_VERTS = 512;
+constexpr int CAP_JOINTS = 64;
+constexpr int CAP_PAIRS = 4095;
+constexpr int CAP_PRIMS = 64;
+constexpr int CAP_PVERTS = 1024;
 
 constexpr int N_PHYS_VARS = 5;    // robot_pos, robot_rot, finger, shape_trans, shape_rot joint max forces (phys_vars.py)
 constexpr int JOINT_PARAMS = 10;   // ax ay bx by p0 p1 p2 bias_rate max_bias max_impulse
-constexpr int PRIM_IWORDS = 7;     // kind, nverts, voff, xform|body<<8|eye_body<<16, rgb(packed), stipple, part ends
+constexpr int PRIM_IWORDS = 7;     // kind, nverts, voff, xform|body<<8|(eye_body+1)<<16|(role+1)<<24|(entity+1)<<26, rgb(packed), stipple, part ends
 // A PR_POLY primitive is a union of convex parts drawn in one colour (a star: five triangles + a pentagon, entities.py:
 // 723-734): its vertices are the parts' vertices back to back and bit i of the `part ends` word marks vertex i as the
 // last one of its part (a plain convex polygon has the single bit nverts - 1) -- hence at most 32 vertices per primitive.

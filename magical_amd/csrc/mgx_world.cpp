@@ -178,6 +178,7 @@ bool World::placement_collides(int ent, const double *poses, const uint8_t *enab
     // world-space shapes of entity e at its pose (bodies follow the entity rigidly, as in finalize())
     auto shapes_of = [&](int e, std::vector<WShape> &out) {
         const EntityDef &E = entities[e];
+        if (!E.enabled) return;
         double x = poses[3 * e], y = poses[3 * e + 1], a = poses[3 * e + 2];
         if (E.kind == 2) {                      // goal sensor: box (w, h) around its centre, never rotated
             double hw = (ent_hw ? ent_hw[2 * e + 1] : E.w) / 2, hh = (ent_hw ? ent_hw[2 * e] : E.h) / 2;
@@ -251,6 +252,7 @@ int World::randomise_all_poses(double *poses, const int *ents, int n, const uint
         bool failed = false;
         for (int i = 0; i < n && !failed; i++) {
             const int e = ents[i];
+            if (!entities[e].enabled) continue;                            // not in this episode's world: nothing to place, no draws
             enabled[e] = 1;
             // ---- pm_randomise_pose (geom.py:116-262)
             const double ox = poses[3 * e], oy = poses[3 * e + 1], oa = poses[3 * e + 2];
@@ -395,6 +397,10 @@ int World::finalize(int max_steps, std::string &err) {
                 pup.eye_body = eye_bodies[k]; pup.eye_pre[0] = 0; pup.eye_pre[1] = radius * 0.07;
                 prims.push_back(pup);
             }
+        } else if (e.kind == 1 && !e.enabled) {
+            // not part of this env's episode: an inert body that only keeps body indices and state rows aligned
+            e.body = (int)bodies.size();
+            bodies.push_back({BODY_STATIC, 0, 0, e.x, e.y, e.angle, -1, 0, 0, 0x1FF, (int)ei, 0.0});
         } else if (e.kind == 1) {
             // ---------------- Shape (entities.py:614-757)
             n_blocks++;
@@ -480,6 +486,7 @@ int World::finalize(int max_steps, std::string &err) {
         } else {
             // ---------------- GoalRegion (entities.py:790-819): static sensor, drawn only
             e.body = -1;
+            if (!e.enabled) { n_goals++; continue; }      // keeps the later regions' ordinals
             double cx = e.x + e.w / 2, cy = e.y - e.h / 2;
             std::vector<Vec2> rect = draw_rect(e.w, e.h);
             for (auto &v : rect) { v.x += cx; v.y += cy; }
@@ -544,16 +551,33 @@ int World::finalize(int max_steps, std::string &err) {
     return 0;
 }
 
-void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<double> &rw, std::vector<double> &pw) const {
+int World::variant(const uint8_t *enabled, const int *shape_types, World &out, std::string &err) const {
+    out = World();
+    for (int k = 0; k < 5; k++) out.phys_vars[k] = phys_vars[k];
+    out.entities = entities;
+    for (size_t i = 0; i < out.entities.size(); i++) {
+        EntityDef &e = out.entities[i];
+        e.body = -1; e.shapes.clear();
+        if (enabled) e.enabled = enabled[i] != 0;
+        if (e.kind == 0 && !e.enabled) { err = "the robot cannot be disabled"; return -1; }
+        if (shape_types && e.kind == 1 && shape_types[i] >= 0) {
+            if (shape_types[i] > 6) { err = "bad shape type"; return -1; }
+            e.shape_type = shape_types[i];
+        }
+    }
+    return out.finalize(max_episode_steps, err);
+}
+
+void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<double> &rw, std::vector<double> &pw, bool strip_prims) const {
     std::memset(&h, 0, sizeof(h));
     h.n_bodies = (int)bodies.size();
     h.n_shapes = (int)shapes.size();
     h.n_joints = (int)joints.size();
     h.n_pairs = (int)pairs.size();
-    h.n_prims = (int)prims.size();
+    h.n_prims = strip_prims ? 0 : (int)prims.size();
     int nverts = 0, npv = 0;
     for (auto &s : shapes) nverts += (s.kind == SH_CIRCLE) ? 1 : (int)s.verts.size();
-    for (auto &p : prims) npv += (int)p.verts.size();
+    if (!strip_prims) for (auto &p : prims) npv += (int)p.verts.size();
     h.n_verts = nverts; h.n_pverts = npv;
     h.n_state = (int)state_map.size();
     h.n_state_p = n_state_p;
@@ -650,7 +674,7 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
         double *pr = &rw[o.prim_r + k * PRIM_RWORDS];
         int nv = (P.kind == PR_NGON) ? P.ngon : (int)P.verts.size();
         pi[0] = P.kind; pi[1] = nv; pi[2] = pvoff;
-        pi[3] = P.xform | (P.body << 8) | ((P.eye_body + 1) << 16);
+        pi[3] = P.xform | (P.body << 8) | ((P.eye_body + 1) << 16) | ((P.role + 1) << 24) | (int32_t)((uint32_t)(P.ent + 1) << 26);
         pi[4] = P.rgb[0] | (P.rgb[1] << 8) | (P.rgb[2] << 16);
         pi[5] = P.stipple | ((P.goal + 1) << 16);      // low 16 bits: line stipple; high: 1 + goal ordinal
         {

@@ -54,6 +54,8 @@ struct EntityDef {
     double x, y, angle, h, w;
     int body;                // main body index after finalize (-1 for goals)
     std::vector<int> shapes;
+    bool enabled = true;     // false: this env's episode does not have the entity (Test*CountPlus): it keeps its index and,
+                             // for a block, an inert body with its state rows, so that indices and rows agree across envs
 };
 
 struct World {
@@ -77,6 +79,9 @@ struct World {
     std::vector<int> island_j;         // first joint (pivot) of every block's {pivot, gear} pair
 
     int finalize(int max_steps, std::string &err);
+    // the same task with other per-episode choices (Test*Shape / CountPlus / All): entity e is present iff enabled[e]
+    // (NULL: as here) and blocks take shape_types[e] (NULL or < 0: as here); finalized like this world
+    int variant(const uint8_t *enabled, const int *shape_types, World &out, std::string &err) const;
     // geom.py:116-262 pm_randomise_pose's collision test, on the host: would entity `ent`, with every entity at
     // poses[3 * e .. 3 * e + 2] (x, y, angle; goals: their box centre), touch the arena walls or a shape of an entity
     // whose `enabled` flag is set?  (space.shape_query of each of its shapes: Chipmunk's cpCollide count > 0)
@@ -89,7 +94,8 @@ struct World {
                             const uint8_t *rand_pos, const uint8_t *rand_rot, const double *pos_limits, const double *rot_limits,
                             uint32_t *mt_key, int *mt_pos, const double *ent_hw = nullptr) const;
     // serialise: header + int words + real words (as double; caller narrows to float if needed)
-    void serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<double> &rw, std::vector<double> &pw) const;
+    // strip_prims: without the draw list (the physics kernels' copy)
+    void serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<double> &rw, std::vector<double> &pw, bool strip_prims = false) const;
 };
 
 // RGB8 (r | g << 8 | b << 16) of entity colour 0..3 in role 0 darkened / 1 base / 2 lightened twice (style.py:28-37)

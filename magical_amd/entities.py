@@ -74,6 +74,19 @@ def shape_colours_obj():
     return SHAPE_COLOURS_OBJ
 
 
+SHAPE_TYPES_OBJ = None
+SHAPE_TYPE_NAMES = tuple(t.value for t in SHAPE_TYPES)
+
+
+def shape_types_obj():
+    """np.asarray(SHAPE_TYPES, dtype='object'): rng.choice argument of the Test*Shape branches."""
+    global SHAPE_TYPES_OBJ
+    if SHAPE_TYPES_OBJ is None:
+        import numpy as np
+        SHAPE_TYPES_OBJ = np.asarray(SHAPE_TYPES, dtype='object')
+    return SHAPE_TYPES_OBJ
+
+
 class Entity:
     ent_id = None      # index in the native world after add_entities()
     body = None        # native body index of the main body (None for goal regions)

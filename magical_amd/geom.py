@@ -117,7 +117,7 @@ def pm_randomise_all_poses(env, poses, entities, arena_lrbt, rng, rand_pos=True,
 
 
 def pm_randomise_all_poses_batch(env, poses, entities, arena_lrbt, rngs, rand_pos=True, rand_rot=True, rel_pos_linf_limits=None,
-                                 rel_rot_limits=None, ignore=(), ent_hw=None):
+                                 rel_rot_limits=None, ignore=(), ent_hw=None, env_idx=None):
     """pm_randomise_all_poses for M envs in one native call: poses float64[M, n_entities, 3] (updated in place), rngs the
     M envs' np.random.RandomState objects, whose MT19937 states are advanced in place through their ctypes address.
     The limits are scalars / per-entity lists as in the reference, or float64[M, n] arrays (NaN = no limit) when they
@@ -149,10 +149,19 @@ def pm_randomise_all_poses_batch(env, poses, entities, arena_lrbt, rngs, rand_po
     arena = np.asarray(arena_lrbt, dtype=np.float64)
     assert poses.dtype == np.float64 and poses.flags.c_contiguous and poses.shape[0] == m
     P8, PD = C.POINTER(C.c_uint8), C.POINTER(C.c_double)
-    rc = env._lib.mgx_world_randomise_all_poses_batch(
-        env._world, m, poses.ctypes.data_as(PD), ents, n, ign.ctypes.data_as(P8), arena.ctypes.data_as(PD), rp.ctypes.data_as(P8),
-        rr.ctypes.data_as(P8), pl.ctypes.data_as(PD), rl.ctypes.data_as(PD), 1 if per_env else 0, addrs.ctypes.data_as(C.POINTER(C.c_uint64)),
-        None if ent_hw is None else np.ascontiguousarray(ent_hw, dtype=np.float64).ctypes.data_as(PD))
+    hw = None if ent_hw is None else np.ascontiguousarray(ent_hw, dtype=np.float64).ctypes.data_as(PD)
+    if getattr(env, 'variable_worlds', False):
+        # every env is placed in its own episode's world (shape types / entity counts differ between envs)
+        assert env_idx is not None and len(env_idx) == m
+        idx32 = np.ascontiguousarray(env_idx, dtype=np.int32)
+        rc = env._lib.mgx_engine_env_randomise_all_poses_batch(
+            env._engine, m, idx32.ctypes.data_as(C.POINTER(C.c_int)), poses.ctypes.data_as(PD), ents, n, ign.ctypes.data_as(P8),
+            arena.ctypes.data_as(PD), rp.ctypes.data_as(P8), rr.ctypes.data_as(P8), pl.ctypes.data_as(PD), rl.ctypes.data_as(PD),
+            1 if per_env else 0, addrs.ctypes.data_as(C.POINTER(C.c_uint64)), hw)
+    else:
+        rc = env._lib.mgx_world_randomise_all_poses_batch(
+            env._world, m, poses.ctypes.data_as(PD), ents, n, ign.ctypes.data_as(P8), arena.ctypes.data_as(PD), rp.ctypes.data_as(P8),
+            rr.ctypes.data_as(P8), pl.ctypes.data_as(PD), rl.ctypes.data_as(PD), 1 if per_env else 0, addrs.ctypes.data_as(C.POINTER(C.c_uint64)), hw)
     if rc < 0:
         raise PlacementError(env._lib.mgx_last_error().decode())
     return poses

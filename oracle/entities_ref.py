@@ -20,6 +20,7 @@ NAN = float('nan')
 SHAPE_TYPES = ('triangle', 'square', 'pentagon', 'hexagon', 'octagon',
                'circle', 'star')  # entities.py:545-554
 SHAPE_COLOURS = ('red', 'green', 'blue', 'yellow')  # entities.py:575-581
+RAND_SHAPE_TYPES = ('square', 'pentagon', 'star', 'circle')   # entities.py:568-574: what the rand_shape* branches draw from
 
 
 def _flat(verts):

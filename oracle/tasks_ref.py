@@ -1,7 +1,8 @@
 """Task layouts + score_on_end_of_traj restatements.
 
-TEST INFRASTRUCTURE.  One class per reference task file; the Demo (all rand_* False) branches of every task, plus the
-colour-only randomisation branches (the *-TestColour-* variants).  Scores follow the reference's
+TEST INFRASTRUCTURE.  One class per reference task file, with every rand_* branch of its on_reset() (the Demo and all
+Test* variants).  `slots` lists the episode's entities in the order of the product's entity list for the task (None
+where this episode has no such entity), so that tests can compare entity by entity.  Scores follow the reference's
 float64 numpy/Python operation order so they can be compared bit-for-bit with
 the product's host scoring.
 """
@@ -10,7 +11,7 @@ import math
 
 import numpy as np
 
-from .entities_ref import SHAPE_COLOURS, GoalRegion, Robot, Shape
+from .entities_ref import RAND_SHAPE_TYPES, SHAPE_COLOURS, GoalRegion, Robot, Shape
 
 ROBOT_RAD = 0.2          # base_env.py:62
 ROBOT_MASS = 1.0         # base_env.py:63
@@ -95,7 +96,11 @@ class MoveToCornerRef(TaskRef):
         shape_colour = 'red'
         if self.flags.get('rand_shape_colour'):          # move_to_corner.py:42-44
             shape_colour = self.draw('colour', lambda: self.rng.choice(np.asarray(SHAPE_COLOURS, dtype='object')))
-        self.shape = w.add(_shape('square', shape_colour, shape_pose[:2], shape_pose[2]))
+        shape_type = 'square'
+        if self.flags.get('rand_shape_type'):            # move_to_corner.py:45-47
+            shape_type = self.draw('shape_type', lambda: self.rng.choice(np.asarray(RAND_SHAPE_TYPES, dtype='object')))
+        self.shape = w.add(_shape(shape_type, shape_colour, shape_pose[:2], shape_pose[2]))
+        self.slots = [self.robot, self.shape]
         if self.flags.get('rand_poses') and self.replay is None:    # move_to_corner.py:56-63
             self.jitter([self.robot, self.shape], rel_pos_linf_limits=JITTER_POS_BOUND, rel_rot_limits=JITTER_ROT_BOUND)
 
@@ -138,6 +143,7 @@ class MoveToRegionRef(TaskRef):
             gx, gy = cx - gw / 2, cy + gh / 2             # GoalRegion(x, y, h, w): top-left corner of the box around the body
         self.goal = w.add(GoalRegion(gx, gy, gh, gw, goal_colour))
         self.robot = w.add(_robot(robot_pose[:2], robot_pose[2]))
+        self.slots = [self.goal, self.robot]
         if (minor or full) and self.replay is None:       # move_to_region.py:63-78
             lim = dict(rel_pos_linf_limits=JITTER_POS_BOUND, rel_rot_limits=[None, JITTER_ROT_BOUND]) if minor else {}
             self.jitter([self.goal, self.robot], rand_rot=(False, True), **lim)
@@ -172,12 +178,26 @@ class MatchRegionsRef(TaskRef):
         distractor_colours = [c for c in SHAPE_COLOURS if c != target_colour]
         distractor_types = [[], ['pentagon'], ['circle', 'pentagon']]
         distractor_poses = [[], [(-0.05, -0.2, -1.09)], [(-0.75, -0.55, 2.78), (0.3, -0.82, -1.15)]]
+        target_count, distractor_counts = len(target_types), [len(lst) for lst in distractor_types]
+        if self.flags.get('rand_shape_count'):           # match_regions.py:101-105
+            target_count, distractor_counts = self.draw('counts', lambda: (
+                self.rng.randint(1, 2 + 1), [self.rng.randint(0, 2 + 1) for _ in distractor_colours]))
+        if self.flags.get('rand_shape_type'):            # match_regions.py:110-117
+            types_np = np.asarray(RAND_SHAPE_TYPES, dtype='object')
+            target_types, distractor_types = self.draw('shape_types', lambda: (
+                [self.rng.choice(types_np) for _ in range(target_count)],
+                [[self.rng.choice(types_np) for _ in range(n)] for n in distractor_counts]))
+        if full:                                          # match_regions.py:122-126
+            target_poses = [(0, 0, 0)] * target_count
+            distractor_poses = [[(0, 0, 0)] * n for n in distractor_counts]
         if self.replay is not None and 'poses' in self.replay:
             (cx, cy, _), (rx, ry, ra), *sp = self.replay['poses']
             gx, gy = cx - gw / 2, cy + gh / 2
             robot = _robot((rx, ry), ra)
-            target_poses, rest = sp[:2], sp[2:]
-            distractor_poses = [[], rest[:1], rest[1:3]]
+            target_poses, rest = sp[:target_count], sp[target_count:]
+            distractor_poses = []
+            for n in distractor_counts:
+                distractor_poses.append(rest[:n]); rest = rest[n:]
         self.sensor = w.add(GoalRegion(gx, gy, gh, gw, target_colour))
         self.target_shapes = [_shape(t, target_colour, (x, y), a) for t, (x, y, a) in zip(target_types, target_poses)]
         self.distractor_shapes = []
@@ -187,6 +207,16 @@ class MatchRegionsRef(TaskRef):
         for e in self.target_shapes + self.distractor_shapes:
             w.add(e)
         self.robot = w.add(robot)
+        # product slots: region, 2 targets, 2 distractors per distractor colour, robot (the Demo list without counts:
+        # region, the 2 targets, the 3 distractors, robot)
+        if self.flags.get('rand_shape_count'):
+            pad = lambda lst, n: list(lst) + [None] * (n - len(lst))
+            self.slots, at = [self.sensor, *pad(self.target_shapes, 2)], 0
+            for n in distractor_counts:
+                self.slots += pad(self.distractor_shapes[at:at + n], 2); at += n
+            self.slots.append(self.robot)
+        else:
+            self.slots = [self.sensor, *self.target_shapes, *self.distractor_shapes, self.robot]
         if (minor or full) and self.replay is None:       # match_regions.py:166-188: the region is never rotated
             all_ents = [self.sensor, self.robot, *self.target_shapes, *self.distractor_shapes]
             lim = dict(rel_pos_linf_limits=JITTER_POS_BOUND, rel_rot_limits=JITTER_ROT_BOUND) if minor else {}
@@ -240,17 +270,24 @@ class MakeLineRef(TaskRef):
         w = self.world
         robot = _robot((0.702, -0.255), 0.347)
         colours = ['blue', 'yellow', 'red', 'green']
-        if self.flags.get('rand_colours'):                # make_line.py:105-107
-            colours = self.draw('colours', lambda: self.rng.choice(SHAPE_COLOURS, size=4).tolist())
         shapes = ['star', 'circle', 'star', 'pentagon']
         poses = [((0.790, -0.820), -0.721), ((-0.177, 0.383), -1.733),
                  ((-0.051, -0.128), 2.696), ((-0.292, -0.745), -0.159)]
+        n_blocks = len(shapes)
+        if self.flags.get('rand_count'):                  # make_line.py:100-102 (MIN_BLOCKS, MAX_BLOCKS = 3, 4, :12-13)
+            n_blocks = self.draw('count', lambda: self.rng.randint(3, 4 + 1))
+            poses = poses[:1] * n_blocks
+        if self.flags.get('rand_colours'):                # make_line.py:105-107
+            colours = self.draw('colours', lambda: self.rng.choice(SHAPE_COLOURS, size=n_blocks).tolist())
+        if self.flags.get('rand_shapes'):                 # make_line.py:108-110
+            shapes = self.draw('shape_types', lambda: self.rng.choice(RAND_SHAPE_TYPES, size=n_blocks).tolist())
         if self.replay is not None and 'poses' in self.replay:
             (rx, ry, ra), *bp = self.replay['poses']
             robot = _robot((rx, ry), ra)
             poses = [((x, y), a) for x, y, a in bp]
         self.blocks = [w.add(_shape(s, c, p, a)) for s, c, (p, a) in zip(shapes, colours, poses)]
         self.robot = w.add(robot)
+        self.slots = [*self.blocks, *[None] * (4 - len(self.blocks)), self.robot]
         if (self.flags.get('rand_layout_minor') or self.flags.get('rand_layout_full')) and self.replay is None:   # make_line.py:124-139
             lim = dict(rel_pos_linf_limits=JITTER_POS_BOUND, rel_rot_limits=JITTER_ROT_BOUND) if self.flags.get('rand_layout_minor') else {}
             self.jitter([self.robot, *self.blocks], **lim)
@@ -272,12 +309,21 @@ class FindDupeRef(TaskRef):
         robot = _robot((-0.57, 0.25), 3.83)
         out_shapes = ['pentagon', 'circle', 'circle', 'square', 'star', 'pentagon']
         out_colours = ['green', 'red', 'red', 'yellow', 'blue', 'yellow']
-        query_colour = 'yellow'
+        query_colour, query_shape = 'yellow', 'pentagon'
+        n_out_blocks = len(out_colours)
+        if self.flags.get('rand_count'):                  # find_dupe.py:84-87
+            n_out_blocks = self.draw('count', lambda: self.rng.randint(1, 5 + 1) + 1)
+        n_distractors = n_out_blocks - 1
         if self.flags.get('rand_colours'):                # find_dupe.py:90-95
             def draw_colours():
                 q = self.rng.choice(SHAPE_COLOURS)
-                return q, self.rng.choice(SHAPE_COLOURS, size=len(out_shapes) - 1).tolist() + [q]
+                return q, self.rng.choice(SHAPE_COLOURS, size=n_distractors).tolist() + [q]
             query_colour, out_colours = self.draw('colours', draw_colours)
+        if self.flags.get('rand_shapes'):                 # find_dupe.py:96-100
+            def draw_shapes():
+                q = self.rng.choice(RAND_SHAPE_TYPES)
+                return q, self.rng.choice(RAND_SHAPE_TYPES, size=n_distractors).tolist() + [q]
+            query_shape, out_shapes = self.draw('shape_types', draw_shapes)
         out_poses = [((-0.066751, 0.7552), -2.9266), ((-0.05195, 0.31468), 1.5418),
                      ((0.57528, -0.46865), -2.2141), ((0.40594, -0.74977), 0.24582),
                      ((0.45254, 0.3681), -1.0834), ((0.76849, -0.10652), 0.10028)]
@@ -287,6 +333,8 @@ class FindDupeRef(TaskRef):
             gh, gw = self.draw('goal_hw', lambda: randomise_hw(RAND_GOAL_MIN_SIZE, RAND_GOAL_MAX_SIZE, self.rng, current_hw=(gh, gw),
                                                                linf_bound=JITTER_TARGET_BOUND if minor else None))
         query_pose = ((-0.33, -0.49), -0.51)
+        if self.flags.get('rand_count'):                  # find_dupe.py:122-124
+            out_poses = [((0, 0), 0)] * n_out_blocks
         if self.replay is not None and 'poses' in self.replay:
             P = self.replay['poses']
             (cx, cy, _) = P['sensor']
@@ -299,12 +347,14 @@ class FindDupeRef(TaskRef):
         for s, c, (p, a) in zip(out_shapes, out_colours, out_poses):
             blk = w.add(_shape(s, c, p, a))
             self.outside_blocks.append(blk)
-            if c == query_colour and s == 'pentagon':
+            if c == query_colour and s == query_shape:
                 self.target_set.append(blk)
-        self.query_block = w.add(_shape('pentagon', query_colour, *query_pose))
+        self.query_block = w.add(_shape(query_shape, query_colour, *query_pose))
         self.target_set.append(self.query_block)
         self.distractor_set = [b for b in self.outside_blocks if b not in self.target_set]
         self.robot = w.add(robot)
+        ob = self.outside_blocks
+        self.slots = [self.sensor, *ob, *[None] * (6 - len(ob)), self.query_block, self.robot]
         if (minor or full) and self.replay is None:       # find_dupe.py:157-196
             from . import placement_ref as pr
             all_ents = [self.sensor, self.robot, *self.outside_blocks]
@@ -346,9 +396,14 @@ class FixColourRef(TaskRef):
         region_xyhws = [(-0.032, 0.348, 0.427, 0.468), (0.019, -0.391, 0.460, 0.458),
                         (-0.681, 0.196, 0.498, 0.418)]
         region_colours = ['green', 'green', 'red']
+        n_regions = len(block_colours)
+        if self.flags.get('rand_count'):                  # fix_colour.py:78-82 (MIN_REGIONS, MAX_REGIONS = 2, 3, :9-10)
+            n_regions = self.draw('count', lambda: self.rng.randint(2, 3 + 1))
+            block_poses = block_poses[:1] * n_regions
+            region_xyhws = region_xyhws[:1] * n_regions
         if self.flags.get('rand_colours'):                # fix_colour.py:84-94
             def draw_colours():
-                rc = self.rng.choice(SHAPE_COLOURS, size=len(block_colours)).tolist()
+                rc = self.rng.choice(SHAPE_COLOURS, size=n_regions).tolist()
                 bc = list(rc)
                 odd_idx = self.rng.randint(len(bc))
                 new_col_idx = self.rng.randint(len(SHAPE_COLOURS) - 1)
@@ -357,6 +412,8 @@ class FixColourRef(TaskRef):
                 bc[odd_idx] = SHAPE_COLOURS[new_col_idx]
                 return rc, bc
             region_colours, block_colours = self.draw('colours', draw_colours)
+        if self.flags.get('rand_shapes'):                 # fix_colour.py:97-99
+            block_shapes = self.draw('shape_types', lambda: self.rng.choice(RAND_SHAPE_TYPES, size=n_regions).tolist())
         minor, full = self.flags.get('rand_layout_minor'), self.flags.get('rand_layout_full')
         if minor or full:                                 # fix_colour.py:102-113 (MIN / MAX_GOAL_SIZE = 0.4 / 0.5, :13-14)
             hws = self.draw('goal_hw', lambda: [randomise_hw(0.4, 0.5, self.rng, current_hw=hw, linf_bound=JITTER_TARGET_BOUND if minor else None)
@@ -376,6 +433,8 @@ class FixColourRef(TaskRef):
         for b in self.blocks:
             w.add(b)
         self.robot = w.add(robot)
+        pad = lambda lst: list(lst) + [None] * (3 - len(lst))
+        self.slots = [*pad(self.sensors), *pad(self.blocks), self.robot]
         if (minor or full) and self.replay is None:       # fix_colour.py:143-187
             from . import placement_ref as pr
             n = len(self.sensors)
@@ -411,27 +470,39 @@ class _ClusterRef(TaskRef):
     def on_reset(self):
         w = self.world
         robot = _robot(*self.ROBOT_POSE)
-        colours = self.COLOURS
+        colours, shape_types, poses = self.COLOURS, self.SHAPES, self.POSES
+        n_shapes = len(colours)
+        if self.flags.get('rand_shape_count'):           # cluster.py:81-85
+            n_shapes = self.draw('count', lambda: self.rng.randint(7, 10 + 1))
+            poses = [((0, 0), 0)] * n_shapes
         if self.flags.get('rand_shape_colour'):          # cluster.py:91-100
             def draw_colours():
                 cs = list(SHAPE_COLOURS)
-                cs.extend([self.rng.choice(SHAPE_COLOURS) for _ in range(len(self.POSES) - len(cs))])
+                cs.extend([self.rng.choice(SHAPE_COLOURS) for _ in range(n_shapes - len(cs))])
                 self.rng.shuffle(cs)
                 return cs
             colours = self.draw('colours', draw_colours)
-        poses = self.POSES
+        if self.flags.get('rand_shape_type'):            # cluster.py:102-110
+            def draw_types():
+                ts = list(RAND_SHAPE_TYPES)
+                ts.extend([self.rng.choice(RAND_SHAPE_TYPES) for _ in range(n_shapes - len(ts))])
+                self.rng.shuffle(ts)
+                return ts
+            shape_types = self.draw('shape_types', draw_types)
         if self.replay is not None and 'poses' in self.replay:
             (rx, ry, ra), *bp = self.replay['poses']
             robot = _robot((rx, ry), ra)
             poses = [((x, y), a) for x, y, a in bp]
         self.shape_ents = [w.add(_shape(s, c, p, a))
-                           for (p, a), c, s in zip(poses, colours, self.SHAPES)]
-        c_values_list = np.asarray(colours if self.by == 'colour' else self.SHAPES, dtype='object')
+                           for (p, a), c, s in zip(poses, colours, shape_types)]
+        c_values_list = np.asarray(colours if self.by == 'colour' else shape_types, dtype='object')
         self.characteristic_values = np.unique(c_values_list)
         self.blocks_by_characteristic = {}
         for shape, c_value in zip(self.shape_ents, c_values_list):
             self.blocks_by_characteristic.setdefault(c_value, []).append(shape)
         self.robot = w.add(robot)
+        n_slots = 10 if self.flags.get('rand_shape_count') else len(self.shape_ents)
+        self.slots = [*self.shape_ents, *[None] * (n_slots - len(self.shape_ents)), self.robot]
         if (self.flags.get('rand_layout_minor') or self.flags.get('rand_layout_full')) and self.replay is None:   # cluster.py:148-161
             lim = dict(rel_pos_linf_limits=JITTER_POS_BOUND, rel_rot_limits=JITTER_ROT_BOUND) if self.flags.get('rand_layout_minor') else {}
             self.jitter([self.robot, *self.shape_ents], **lim)

@@ -139,14 +139,8 @@ def _variant_names():
 @pytest.mark.parametrize('env_name', _variant_names())
 def test_rollouts(env_name):
     """The reference's own test (tests/test_rollout_preproc.py:17-36) for every task variant: seeded envs roll out
-    trajectories of the registered length, twice, with sampled actions.  Variants that need per-env collision
-    geometry are registered but not built: they must say so."""
+    trajectories of the registered length, twice, with sampled actions."""
     import magical_amd
-    built = not any(v in env_name for v in ('TestShape', 'TestCountPlus', 'TestAll')) or env_name.startswith('MoveToRegion')
-    if not built:
-        with pytest.raises(NotImplementedError):
-            magical_amd.make(env_name, n_envs=2, device='cuda:0')
-        return
     env = magical_amd.make(env_name, n_envs=3, device='cuda:0', auto_reset=False)
     try:
         env.seed(7)
@@ -483,6 +477,77 @@ def test_pose_randomisation_matches_oracle(task, variant, flags):
             # first step: rounding only; afterwards the reference dynamics amplify it, more so in
             # random layouts where the robot may start next to a block
             assert err < (1e-8 if s % ep == 0 else 3e-2), (task, s, k, err)
+    env.close()
+
+
+_COUNT = {'rand_layout_full': True}
+WORLD_CASES = [
+    ('MoveToCorner', 'TestShape', {'rand_shape_type': True}),
+    ('MoveToCorner', 'TestAll', {'rand_shape_colour': True, 'rand_shape_type': True, 'rand_poses': True, 'rand_dynamics': True}),
+    ('MatchRegions', 'TestShape', {'rand_shape_type': True}),
+    ('MatchRegions', 'TestCountPlus', dict(_COUNT, rand_target_colour=True, rand_shape_type=True, rand_shape_count=True)),
+    ('MakeLine', 'TestShape', {'rand_shapes': True}),
+    ('MakeLine', 'TestAll', dict(_COUNT, rand_colours=True, rand_shapes=True, rand_count=True, rand_dynamics=True)),
+    ('FindDupe', 'TestShape', {'rand_shapes': True}),
+    ('FindDupe', 'TestCountPlus', dict(_COUNT, rand_colours=True, rand_shapes=True, rand_count=True)),
+    ('FixColour', 'TestShape', {'rand_shapes': True}),
+    ('FixColour', 'TestCountPlus', dict(_COUNT, rand_colours=True, rand_shapes=True, rand_count=True)),
+    ('ClusterColour', 'TestShape', {'rand_shape_type': True}),
+    ('ClusterColour', 'TestCountPlus', dict(_COUNT, rand_shape_colour=True, rand_shape_type=True, rand_shape_count=True)),
+    ('ClusterShape', 'TestShape', {'rand_shape_type': True}),
+    ('ClusterShape', 'TestAll', dict(_COUNT, rand_shape_colour=True, rand_shape_type=True, rand_shape_count=True, rand_dynamics=True)),
+]
+ST_ID = {'triangle': 0, 'square': 1, 'pentagon': 2, 'hexagon': 3, 'octagon': 4, 'circle': 5, 'star': 6}
+
+
+@pytest.mark.parametrize('task,variant,flags', WORLD_CASES)
+def test_per_env_worlds_match_oracle(task, variant, flags):
+    """Test*Shape / TestCountPlus / TestAll: every env draws the blocks' shape types and the number of entities from its
+    own stream (e.g. cluster.py:81-110, match_regions.py:101-117) and runs in its own world.  Same draws as the oracle's
+    restatement of the reference's on_reset -> the same entities (compared slot by slot), identical first observations
+    (bit-exact: shapes, colours, counts and poses all show in the frame), identical scores; the fp64 engine tracks the
+    oracle (per-step tolerance as in the other rollout tests); the second episode draws again."""
+    from oracle.env_ref import LoRes4ERef, RefEnv
+    from oracle.entities_ref import GoalRegion as RefGoal
+    n, ep, seed = 6, 3, 4242
+    env = _make(f'{task}-{variant}-LoRes4E-v0', n, dtype='f64', max_episode_steps=ep)
+    env.seed(seed)
+    obs = env.reset().cpu().numpy()
+    refs = [LoRes4ERef(RefEnv(task, max_episode_steps=ep, seed=seed + k, **flags)) for k in range(n)]
+    first = [r.reset() for r in refs]
+    ents = env._entities
+    def compare(tol, what):
+        poses = env.get_poses()
+        worst = 0.0
+        for k, r in enumerate(refs):
+            slots = r.env.task.slots
+            assert len(slots) == len(ents), (task, len(slots), len(ents))
+            for ent, ref_ent in zip(ents, slots):
+                assert bool(env.entity_enabled[k, ent.ent_id]) == (ref_ent is not None), (task, k, ent.ent_id)
+                if ref_ent is None or isinstance(ref_ent, RefGoal):
+                    continue
+                if hasattr(ref_ent, 'shape_type'):
+                    assert env.entity_shape_types[k, ent.ent_id] == ST_ID[str(ref_ent.shape_type)], (task, k, ent.ent_id)
+                want = np.asarray(r.env.task.main_pose(ref_ent))
+                worst = max(worst, np.abs(poses[k, ent.body] - want).max())
+        assert worst < tol, (task, what, worst)
+    def check_reset(obs_now, firsts):
+        compare(1e-12, 'reset')
+        for k in range(n):
+            assert np.array_equal(obs_now[k], firsts[k]), (task, k)
+    check_reset(obs, first)
+    assert len({tuple(env.entity_shape_types[k]) + tuple(env.entity_enabled[k]) for k in range(n)}) > 1      # the envs' worlds differ
+    tape = _tape(53, 2 * ep, n)
+    for s in range(2 * ep):
+        obs, _, done, info = env.step(tape[s])
+        obs = obs.cpu().numpy()
+        outs = [r.step(tape[s, k]) for k, r in enumerate(refs)]
+        if done.all():
+            for k, (_, _, d, inf) in enumerate(outs):
+                assert d and abs(inf['eval_score'] - info['eval_score'][k]) < 1e-12, (task, k, inf['eval_score'], info['eval_score'][k])
+            check_reset(obs, [r.reset() for r in refs])
+            continue
+        compare(1e-8 if s % ep == 0 else 3e-2, f'step {s}')
     env.close()
 
 
