@@ -219,8 +219,12 @@ class BaseEnv(abc.ABC):
                 self._pose_rows[b.value, c.value] = r.value
             else:
                 self._motion_rows[b.value, c.value] = r.value
-        self.lanes_per_env = L.mgx_engine_lanes_per_env(eng)
         del out
+
+    @property
+    def lanes_per_env(self):
+        """Lanes of a wavefront that step one env (with per-env worlds the engine re-picks it as worlds come and go)."""
+        return self._lib.mgx_engine_lanes_per_env(self._engine)
 
     def _info(self, key):
         out = C.c_int()
@@ -306,7 +310,7 @@ class BaseEnv(abc.ABC):
             if self.variable_worlds:
                 trow, erow = self._default_shape_types.copy(), np.ones(len(self._entities), dtype=bool)
                 for ent, t in (var or {}).get('shape_types', {}).items():
-                    trow[ent.ent_id] = en.SHAPE_TYPE_ID[en.ShapeType(t)]
+                    trow[ent.ent_id] = en.SHAPE_TYPE_ID[t]          # str-Enum keys hash and compare as their values
                 for ent, on in (var or {}).get('enabled', {}).items():
                     erow[ent.ent_id] = bool(on)
                 world_rows.append((trow, erow))

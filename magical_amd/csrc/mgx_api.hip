@@ -62,8 +62,10 @@ struct mgx_engine {
     std::vector<std::shared_ptr<World>> env_world;                       // [n_envs]; empty pointer = the default world
     std::unordered_map<std::string, std::weak_ptr<World>> world_by_sig;  // live variants, shared between envs
     int step_stride = 0, raster_stride = 0;                             // words per env in the two blob tables
+    // footprints of the envs' current worlds: the launch geometry follows their maxima, not the capacity world's
+    std::vector<int> fp_step_words, fp_env_stride, fp_raster_words, fp_scratch_d, fp_off_tiles;
     uint32_t *d_stage = nullptr; size_t stage_words = 0;                 // upload staging (device)
-    int32_t *d_stage_idx = nullptr; size_t stage_idx_n = 0;
+    int32_t *d_stage_idx = nullptr; size_t stage_idx_n = 0;       // (env, offsets, sizes) rows of an upload
     int timing = 0;             // 0 = off, n = bracket every n-th launch of each kind with HIP events
     int launch_count[2] = {0, 0};
     int dbg_iterations = -1;    // development probe: override the solver iteration count
@@ -357,13 +359,18 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     // lanes per env: caller's choice, else the widest group (most narrowphase parallelism) that still lets
     // two workgroups share a CU's LDS; worlds too big for that take the narrowest group that fits at all
     int L = e->L_request;
-    if (L == 0) {
+    if (L == 0 && !e->env_worlds) {
         L = 16;
         while (L < 64 && step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES / 2) L *= 2;
-        if (step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES / 2) {
-            L = 16;
-            while (L < 64 && step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES) L *= 2;
+    } else if (L == 0) {
+        // per-env templates: LDS is what limits the envs in flight per CU; take the group width that fits most of them
+        // (16, 32 and 64 lanes run the same arithmetic, tools/lanes_invariance.py, so the choice may change between launches)
+        int best = 0;
+        for (int cand = 16; cand <= 64; cand *= 2) {
+            int envs = (int)((size_t)MAX_LDS_BYTES / (step_lds_bytes(e, cand) + 512)) * (64 / cand);
+            if (envs > best) { best = envs; L = cand; }
         }
+        if (best == 0) L = 64;
     }
     if (L != 4 && L != 8 && L != 16 && L != 32 && L != 64) return fail(MGX_ERR_ARG, "lanes_per_env must be 0, 4, 8, 16, 32 or 64");
     if (step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "world working set does not fit LDS at this lanes_per_env");
@@ -594,6 +601,14 @@ __global__ void k_scatter_rows(uint32_t *dst, long dst_stride, const uint32_t *s
     for (int i = threadIdx.x; i < n_words; i += blockDim.x) dst[d * dst_stride + i] = src[r * src_stride + i];
 }
 
+// env rows[5r]: its step blob <- stage[rows[5r+1] .. +rows[5r+2]), its raster blob <- stage[rows[5r+3] .. +rows[5r+4])
+__global__ void k_place_blobs(uint32_t *tab_s, long stride_s, uint32_t *tab_r, long stride_r, const uint32_t *stage, const int32_t *rows) {
+    const int32_t *r = rows + 5 * (long)blockIdx.x;
+    const long env = r[0];
+    for (int i = threadIdx.x; i < r[2]; i += blockDim.x) tab_s[env * stride_s + i] = stage[(long)r[1] + i];
+    for (int i = threadIdx.x; i < r[4]; i += blockDim.x) tab_r[env * stride_r + i] = stage[(long)r[3] + i];
+}
+
 extern "C" {
 
 int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world) {
@@ -624,7 +639,15 @@ int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world)
     e->tdev.words = tab_s; e->tdev.tmpl_stride_words = step_stride;
     e->rdev.words = tab_r; e->rdev.tmpl_stride_words = raster_stride;
     e->env_world.assign(e->n_envs, std::shared_ptr<World>());
-    int rc = configure_launch(e, (int)cb.step.size(), cb.step_env_stride, (int)cb.raster.size(), cb.raster_scratch_d, cb.raster_off_tiles);
+    {   // the capacity world itself must be launchable
+        int rc = configure_launch(e, (int)cb.step.size(), cb.step_env_stride, (int)cb.raster.size(), cb.raster_scratch_d, cb.raster_off_tiles);
+        if (rc) return rc;
+        if (e->lds_raster > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "capacity world's draw list does not fit LDS");
+    }
+    e->fp_step_words.assign(e->n_envs, (int)db.step.size()); e->fp_env_stride.assign(e->n_envs, db.step_env_stride);
+    e->fp_raster_words.assign(e->n_envs, (int)db.raster.size()); e->fp_scratch_d.assign(e->n_envs, db.raster_scratch_d);
+    e->fp_off_tiles.assign(e->n_envs, db.raster_off_tiles);
+    int rc = configure_launch(e, (int)db.step.size(), db.step_env_stride, (int)db.raster.size(), db.raster_scratch_d, db.raster_off_tiles);
     if (rc) return rc;
     e->rows_p = std::max(e->rows_p, state_rows_p(cb.h)); e->rows_f = std::max(e->rows_f, state_rows_f(cb.h)); e->rows_i = std::max(e->rows_i, state_rows_i(cb.h));
     return MGX_OK;
@@ -686,19 +709,30 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     for (auto &U : uniq) {
         if (U.rc) return fail(U.rc == -2 ? MGX_ERR_CAPACITY : MGX_ERR_ARG, U.err);
         if ((int)U.blobs.step.size() > e->step_stride || (int)U.blobs.raster.size() > e->raster_stride ||
-            U.blobs.step_env_stride > e->tdev.env_stride_words || U.blobs.raster_scratch_d > e->rdev.scratch_d || U.blobs.raster_off_tiles > e->rdev.off_tiles ||
             U.blobs.h.n_prims > 64)
             return fail(MGX_ERR_CAPACITY, "world variant larger than the capacity world");
         if (state_rows_p(U.blobs.h) > e->rows_p || state_rows_f(U.blobs.h) > e->rows_f || state_rows_i(U.blobs.h) > e->rows_i)
             return fail(MGX_ERR_CAPACITY, "world variant needs more state rows than the capacity world");
     }
-    // upload: one staging buffer [m][step_stride | raster_stride], then scatter into the envs' slots
-    const size_t row = (size_t)e->step_stride + e->raster_stride;
-    std::vector<uint32_t> host((size_t)m * row, 0);
+    // upload: the distinct blobs once, packed back to back, then one device-side copy per env into its table slot
+    std::vector<int32_t> off_s(uniq.size()), off_r(uniq.size());
+    size_t total = 0;
+    for (size_t u = 0; u < uniq.size(); u++) {
+        off_s[u] = (int32_t)total; total += uniq[u].blobs.step.size();
+        off_r[u] = (int32_t)total; total += uniq[u].blobs.raster.size();
+        if (total > 0x7fffffffull) return fail(MGX_ERR_CAPACITY, "too many distinct worlds in one call");
+    }
+    std::vector<uint32_t> host(total);
+    for (size_t u = 0; u < uniq.size(); u++) {
+        std::memcpy(host.data() + off_s[u], uniq[u].blobs.step.data(), uniq[u].blobs.step.size() * 4);
+        std::memcpy(host.data() + off_r[u], uniq[u].blobs.raster.data(), uniq[u].blobs.raster.size() * 4);
+    }
+    // per env: destination env, source offsets and sizes of its two blobs
+    std::vector<int32_t> rows((size_t)5 * m);
     for (int k = 0; k < m; k++) {
-        const WorldBlobs &B = uniq[which[k]].blobs;
-        std::memcpy(host.data() + (size_t)k * row, B.step.data(), B.step.size() * 4);
-        std::memcpy(host.data() + (size_t)k * row + e->step_stride, B.raster.data(), B.raster.size() * 4);
+        const int u = which[k];
+        rows[5 * k] = env_idx[k]; rows[5 * k + 1] = off_s[u]; rows[5 * k + 2] = (int32_t)uniq[u].blobs.step.size();
+        rows[5 * k + 3] = off_r[u]; rows[5 * k + 4] = (int32_t)uniq[u].blobs.raster.size();
     }
     if (e->stage_words < host.size()) {
         if (e->d_stage) (void)hipFree(e->d_stage);
@@ -706,20 +740,30 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         HIP_OK(hipMalloc(&e->d_stage, host.size() * 4));
         e->stage_words = host.size();
     }
-    if (e->stage_idx_n < (size_t)m) {
+    if (e->stage_idx_n < rows.size()) {
         if (e->d_stage_idx) (void)hipFree(e->d_stage_idx);
         e->d_stage_idx = nullptr; e->stage_idx_n = 0;
-        HIP_OK(hipMalloc(&e->d_stage_idx, (size_t)m * 4));
-        e->stage_idx_n = m;
+        HIP_OK(hipMalloc(&e->d_stage_idx, rows.size() * 4));
+        e->stage_idx_n = rows.size();
     }
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(hipMemcpyAsync(e->d_stage, host.data(), host.size() * 4, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(e->d_stage_idx, env_idx, (size_t)m * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_scatter_rows, dim3(m), dim3(256), 0, st, e->d_step, (long)e->step_stride, e->d_stage, (long)row, e->d_stage_idx, e->step_stride);
-    hipLaunchKernelGGL(k_scatter_rows, dim3(m), dim3(256), 0, st, e->d_raster, (long)e->raster_stride, e->d_stage + e->step_stride, (long)row, e->d_stage_idx, e->raster_stride);
+    HIP_OK(hipMemcpyAsync(e->d_stage_idx, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_place_blobs, dim3(m), dim3(256), 0, st, e->d_step, (long)e->step_stride, e->d_raster, (long)e->raster_stride, e->d_stage, e->d_stage_idx);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(st));        // `host` and env_idx are read by the copies above
-    for (int k = 0; k < m; k++) e->env_world[env_idx[k]] = uniq[which[k]].world;
+    HIP_OK(hipStreamSynchronize(st));        // `host` and `rows` are read by the copies above
+    for (int k = 0; k < m; k++) {
+        const int env = env_idx[k];
+        const WorldBlobs &B = uniq[which[k]].blobs;
+        e->env_world[env] = uniq[which[k]].world;
+        e->fp_step_words[env] = (int)B.step.size(); e->fp_env_stride[env] = B.step_env_stride;
+        e->fp_raster_words[env] = (int)B.raster.size(); e->fp_scratch_d[env] = B.raster_scratch_d; e->fp_off_tiles[env] = B.raster_off_tiles;
+    }
+    {
+        auto mx = [](const std::vector<int> &v) { return *std::max_element(v.begin(), v.end()); };
+        int rc = configure_launch(e, mx(e->fp_step_words), mx(e->fp_env_stride), mx(e->fp_raster_words), mx(e->fp_scratch_d), mx(e->fp_off_tiles));
+        if (rc) return rc;
+    }
     for (auto &U : uniq) e->world_by_sig[U.sig] = U.world;
     if (e->world_by_sig.size() > (size_t)4 * e->n_envs + 64)
         for (auto it = e->world_by_sig.begin(); it != e->world_by_sig.end();) it = it->second.expired() ? e->world_by_sig.erase(it) : std::next(it);

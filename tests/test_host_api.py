@@ -113,6 +113,59 @@ def test_world_builder_matches_oracle_tables():
         L.mgx_world_destroy(w)
 
 
+def test_world_variants_keep_indices_and_match_oracle_worlds():
+    """mgx_world_variant (Test*Shape / CountPlus worlds): absent blocks keep their entity index and an inert body with its
+    state rows, so body indices and the host-addressed state rows are those of the full world; the present entities'
+    masses / inertias / joint count equal the oracle's world built with only those entities."""
+    from magical_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        pytest.skip('HIP library not built')
+    from oracle.env_ref import RefEnv
+    from tests.util import ref_body_index
+    L = _native.lib()
+    info = lambda w, key: (lambda out: (_native.check(L.mgx_world_info(w, _native.INFO[key], ctypes.byref(out))), out.value)[1])(ctypes.c_int())
+    flags = dict(rand_shape_colour=True, rand_shape_type=True, rand_shape_count=True, rand_layout_full=True)
+    st_id = {'triangle': 0, 'square': 1, 'pentagon': 2, 'hexagon': 3, 'octagon': 4, 'circle': 5, 'star': 6}
+    w = ctypes.c_void_p()
+    _native.check(L.mgx_world_create(ctypes.byref(w)))
+    for k in range(10):                                      # the ten block slots of Cluster*-TestCountPlus, then the robot
+        _native.check(L.mgx_world_add_shape(w, 1, 0, 0.0, 0.0, 0.0))
+    _native.check(L.mgx_world_add_robot(w, 0.286, -0.202, -1.878))
+    _native.check(L.mgx_world_finalize(w, 100))
+    full = {k: info(w, k) for k in ('n_bodies', 'state_rows_p', 'physvar_row', 'n_shapes', 'n_joints')}
+    seen_counts = set()
+    for seed in range(6):
+        ref = RefEnv('ClusterShape', seed=seed, **flags)
+        ref.reset()
+        slots = ref.task.slots
+        enabled = np.array([s is not None for s in slots], dtype=np.uint8)
+        types = np.array([st_id[str(s.shape_type)] if s is not None and hasattr(s, 'shape_type') else -1 for s in slots], dtype=np.int32)
+        seen_counts.add(int(enabled.sum()))
+        v = ctypes.c_void_p()
+        _native.check(L.mgx_world_variant(w, enabled.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), types.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(v)))
+        assert {k: info(v, k) for k in ('n_bodies', 'state_rows_p', 'physvar_row')} == {k: full[k] for k in ('n_bodies', 'state_rows_p', 'physvar_row')}
+        assert info(v, 'n_joints') == ref.L.ref_njoints(ref.h)
+        nb = full['n_bodies']
+        mass = (ctypes.c_double * (2 * nb))()
+        _native.check(L.mgx_world_body_table(v, mass, None))
+        mass = np.array(mass).reshape(nb, 2)
+        body = ctypes.c_int()
+        want = ref.body_mass()
+        for e, s in enumerate(slots):
+            _native.check(L.mgx_world_entity(v, e, None, ctypes.byref(body), None, None))
+            if s is None:
+                assert np.all(mass[body.value] == 0.0)                       # inert
+            else:
+                assert np.allclose(mass[body.value], want[s.bodies[0]], rtol=1e-14, atol=0), (seed, e)
+        L.mgx_world_destroy(v)
+    assert len(seen_counts) > 1
+    # the robot cannot be absent; unknown shape types are rejected
+    bad = np.ones(11, dtype=np.uint8); bad[10] = 0
+    v = ctypes.c_void_p()
+    assert L.mgx_world_variant(w, bad.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), None, ctypes.byref(v)) < 0
+    L.mgx_world_destroy(w)
+
+
 def test_palette_table_matches_colorsys():
     """The RGB8 palette baked into mgx_world.cpp equals style.py evaluated with colorsys (oracle/style_ref.py)."""
     from oracle.style_ref import COLOURS_RGB, darken_rgb, lighten_rgb, to_u8

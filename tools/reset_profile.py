@@ -1,0 +1,24 @@
+"""GPU-box probe: where does a reset of N envs of a Test* variant spend its host time?  (cProfile, top entries)"""
+import sys, os, time, cProfile, pstats
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import magical_amd
+name = sys.argv[1] if len(sys.argv) > 1 else 'MatchRegions-TestCountPlus-LoRes4E-v0'
+N = 4096
+env = magical_amd.make(name, n_envs=N, device='cuda:0')
+env.seed(3); env.reset(); torch.cuda.synchronize()
+idx = np.arange(N)
+pr = cProfile.Profile()
+t0 = time.perf_counter()
+pr.enable()
+env._reset_envs(idx, None); torch.cuda.synchronize()
+pr.disable()
+print(name, 'reset of %d envs: %.1f ms' % (N, (time.perf_counter() - t0) * 1e3))
+pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
+for _ in range(3):
+    t0 = time.perf_counter(); env.step(torch.zeros(N, dtype=torch.int32, device='cuda:0')); torch.cuda.synchronize()
+print('step %.2f ms' % ((time.perf_counter() - t0) * 1e3))
+env.set_timing(1)
+for _ in range(20): env.step(torch.zeros(N, dtype=torch.int32, device='cuda:0'))
+torch.cuda.synchronize()
+print('k_step %.3f ms  k_raster %.3f ms' % (env.read_timing('step').mean(), env.read_timing('raster').mean()))
