@@ -43,6 +43,7 @@ struct WorldBlobs {
     std::vector<uint32_t> step;      // [header without prims][ints][R words][P words]
     std::vector<uint32_t> raster;    // [header][ints][prim reals + prim verts, fp64]
     int step_env_stride = 0;         // LDS words of the per-env working set
+    int step_off_r = 0, step_off_p = 0, step_env_off_r = 0, step_env_off_i = 0;
     int raster_scratch_d = 0, raster_off_tiles = 0;
 };
 
@@ -326,6 +327,8 @@ static void make_blobs_t(const World &w, WorldBlobs &b) {
         { R *d = reinterpret_cast<R *>(b.step.data() + off_r); for (size_t i = 0; i < rw.size(); i++) d[i] = (R)rw[i]; }
         { P *d = reinterpret_cast<P *>(b.step.data() + off_p); for (size_t i = 0; i < pw.size(); i++) d[i] = (P)pw[i]; }
         WorkOff wo(hs);
+        b.step_off_r = off_r; b.step_off_p = off_p;
+        b.step_env_off_r = even(wo.n_p * (int)(sizeof(P) / 4)); b.step_env_off_i = b.step_env_off_r + even(wo.n_r * (int)(sizeof(R) / 4));
         int stride = even(wo.n_p * (int)(sizeof(P) / 4)) + even(wo.n_r * (int)(sizeof(R) / 4)) + even(wo.n_i);
         while (stride % 32 != 2) stride += 2;     // envs of one wave start on distinct LDS banks
         b.step_env_stride = stride;
@@ -349,10 +352,7 @@ static void make_blobs(int dtype, const World &w, WorldBlobs &b) {
     else make_blobs_t<float, float>(w, b);
 }
 
-static size_t step_lds_bytes(const mgx_engine *e, int L) {
-    const int epb = 64 / L;
-    return (size_t)((e->env_worlds ? epb : 1) * e->tdev.lds_tmpl_words + epb * e->tdev.env_stride_words) * 4;
-}
+static size_t step_lds_bytes(const mgx_engine *e, int L) { return (size_t)(e->tdev.lds_tmpl_words + (64 / L) * e->tdev.env_stride_words) * 4; }
 // size the launch geometry (lanes per env, LDS, raster variant) for blobs of the given sizes
 static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, int raster_words, int scratch_d, int off_tiles) {
     e->tdev.off_i = HDR_WORDS; e->tdev.lds_tmpl_words = even(step_words); e->tdev.env_stride_words = step_env_stride;
@@ -363,14 +363,7 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
         L = 16;
         while (L < 64 && step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES / 2) L *= 2;
     } else if (L == 0) {
-        // per-env templates: LDS is what limits the envs in flight per CU; take the group width that fits most of them
-        // (16, 32 and 64 lanes run the same arithmetic, tools/lanes_invariance.py, so the choice may change between launches)
-        int best = 0;
-        for (int cand = 16; cand <= 64; cand *= 2) {
-            int envs = (int)((size_t)MAX_LDS_BYTES / (step_lds_bytes(e, cand) + 512)) * (64 / cand);
-            if (envs > best) { best = envs; L = cand; }
-        }
-        if (best == 0) L = 64;
+        L = 64;      // per-env templates: one env per wavefront, so that its template copy in LDS is shared by all lanes
     }
     if (L != 4 && L != 8 && L != 16 && L != 32 && L != 64) return fail(MGX_ERR_ARG, "lanes_per_env must be 0, 4, 8, 16, 32 or 64");
     if (step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "world working set does not fit LDS at this lanes_per_env");
@@ -404,6 +397,7 @@ static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const i
 template <typename R, typename P>
 static int launch_step(mgx_engine *e, void *sp, void *sf, int32_t *si, const int32_t *actions, uint8_t *done, int n_sub,
                        int count_step, hipStream_t st) {
+    if (e->env_worlds && e->L != 64) return fail(MGX_ERR_ARG, "per-env worlds run one env per wavefront (lanes_per_env 64)");
     switch (e->L) {
         case 4: return launch_step_L<R, P, 4>(e, sp, sf, si, actions, done, n_sub, count_step, st);
         case 8: return launch_step_L<R, P, 8>(e, sp, sf, si, actions, done, n_sub, count_step, st);
@@ -461,6 +455,7 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
         mgx_engine_destroy(e); return fail(MGX_ERR_HIP, "template upload failed");
     }
     e->tdev.words = e->d_step; e->tdev.n_words = (int)b.step.size(); e->tdev.tmpl_stride_words = 0;
+    e->tdev.off_r = b.step_off_r; e->tdev.off_p = b.step_off_p; e->tdev.env_off_r = b.step_env_off_r; e->tdev.env_off_i = b.step_env_off_i;
     e->rdev.words = e->d_raster; e->rdev.n_words = (int)b.raster.size(); e->rdev.tmpl_stride_words = 0;
     e->rdev.bg_rgb = BG_RGB; e->rdev.qcap = QCAP; e->rdev.ecap = ECAP; e->rdev.palette = e->d_palette;
     *out = e;

@@ -17,12 +17,14 @@ namespace mgx {
 
 // template blob in global memory: [TmplHeader][int words][R words][P words], P part 8-byte aligned.
 // One blob shared by every env (tmpl_stride_words == 0), or one per env at words + env * tmpl_stride_words (tasks whose
-// episodes differ in shape types / entity counts): then every env of a workgroup stages its own copy into LDS.
+// episodes differ in shape types / entity counts): those run one env per workgroup (L = 64), which stages its env's copy.
 struct TmplDev {
     const uint32_t *words;
     int n_words;       // 32-bit words of the shared blob (per-env blobs carry their sizes in their headers)
     int off_i;         // word offset of the int array (the R and P arrays follow, see tmpl_off_r / tmpl_off_p)
     long tmpl_stride_words;    // 0: one template for all envs
+    int off_r, off_p;          // shared blob: word offsets of the R and P arrays
+    int env_off_r, env_off_i;  // shared blob: word offsets of the R and int regions inside an env's slab (P region first)
     int env_stride_words;      // per-env LDS stride of the working set in 32-bit words (multiple of 2)
     int lds_tmpl_words;        // LDS words reserved per template copy (multiple of 2)
     unsigned long long *dbg_clk;   // development probe (MGX_STEP_PROBE builds): per-workgroup phase cycles [blocks][32]
@@ -61,27 +63,30 @@ __global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *_
     long env = (long)wg * EPB + env_local;
     const bool valid = env < n_envs;
     if (!valid) env = n_envs - 1;   // tail lanes shadow the last env (no stores) so barriers stay uniform
-    uint32_t *tl = lds;             // this env's template in LDS
-    int n_tmpl = 1;
-    if (t.tmpl_stride_words == 0) {
-        for (int i = tid; i < t.n_words; i += 64) lds[i] = t.words[i];
-    } else {
-        const uint32_t *src = t.words + env * t.tmpl_stride_words;
-        const int n = tmpl_total_words<R, P>(*reinterpret_cast<const TmplHeader *>(src), t.off_i);
-        tl = lds + env_local * t.lds_tmpl_words;
-        n_tmpl = EPB;
-        for (int i = lane; i < n; i += L) tl[i] = src[i];
+    // the template in LDS.  Per-env worlds run one env per workgroup (L = 64), so the copy -- this env's own -- is still
+    // shared by all lanes and every template address stays wave-uniform
+    const bool per_env = L == 64 && t.tmpl_stride_words != 0;
+    {
+        const uint32_t *src = t.words;
+        int n = t.n_words;
+        if (per_env) {
+            src += (long)__builtin_amdgcn_readfirstlane((int)env) * t.tmpl_stride_words;
+            n = tmpl_total_words<R, P>(*reinterpret_cast<const TmplHeader *>(src), t.off_i);
+        }
+        for (int i = tid; i < n; i += 64) lds[i] = src[i];
     }
     __syncthreads();
-    const TmplHeader *h = reinterpret_cast<const TmplHeader *>(tl);
-    const int32_t *ti = reinterpret_cast<const int32_t *>(tl + t.off_i);
-    const R *tr = reinterpret_cast<const R *>(tl + tmpl_off_r<R>(*h, t.off_i));
-    const P *tp = reinterpret_cast<const P *>(tl + tmpl_off_p<R, P>(*h, t.off_i));
-
-    uint32_t *slab = lds + n_tmpl * t.lds_tmpl_words + env_local * t.env_stride_words;
-    // the working set of THIS env's world inside its slab: pose region, real region, int region
-    const WorkOff wo_(*h);
-    const int slab_off_r = even_words(wo_.n_p * (int)(sizeof(P) / 4)), slab_off_i = slab_off_r + even_words(wo_.n_r * (int)(sizeof(R) / 4));
+    const TmplHeader *h = reinterpret_cast<const TmplHeader *>(lds);
+    const int32_t *ti = reinterpret_cast<const int32_t *>(lds + t.off_i);
+    const R *tr = reinterpret_cast<const R *>(lds + (per_env ? tmpl_off_r<R>(*h, t.off_i) : t.off_r));
+    const P *tp = reinterpret_cast<const P *>(lds + (per_env ? tmpl_off_p<R, P>(*h, t.off_i) : t.off_p));
+    uint32_t *slab = lds + t.lds_tmpl_words + env_local * t.env_stride_words;
+    // the working set inside the slab: pose region, real region, int region (per-env worlds: of THIS env's world)
+    int slab_off_r = t.env_off_r, slab_off_i = t.env_off_i;
+    if (per_env) {
+        const WorkOff wo_(*h);
+        slab_off_r = even_words(wo_.n_p * (int)(sizeof(P) / 4)); slab_off_i = slab_off_r + even_words(wo_.n_r * (int)(sizeof(R) / 4));
+    }
     Env<R, P> e(h, ti, tr, tp, reinterpret_cast<R *>(slab + slab_off_r), reinterpret_cast<P *>(slab),
                 reinterpret_cast<int32_t *>(slab + slab_off_i));
     const long stride = n_envs;
@@ -98,19 +103,22 @@ __global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *_
     SYNC(ph_init_work(e, lane, nl))
     SYNC(ph_load_state(e, sp, sf, si, stride, env, lane, nl))
     ph_refresh_trig(e, lane, nl);
-    if (lane == 0) E_I(misc, M_ACTION) = actions[env];
+    if (lane == 0) {
+        E_I(misc, M_ACTION) = actions[env];
+        // the episode step counter and the done flag depend on nothing below: settle them here, so that `done` and
+        // `count_step` are not carried through the whole kernel
+        if (count_step) {
+            const int steps = E_I(misc, M_STEPS) + 1;
+            E_I(misc, M_STEPS) = steps;
+            if (done && valid) done[env] = steps >= h->max_episode_steps ? 1 : 0;
+        }
+    }
     __syncthreads();
     if (lane == 0) ph_control(e);
     __syncthreads();
     for (int sub = 0; sub < n_sub; sub++) {
         MGX_SUBSTEP_PHASES(SYNC)
     }
-    if (lane == 0 && count_step) {
-        int steps = E_I(misc, M_STEPS) + 1;
-        E_I(misc, M_STEPS) = steps;
-        if (done && valid) done[env] = steps >= h->max_episode_steps ? 1 : 0;
-    }
-    __syncthreads();
     if (valid) ph_store_state(e, sp, sf, si, stride, env, lane, nl);
 #ifdef MGX_STEP_PROBE
     if (t.dbg_clk && tid == 0) for (int i = 0; i < 20; i++) t.dbg_clk[(long)blockIdx.x * 32 + i] = pacc[i];

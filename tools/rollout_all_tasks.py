@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""one rollout of every Demo task, `--envs` envs per task sharded over the GPUs of the job,
+"""one rollout of every task (Demo, or the --variant given / every variant with `all`), `--envs` envs per task sharded over the GPUs of the job,
 per-env scores gathered on every rank (RCCL all_gather over xGMI; observations never leave their GPU).
 
     python tools/rollout_all_tasks.py --envs 8192 [--preproc LoRes4E]
@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--envs', type=int, default=8192, help='envs per task over the whole job')
     ap.add_argument('--preproc', default='LoRes4E')
+    ap.add_argument('--variant', default='Demo', help="'Demo', a Test* variant name, or 'all' for every registered variant of every task")
     ap.add_argument('--seed', type=int, default=0)
     args = ap.parse_args()
     import torch
@@ -28,8 +29,16 @@ def main():
     rank, world, local_rank = init_from_env(backend='nccl')
     torch.cuda.set_device(local_rank)
     lo, hi = env_shard(args.envs, rank, world)
-    for task in TASKS:
-        name = f'{task}-Demo-{args.preproc}-v0' if args.preproc else f'{task}-Demo-v0'
+    magical_amd.register_envs()
+    variants = (sorted({magical_amd.EnvName(n).variant for n in magical_amd.ALL_REGISTERED_ENVS}, key=lambda v: (v != 'Demo', v))
+                if args.variant == 'all' else [args.variant])
+    names = []
+    for variant in variants:
+        for task in TASKS:
+            name = f'{task}-{variant}-{args.preproc}-v0' if args.preproc else f'{task}-{variant}-v0'
+            if name in magical_amd.ALL_REGISTERED_ENVS:
+                names.append((task, name))
+    for task, name in names:
         env = magical_amd.make(name, n_envs=hi - lo, device=f'cuda:{local_rank}')
         T = env.max_episode_steps
         # the action tape of the whole job, every rank takes its slice (same results for any number of GPUs)
