@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import magical_amd
-for name in ['ClusterColour-Demo-v0', 'MatchRegions-Demo-v0', 'MoveToCorner-Demo-v0', 'ClusterShape-TestAll-v0']:
+for name in ['ClusterColour-Demo-v0', 'MatchRegions-Demo-v0', 'MoveToCorner-Demo-v0']:
     outs = {}
     for L in (16, 32, 64):
         try:
