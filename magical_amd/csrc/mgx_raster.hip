@@ -79,6 +79,43 @@ template <int LAYOUT> __device__ __forceinline__ void store_pre(uint8_t *frame, 
     }
     px[0] = d0; px[1] = d1; px[2] = d2;
 }
+// Two horizontally adjacent pixels (24 B) per lane: 16 lanes cover a 32-pixel row = 384 B = three whole 128 B lines, so
+// the in-place shift of a PAIR of 16x4 tiles reads and writes complete lines only (a single tile's row is 1.5 lines).
+struct OldPx2 { OldPx a, b; };
+template <int LAYOUT> __device__ __forceinline__ OldPx2 load_old2(const uint8_t *frame, uint32_t off) {
+    const uint32_t *px = reinterpret_cast<const uint32_t *>(frame + off);
+    OldPx2 o;
+    o.a.o0 = px[0]; o.b.o0 = px[3];
+    if (LAYOUT == LAY_SLOT0) { o.a.o1 = o.a.o2 = o.b.o1 = o.b.o2 = 0; }
+    else { o.a.o1 = px[1]; o.a.o2 = px[2]; o.b.o1 = px[4]; o.b.o2 = px[5]; }
+    return o;
+}
+template <int LAYOUT> __device__ __forceinline__ void shifted_px(int c, bool fill, const OldPx &o, uint32_t &d0, uint32_t &d1, uint32_t &d2) {
+    const uint32_t r = c & 0xFF, g = (c >> 8) & 0xFF, b = (c >> 16) & 0xFF;
+    if (fill) {
+        d0 = LAYOUT == LAY_STACK4 ? (r | (g << 8) | (b << 16) | (r << 24)) : ((o.o0 & 0xFFFFFFu) | (r << 24));
+        d1 = g | (b << 8) | (r << 16) | (g << 24);
+        d2 = b | (r << 8) | (g << 16) | (b << 24);
+    } else {
+        d0 = LAYOUT == LAY_STACK4 ? ((o.o0 >> 24) | (o.o1 << 8)) : ((o.o0 & 0xFFFFFFu) | ((o.o1 >> 16) << 24));
+        d1 = (o.o1 >> 24) | (o.o2 << 8);
+        d2 = (o.o2 >> 24) | ((uint32_t)c << 8);
+    }
+}
+template <int LAYOUT> __device__ __forceinline__ void store_pre2(uint8_t *frame, uint32_t off, int c0, int c1, bool fill, const OldPx2 &o) {
+    uint32_t *px = reinterpret_cast<uint32_t *>(frame + off);
+    if (LAYOUT == LAY_SLOT0) {
+        px[0] = (o.a.o0 & 0xFF000000u) | ((uint32_t)c0 & 0xFFFFFFu);
+        px[3] = (o.b.o0 & 0xFF000000u) | ((uint32_t)c1 & 0xFFFFFFu);
+        return;
+    }
+    uint32_t d[6];
+    shifted_px<LAYOUT>(c0, fill, o.a, d[0], d[1], d[2]);
+    shifted_px<LAYOUT>(c1, fill, o.b, d[3], d[4], d[5]);
+    // 24 B, 8-byte aligned
+    uint2 *q = reinterpret_cast<uint2 *>(px);
+    q[0] = make_uint2(d[0], d[1]); q[1] = make_uint2(d[2], d[3]); q[2] = make_uint2(d[4], d[5]);
+}
 // phases Q / E: the pixel has already been shifted by phase T; write only the bytes that hold the new frame
 template <int LAYOUT> __device__ __forceinline__ void store_patch(uint8_t *frame, int X, int Y, int c, bool fill) {
     uint8_t *px = frame + (long)(Y * LORES + X) * 12;
@@ -270,8 +307,7 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
     const bool fill = LAYOUT != LAY_FRAME && fill_mask != nullptr && fill_mask[env] != 0;
     const bool need_old = layout_needs_old<LAYOUT>(fill);
     uint8_t *frame = out + env * env_stride;
-    // wave w walks tiles w, w + 4, ... (pairing horizontally adjacent tiles to complete 128 B lines back to back was
-    // measured slower and produced more write-back traffic)
+    // wave w walks tiles w, w + 4, ... (FRAME layout; the stacked layouts walk pairs of tiles, below)
     auto seq_tile = [&](int i) { return wave + 4 * i; };
     constexpr int N_SEQ = N_TILES / 4;
     static_assert(N_TILES % 4 == 0, "tiles per wave");
@@ -339,42 +375,50 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
             if (!queued) store_frame_px(frame, X, Y, c);
         }
     } else {
-        // STACK4 shifts 12 B per pixel in place.  The old pixels are fetched a whole group of G tiles ahead (G x 768 B
-        // in flight per wavefront) so that the read latency is covered by the previous group's classification.
-        constexpr int G = MGX_STACK_GROUP;
-        static_assert(N_SEQ % G == 0, "tile groups");
-        OldPx nxt[G];
+        // STACK4 shifts 12 B per pixel in place.  Memory is walked in PAIRS of horizontally adjacent tiles (32 x 4 pixels, lane =
+        // two adjacent pixels, whole cache lines); the old pixels of a whole group of G tiles (G / 2 pairs, G x 768 B per
+        // wavefront) are fetched ahead so that the read latency is covered by the previous group's classification.
+        constexpr int G = MGX_STACK_GROUP, GP = G / 2;
+        static_assert(G % 2 == 0 && N_SEQ % G == 0 && TILES_X % 2 == 0, "tile pairs / groups");
+        // wave w's i-th pair = tiles 2 (w + 4 i), 2 (w + 4 i) + 1; this lane's two pixels of it sit at pair_off(pair)
+        const int mr = lane >> 4, mc = lane & 15;
+        auto pair_tile = [&](int i) { return 2 * (wave + 4 * i); };
+        auto pair_off = [&](int tile0) { return (uint32_t)((((tile0 / TILES_X) * TILE_H + mr) * LORES + (tile0 % TILES_X) * TILE_W + 2 * mc) * 12); };
+        // the classification has lane = one pixel of ONE tile: lane (mr, mc) of the pair takes its two colours from lanes
+        // src, src + 1 of the left (mc < 8) or right tile
+        const int src = mr * 16 + ((2 * mc) & 15);
+        const bool right = mc >= 8;
+        OldPx2 nxt[GP];
 #pragma unroll
-        for (int u = 0; u < G; u++) {
-            nxt[u] = OldPx{0, 0, 0};
-            const int tile = seq_tile(u);
-            if (need_old) nxt[u] = load_old<LAYOUT>(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty);
+        for (int u = 0; u < GP; u++) {
+            nxt[u] = OldPx2{{0, 0, 0}, {0, 0, 0}};
+            if (need_old) nxt[u] = load_old2<LAYOUT>(frame, pair_off(pair_tile(u)));
         }
-        for (int g = 0; g < N_SEQ; g += G) {
-            OldPx cur[G];
+        for (int g = 0; g < N_SEQ / 2; g += GP) {
+            OldPx2 cur[GP];
 #pragma unroll
-            for (int u = 0; u < G; u++) {
+            for (int u = 0; u < GP; u++) {
                 cur[u] = nxt[u];
-                const int tile = seq_tile(g + G + u);
-                if (need_old && g + G < N_SEQ) nxt[u] = load_old<LAYOUT>(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty);
+                if (need_old && g + GP < N_SEQ / 2) nxt[u] = load_old2<LAYOUT>(frame, pair_off(pair_tile(g + GP + u)));
             }
             int col[G];
 #pragma unroll
             for (int v = 0; v < G; v++) col[v] = 0;
 #pragma unroll 1
             for (int u = 0; u < G; u++) {
-                const int tile = seq_tile(g + u);
+                const int tile = pair_tile(g + (u >> 1)) + (u & 1);
                 bool queued;
                 const int c = do_tile(tile, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty, queued);
 #pragma unroll
                 for (int v = 0; v < G; v++) col[v] = u == v ? c : col[v];
             }
 #pragma unroll
-            for (int u = 0; u < G; u++) {
-                const int tile = seq_tile(g + u);
+            for (int u = 0; u < GP; u++) {
+                const int a0 = __shfl(col[2 * u], src), a1 = __shfl(col[2 * u], src + 1);
+                const int b0 = __shfl(col[2 * u + 1], src), b1 = __shfl(col[2 * u + 1], src + 1);
                 // queued pixels are shifted here too (with a placeholder for the new frame's bytes) so that phases Q / E
                 // only patch those bytes in, without reading the pixel back
-                store_pre<LAYOUT>(frame, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty, col[u], fill, cur[u]);
+                store_pre2<LAYOUT>(frame, pair_off(pair_tile(g + u)), right ? b0 : a0, right ? b1 : a1, fill, cur[u]);
             }
         }
     }
