@@ -551,6 +551,37 @@ def test_per_env_worlds_match_oracle(task, variant, flags):
     env.close()
 
 
+def _variant_vector_cases():
+    import json
+    import os
+    return sorted(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'variant_vectors.json'))).items())
+
+
+@pytest.mark.parametrize('name,rec', _variant_vector_cases(), ids=[k for k, _ in _variant_vector_cases()])
+def test_variants_match_golden_vectors(name, rec):
+    """The committed fixture tests/golden/variant_vectors.json: seeded like the recording, the product draws the same
+    worlds (entity slots present, shape types, poses) over two consecutive resets and renders byte-identical first
+    observations, without the oracle being consulted; the scores after the recorded tapes agree."""
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    task, variant = name.split('-')
+    env = _make(f'{task}-{variant}-LoRes4E-v0', 1, dtype='f64', max_episode_steps=rec['episode_steps'])
+    env.seed(rec['seed'])
+    obs = env.reset()
+    for ep, gold in enumerate(rec['episodes']):
+        assert env.entity_enabled[0].tolist() == gold['enabled'], (name, ep)
+        for ent, st, pose in zip(env._entities, gold['shape_types'], gold['poses']):
+            if st is not None:
+                assert env.entity_shape_types[0, ent.ent_id] == ST_ID[st], (name, ep, ent.ent_id)
+            if pose is not None:
+                assert np.abs(env.get_poses()[0, ent.body] - np.asarray(pose)).max() < 1e-12, (name, ep, ent.ent_id)
+        assert sha(obs[0].cpu().numpy()) == gold['lores4e'], (name, ep)
+        for a in gold['tape']:
+            obs, _, done, info = env.step(np.array([a], dtype=np.int32))
+        assert done.all() and abs(info['eval_score'][0] - gold['score']) < 1e-9, (name, ep)
+    env.close()
+
+
 def test_debug_reward_env():
     """MoveToCorner-Demo-DebugReward-v0 (move_to_corner.py:77-98): the shaped reward on the device equals the oracle's
     restatement on the same poses; the preprocessor-suffixed names build the plain env, as in the reference."""

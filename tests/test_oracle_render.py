@@ -132,3 +132,29 @@ def test_oracle_reproduces_golden_vectors():
         assert np.abs(env.env.bodies() - want).max() < 1e-9, task
         if np.array_equal(env.env.bodies(), want):
             assert sha(obs) == rec['final']['lores4e'] and sha(env.env.render_lores('ego')) == rec['final']['ego']
+
+
+def test_oracle_reproduces_variant_vectors():
+    """tests/golden/variant_vectors.json (made by make_variant_vectors.py): seeded alike, the oracle's restatement of the
+    reference's on_reset draws (counts, shape types, colours, layout; two consecutive resets of one stream) still yields
+    the recorded worlds, first observations and scores."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    gold_path = os.path.join(GOLDEN, 'variant_vectors.json')
+    gold = json.load(open(gold_path))
+    sys.path.insert(0, GOLDEN)
+    import make_variant_vectors as mk
+    assert {f'{t}-{v}' for t, v, _ in mk.CASES} == set(gold)
+    for task, variant, flags in mk.CASES:
+        rec = gold[f'{task}-{variant}']
+        assert rec['flags'] == flags and rec['seed'] == mk.SEED
+        now = mk.record(task, flags, mk.SEED)
+        for ep, (a, b) in enumerate(zip(now, rec['episodes'])):
+            assert a['enabled'] == b['enabled'] and a['shape_types'] == b['shape_types'] and a['tape'] == b['tape'], (task, ep)
+            for pa, pb in zip(a['poses'], b['poses']):
+                assert (pa is None) == (pb is None) and (pa is None or np.abs(np.asarray(pa) - np.asarray(pb)).max() < 1e-12), (task, ep)
+            if a['poses'] == b['poses']:
+                assert a['lores4e'] == b['lores4e'], (task, ep)
+            assert abs(a['score'] - b['score']) < 1e-9, (task, ep)
