@@ -750,3 +750,42 @@ def test_full_size_properties_4096():
     assert np.all(np.abs(poses[:, 1:, :2]) < 1.2)
     assert int(env.state_i[2].sum()) == 0           # no contact-cache / overlap-list overflow
     env.close()
+
+
+def test_per_env_worlds_full_size_properties_4096():
+    """Per-env worlds at BASELINE.json's size (ClusterColour-TestAll: counts, shape types, colours, layout and dynamics all
+    drawn per episode).  Size-independent properties: envs [k0, k0 + 32) of a 4096-env batch seeded s equal a 32-env batch
+    seeded s + k0, bit for bit (worlds, poses, states and
+    observations through two resets), so an env does not depend on what the rest of the batch holds or on how the
+    templates were uploaded; two equally seeded engines agree; nothing overflows, nothing escapes the arena."""
+    import torch
+    n, m, k0, seed = 4096, 32, 1500, 77
+    name = 'ClusterColour-TestAll-LoRes4E-v0'
+    big, big2, small = _make(name, n), _make(name, n), _make(name, m)
+    big.seed(seed); big2.seed(seed); small.seed(seed + k0)
+    tape = _tape(5, 245, n)
+    ob, ob2, os_ = big.reset(), big2.reset(), small.reset()
+    sl = slice(k0, k0 + m)
+    def same():
+        assert np.array_equal(big.entity_shape_types[sl], small.entity_shape_types) and np.array_equal(big.entity_enabled[sl], small.entity_enabled)
+        rows = big._pose_rows.max() + 1
+        assert torch.equal(big.state_p[:rows, sl], small.state_p[:rows]), 'poses'
+        assert torch.equal(ob[sl], os_), 'observations'
+        assert torch.equal(ob, ob2) and torch.equal(big.state_p, big2.state_p)
+    same()
+    assert len({tuple(r) for r in big.entity_shape_types}) > 1000            # thousands of distinct worlds in flight
+    for s in range(245):
+        ob, _, done, info = big.step(tape[s])
+        ob2, _, _, info2 = big2.step(tape[s])
+        os_, _, done_s, info_s = small.step(tape[s, sl])
+        if s in (0, 100, 239, 244):
+            same()
+        if done.any():
+            assert done.all() and done_s.all() and s == 239
+            assert np.array_equal(info['eval_score'][sl], info_s['eval_score']) and np.array_equal(info['eval_score'], info2['eval_score'])
+    assert int(big.state_i[2].sum()) == 0
+    present = torch.as_tensor(big.entity_enabled[:, [e.ent_id for e in big._entities if e.body is not None]])
+    pos = torch.as_tensor(big.get_poses()[:, [e.body for e in big._entities if e.body is not None], :2])
+    assert float(pos[present].abs().max()) < 1.2
+    for e in (big, big2, small):
+        e.close()
