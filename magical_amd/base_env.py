@@ -40,7 +40,9 @@ class PhysicsVariables:
 
     @classmethod
     def sample(cls, rng):
-        return [float(rng.uniform(*getattr(cls, n)[1])) for n in cls.NAMES]
+        # rng.uniform(lo, hi) per variable, in order = lo + (hi - lo) * random_sample(): one call for the five doubles
+        u = rng.random_sample(len(cls.NAMES))
+        return [float(lo + (hi - lo) * x) for x, (lo, hi) in zip(u, (getattr(cls, n)[1] for n in cls.NAMES))]
 
 
 class BaseEnv(abc.ABC):

@@ -41,7 +41,7 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
             # at least one block of each colour, the rest drawn, then shuffled
             names = en.SHAPE_COLOUR_NAMES
             colours = list(names)
-            colours.extend([rng.choice(names) for _ in range(n_shapes - len(colours))])
+            colours.extend(en.draw_choice(rng, names, size=n_shapes - len(colours)) if n_shapes > len(colours) else [])
             rng.shuffle(colours)
             var['colours'] = dict(zip(ents, colours))
             if self.cluster_by == self.ClusterBy.COLOUR:
@@ -50,7 +50,7 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
             # likewise one of each type
             names = en.SHAPE_TYPE_NAMES
             shape_types = list(names)
-            shape_types.extend([rng.choice(names) for _ in range(n_shapes - len(shape_types))])
+            shape_types.extend(en.draw_choice(rng, names, size=n_shapes - len(shape_types)) if n_shapes > len(shape_types) else [])
             rng.shuffle(shape_types)
             var['shape_types'] = dict(zip(ents, shape_types))
             if self.cluster_by == self.ClusterBy.TYPE:

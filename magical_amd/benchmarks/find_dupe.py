@@ -47,15 +47,15 @@ class FindDupeEnv(BaseEnv):
         out_block_shapes = [t.value for t in DEFAULT_OUT_BLOCK_SHAPES]
         if self.rand_colours:
             names = en.SHAPE_COLOUR_NAMES
-            query_colour = rng.choice(names)
-            out_block_colours = rng.choice(names, size=n_distractors).tolist()
+            query_colour = en.draw_choice(rng, names)
+            out_block_colours = en.draw_choice(rng, names, size=n_distractors)
             out_block_colours.append(query_colour)               # the last outside block always matches the query
             colours = {self.__sensor_ref: query_colour, self.__all_blocks[0]: query_colour}
             colours.update(zip(outside, out_block_colours))
             var['colours'] = colours
         if self.rand_shapes:
-            query_shape = rng.choice(en.SHAPE_TYPE_NAMES)
-            out_block_shapes = rng.choice(en.SHAPE_TYPE_NAMES, size=n_distractors).tolist()
+            query_shape = en.draw_choice(rng, en.SHAPE_TYPE_NAMES)
+            out_block_shapes = en.draw_choice(rng, en.SHAPE_TYPE_NAMES, size=n_distractors)
             out_block_shapes.append(query_shape)
             var['shape_types'] = {self.__all_blocks[0]: query_shape}
             var['shape_types'].update(zip(outside, out_block_shapes))

@@ -38,7 +38,7 @@ class FixColourEnv(BaseEnv):
             var['enabled'] = {e: i < n_regions for ents in (self._sensors, self._blocks) for i, e in enumerate(ents)}
         if self.rand_colours:
             names = en.SHAPE_COLOUR_NAMES
-            region_colours = rng.choice(names, size=n_regions).tolist()
+            region_colours = en.draw_choice(rng, names, size=n_regions)
             block_colours = list(region_colours)
             odd_idx = rng.randint(len(block_colours))            # one block gets a colour that is not its region's
             new_col_idx = rng.randint(len(names) - 1)
@@ -53,7 +53,7 @@ class FixColourEnv(BaseEnv):
             colours.update(zip(self._blocks, block_colours))
             var['colours'] = colours
         if self.rand_shapes:                      # fix_colour.py:97-99
-            var['shape_types'] = dict(zip(self._blocks, rng.choice(en.SHAPE_TYPE_NAMES, size=n_regions).tolist()))
+            var['shape_types'] = dict(zip(self._blocks, en.draw_choice(rng, en.SHAPE_TYPE_NAMES, size=n_regions)))
         if self.rand_layout_minor or self.rand_layout_full:
             minor = self.rand_layout_minor
             hw_bound = self.JITTER_TARGET_BOUND if minor else None

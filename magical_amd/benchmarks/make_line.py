@@ -102,10 +102,10 @@ class MakeLineEnv(BaseEnv):
             n_blocks = rng.randint(MIN_BLOCKS, MAX_BLOCKS + 1)
             var['enabled'] = {b: i < n_blocks for i, b in enumerate(self._blocks)}
         if self.rand_colours:
-            block_colours = rng.choice(en.SHAPE_COLOUR_NAMES, size=n_blocks).tolist()
+            block_colours = en.draw_choice(rng, en.SHAPE_COLOUR_NAMES, size=n_blocks)
             var['colours'] = dict(zip(self._blocks, block_colours))
         if self.rand_shapes:                      # make_line.py:108-110
-            var['shape_types'] = dict(zip(self._blocks, rng.choice(en.SHAPE_TYPE_NAMES, size=n_blocks).tolist()))
+            var['shape_types'] = dict(zip(self._blocks, en.draw_choice(rng, en.SHAPE_TYPE_NAMES, size=n_blocks)))
         if self.rand_layout_minor or self.rand_layout_full:
             all_ents = (self._robot, *self._blocks)
             pos_limits, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if self.rand_layout_minor else (None, None)

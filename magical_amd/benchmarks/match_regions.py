@@ -27,7 +27,7 @@ class MatchRegionsEnv(BaseEnv):
         var = {}
         if self.rand_target_colour:
             # the sensor and the targets take the drawn colour, the distractor groups the remaining ones in SHAPE_COLOURS order
-            target_colour = rng.choice(en.SHAPE_COLOUR_NAMES)
+            target_colour = en.draw_choice(rng, en.SHAPE_COLOUR_NAMES)
             distractor_colours = [c for c in en.SHAPE_COLOUR_NAMES if c != target_colour]
             colours = {self.__sensor_ref: target_colour}
             colours.update({s: target_colour for s in self.__target_shapes})
@@ -47,10 +47,10 @@ class MatchRegionsEnv(BaseEnv):
             for g, n in zip(groups, distractor_counts):
                 var['enabled'].update({s: i < n for i, s in enumerate(g)})
         if self.rand_shape_type:
-            types_np = en.shape_types_obj()
-            var['shape_types'] = {s: rng.choice(types_np) for s in targets[:target_count]}
+            types_np = en.SHAPE_TYPE_NAMES
+            var['shape_types'] = {s: en.draw_choice(rng, types_np) for s in targets[:target_count]}
             for g, n in zip(groups, distractor_counts):
-                var['shape_types'].update({s: rng.choice(types_np) for s in g[:n]})
+                var['shape_types'].update({s: en.draw_choice(rng, types_np) for s in g[:n]})
         if self.rand_layout_minor or self.rand_layout_full:
             all_ents = (self.__sensor_ref, self._robot, *self.__target_shapes, *self.__distractor_shapes)
             pos_limits, rot_limits = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if self.rand_layout_minor else (None, None)

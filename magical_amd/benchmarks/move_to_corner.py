@@ -46,9 +46,9 @@ class MoveToCornerEnv(BaseEnv):
             return None
         var = {}
         if self.rand_shape_colour:
-            var['colours'] = {self.__shape_ref: rng.choice(en.shape_colours_obj())}
+            var['colours'] = {self.__shape_ref: en.draw_choice(rng, en.SHAPE_COLOUR_NAMES)}
         if self.rand_shape_type:
-            var['shape_types'] = {self.__shape_ref: rng.choice(en.shape_types_obj())}
+            var['shape_types'] = {self.__shape_ref: en.draw_choice(rng, en.SHAPE_TYPE_NAMES)}
         if self.rand_poses:
             var['randomise_poses'] = ((self._robot, self.__shape_ref), dict(
                 rand_pos=True, rand_rot=True, rel_pos_linf_limits=self.JITTER_POS_BOUND, rel_rot_limits=self.JITTER_ROT_BOUND))

@@ -25,7 +25,7 @@ class MoveToRegionEnv(BaseEnv):
             var['goal_hw'] = {self.__goal_ref: geom.randomise_hw(self.RAND_GOAL_MIN_SIZE, self.RAND_GOAL_MAX_SIZE, rng,
                                                                  current_hw=DEFAULT_GOAL_XYHW[2:], linf_bound=hw_bound)}
         if self.rand_goal_colour:
-            var['colours'] = {self.__goal_ref: rng.choice(en.shape_colours_obj())}
+            var['colours'] = {self.__goal_ref: en.draw_choice(rng, en.SHAPE_COLOUR_NAMES)}
         if self.rand_poses_minor or self.rand_poses_full:
             # the goal region is never rotated; under minor jitter only the robot's rotation is bounded
             pos_limits, rot_limits = (self.JITTER_POS_BOUND, [None, self.JITTER_ROT_BOUND]) if self.rand_poses_minor else (None, None)

@@ -87,6 +87,15 @@ def shape_types_obj():
     return SHAPE_TYPES_OBJ
 
 
+def draw_choice(rng, seq, size=None):
+    """rng.choice(seq[, size=n]) of the reference's per-episode draws, without numpy's argument handling: choice() is
+    randint(0, len(seq)[, size]) followed by indexing, so the stream advances identically (tests/test_host_api.py);
+    this is several times cheaper, and the draws run once per env and reset."""
+    if size is None:
+        return seq[rng.randint(0, len(seq))]
+    return [seq[i] for i in rng.randint(0, len(seq), size=size)]
+
+
 class Entity:
     ent_id = None      # index in the native world after add_entities()
     body = None        # native body index of the main body (None for goal regions)

@@ -178,6 +178,7 @@ def randomise_hw(min_side, max_side, rng, current_hw=None, linf_bound=None):
         assert linf_bound == float(linf_bound) and current_hw is not None and len(current_hw) == 2
         lo_h, hi_h = max(lo_h, current_hw[0] - linf_bound), min(hi_h, current_hw[0] + linf_bound)
         lo_w, hi_w = max(lo_w, current_hw[1] - linf_bound), min(hi_w, current_hw[1] + linf_bound)
-    h = rng.uniform(lo_h, hi_h)
-    w = rng.uniform(lo_w, hi_w)
+    uh, uw = rng.random_sample(2)
+    h = lo_h + (hi_h - lo_h) * uh
+    w = lo_w + (hi_w - lo_w) * uw
     return h, w

@@ -271,3 +271,25 @@ def test_make_line_batched_score_is_bit_identical():
             want = np.array([longest_line(np.ascontiguousarray(q), inlier, sep) for q in p])
         assert np.array_equal(got, want), np.nonzero(got != want)[0][:5]
         assert len(np.unique(want)) >= 2
+
+
+def test_cheap_draws_advance_the_stream_like_the_reference_calls():
+    """The per-env draws replace rng.choice / rng.uniform by their cheaper constituents (entities.draw_choice,
+    PhysicsVariables.sample, geom.randomise_hw): same values, same stream position, for scalar and sized draws."""
+    from magical_amd import entities as en, geom
+    from magical_amd.base_env import PhysicsVariables
+    names = en.SHAPE_COLOUR_NAMES
+    for seed in range(50):
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        want = [a.choice(np.asarray(names, dtype='object')) for _ in range(3)] + a.choice(names, size=5).tolist() + [a.choice(names) for _ in range(4)]
+        got = [en.draw_choice(b, names) for _ in range(3)] + en.draw_choice(b, names, size=5) + en.draw_choice(b, names, size=4)
+        assert [str(x) for x in want] == [str(x) for x in got]
+        want_pv = [float(a.uniform(*getattr(PhysicsVariables, n)[1])) for n in PhysicsVariables.NAMES]
+        assert PhysicsVariables.sample(b) == want_pv
+        for kw in (dict(), dict(current_hw=(0.7, 0.6), linf_bound=0.0075)):
+            minima, maxima = np.asarray((0.5, 0.5)), np.asarray((0.8, 0.8))
+            if kw:
+                minima = np.maximum(minima, np.asarray(kw['current_hw']) - kw['linf_bound']); maxima = np.minimum(maxima, np.asarray(kw['current_hw']) + kw['linf_bound'])
+            h, w = a.uniform(minima, maxima)                       # geom.py:344-360
+            assert geom.randomise_hw(0.5, 0.8, b, **kw) == (h, w)
+        assert a.random_sample() == b.random_sample()

@@ -14,7 +14,7 @@ pr.enable()
 env._reset_envs(idx, None); torch.cuda.synchronize()
 pr.disable()
 print(name, 'reset of %d envs: %.1f ms' % (N, (time.perf_counter() - t0) * 1e3))
-pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
+pstats.Stats(pr).sort_stats('cumulative').print_stats(40)
 for _ in range(3):
     t0 = time.perf_counter(); env.step(torch.zeros(N, dtype=torch.int32, device='cuda:0')); torch.cuda.synchronize()
 print('step %.2f ms' % ((time.perf_counter() - t0) * 1e3))
