@@ -66,6 +66,7 @@ struct mgx_engine {
     // footprints of the envs' current worlds: the launch geometry follows their maxima, not the capacity world's
     std::vector<int> fp_step_words, fp_env_stride, fp_raster_words, fp_scratch_d, fp_off_tiles;
     uint32_t *d_stage = nullptr; size_t stage_words = 0;                 // upload staging (device)
+    uint32_t *h_stage = nullptr; size_t h_stage_words = 0;               // upload staging (pinned host memory)
     int32_t *d_stage_idx = nullptr; size_t stage_idx_n = 0;       // (env, offsets, sizes) rows of an upload
     int timing = 0;             // 0 = off, n = bracket every n-th launch of each kind with HIP events
     int launch_count[2] = {0, 0};
@@ -467,6 +468,7 @@ void mgx_engine_destroy(mgx_engine *e) {
     if (e->d_raster) (void)hipFree(e->d_raster);
     if (e->d_palette) (void)hipFree(e->d_palette);
     if (e->d_stage) (void)hipFree(e->d_stage);
+    if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->d_stage_idx) (void)hipFree(e->d_stage_idx);
     for (int k = 0; k < 2; k++) for (auto &ev : e->ev[k]) (void)hipEventDestroy(ev);
     delete e;
@@ -717,10 +719,25 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         off_r[u] = (int32_t)total; total += uniq[u].blobs.raster.size();
         if (total > 0x7fffffffull) return fail(MGX_ERR_CAPACITY, "too many distinct worlds in one call");
     }
-    std::vector<uint32_t> host(total);
-    for (size_t u = 0; u < uniq.size(); u++) {
-        std::memcpy(host.data() + off_s[u], uniq[u].blobs.step.data(), uniq[u].blobs.step.size() * 4);
-        std::memcpy(host.data() + off_r[u], uniq[u].blobs.raster.data(), uniq[u].blobs.raster.size() * 4);
+    // (pinned staging: a pageable copy of this size -- 160 MB for 4096 distinct Cluster worlds -- would dominate the reset)
+    if (e->h_stage_words < total) {
+        if (e->h_stage) (void)hipHostFree(e->h_stage);
+        e->h_stage = nullptr; e->h_stage_words = 0;
+        HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&e->h_stage), total * 4 + 4096, hipHostMallocDefault));
+        e->h_stage_words = total + 1024;
+    }
+    uint32_t *host = e->h_stage;
+    auto pack = [&](int t) {
+        for (size_t u = t; u < uniq.size(); u += n_threads) {
+            std::memcpy(host + off_s[u], uniq[u].blobs.step.data(), uniq[u].blobs.step.size() * 4);
+            std::memcpy(host + off_r[u], uniq[u].blobs.raster.data(), uniq[u].blobs.raster.size() * 4);
+        }
+    };
+    if (n_threads == 1) pack(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; t++) pool.emplace_back(pack, t);
+        for (auto &th : pool) th.join();
     }
     // per env: destination env, source offsets and sizes of its two blobs
     std::vector<int32_t> rows((size_t)5 * m);
@@ -729,11 +746,11 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         rows[5 * k] = env_idx[k]; rows[5 * k + 1] = off_s[u]; rows[5 * k + 2] = (int32_t)uniq[u].blobs.step.size();
         rows[5 * k + 3] = off_r[u]; rows[5 * k + 4] = (int32_t)uniq[u].blobs.raster.size();
     }
-    if (e->stage_words < host.size()) {
+    if (e->stage_words < total) {
         if (e->d_stage) (void)hipFree(e->d_stage);
         e->d_stage = nullptr; e->stage_words = 0;
-        HIP_OK(hipMalloc(&e->d_stage, host.size() * 4));
-        e->stage_words = host.size();
+        HIP_OK(hipMalloc(&e->d_stage, total * 4 + 4096));
+        e->stage_words = total + 1024;
     }
     if (e->stage_idx_n < rows.size()) {
         if (e->d_stage_idx) (void)hipFree(e->d_stage_idx);
@@ -742,14 +759,16 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         e->stage_idx_n = rows.size();
     }
     hipStream_t st = (hipStream_t)stream;
-    HIP_OK(hipMemcpyAsync(e->d_stage, host.data(), host.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->d_stage, host, total * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(e->d_stage_idx, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_place_blobs, dim3(m), dim3(256), 0, st, e->d_step, (long)e->step_stride, e->d_raster, (long)e->raster_stride, e->d_stage, e->d_stage_idx);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(st));        // `host` and `rows` are read by the copies above
+    HIP_OK(hipStreamSynchronize(st));        // the staging buffer and `rows` are read by the copies above
+    std::vector<std::shared_ptr<World>> retired(m);      // the envs' previous worlds: freed below, a few threads wide
     for (int k = 0; k < m; k++) {
         const int env = env_idx[k];
         const WorldBlobs &B = uniq[which[k]].blobs;
+        retired[k] = std::move(e->env_world[env]);
         e->env_world[env] = uniq[which[k]].world;
         e->fp_step_words[env] = (int)B.step.size(); e->fp_env_stride[env] = B.step_env_stride;
         e->fp_raster_words[env] = (int)B.raster.size(); e->fp_scratch_d[env] = B.raster_scratch_d; e->fp_off_tiles[env] = B.raster_off_tiles;
@@ -760,6 +779,19 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         if (rc) return rc;
     }
     for (auto &U : uniq) e->world_by_sig[U.sig] = U.world;
+    {
+        // a World is a few hundred small allocations: drop the retired ones (and this call's blob buffers) in parallel
+        auto drop = [&](int t) {
+            for (size_t k = t; k < retired.size(); k += n_threads) retired[k].reset();
+            for (size_t u = t; u < uniq.size(); u += n_threads) { WorldBlobs empty; std::swap(uniq[u].blobs, empty); }
+        };
+        if (n_threads == 1) drop(0);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < n_threads; t++) pool.emplace_back(drop, t);
+            for (auto &th : pool) th.join();
+        }
+    }
     if (e->world_by_sig.size() > (size_t)4 * e->n_envs + 64)
         for (auto it = e->world_by_sig.begin(); it != e->world_by_sig.end();) it = it->second.expired() ? e->world_by_sig.erase(it) : std::next(it);
     return (int)uniq.size();

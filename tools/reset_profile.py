@@ -8,12 +8,25 @@ N = 4096
 env = magical_amd.make(name, n_envs=N, device='cuda:0')
 env.seed(3); env.reset(); torch.cuda.synchronize()
 idx = np.arange(N)
+# time the native calls of the reset separately (cProfile does not see inside ctypes)
+native_ms = {}
+class _Timed:
+    def __init__(self, lib): self._lib = lib
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith('mgx_engine_set_env_variants') and 'randomise' not in name and 'reset' not in name:
+            return fn
+        def call(*a):
+            t = time.perf_counter(); r = fn(*a); native_ms[name] = native_ms.get(name, 0.0) + (time.perf_counter() - t) * 1e3
+            return r
+        return call
+env._lib = _Timed(env._lib)
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()
 env._reset_envs(idx, None); torch.cuda.synchronize()
 pr.disable()
-print(name, 'reset of %d envs: %.1f ms' % (N, (time.perf_counter() - t0) * 1e3))
+print(name, 'reset of %d envs: %.1f ms' % (N, (time.perf_counter() - t0) * 1e3), 'native calls (ms):', {k: round(v, 1) for k, v in native_ms.items()})
 pstats.Stats(pr).sort_stats('cumulative').print_stats(40)
 for _ in range(3):
     t0 = time.perf_counter(); env.step(torch.zeros(N, dtype=torch.int32, device='cuda:0')); torch.cuda.synchronize()
