@@ -484,6 +484,57 @@ class BaseEnv(abc.ABC):
                     out[:, b, c] = sp[r]
         return out
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    # per-env task bookkeeping (numpy arrays or None) that belongs to an episode in flight; tasks list theirs
+    TASK_STATE_ATTRS = ()
+
+    def get_state(self):
+        """Snapshot of everything the envs' futures depend on: the three device state blobs, the per-env episode choices
+        (force limits, colours, poses, goal rectangles, worlds), the tasks' per-env bookkeeping, the episode counters and
+        every env's random stream.  The reference can only pickle constructor arguments (base_env.py:20-46); this is the
+        batched engine's counterpart of rebuilding a world from reconstruct_signature() dumps (entities.py:46-84)."""
+        d = {'state_p': self.state_p.clone(), 'state_f': self.state_f.clone(), 'state_i': self.state_i.clone(),
+             'steps': self._steps.copy(), 'phys_vars': self.phys_vars.copy(), 'entity_colours': self.entity_colours.copy(),
+             'entity_poses': self.entity_poses.copy(), 'goal_xyhw': self.goal_xyhw.copy(),
+             'entity_shape_types': self.entity_shape_types.copy(), 'entity_enabled': self.entity_enabled.copy(),
+             'rng': [r.get_state() for r in self.rngs],
+             'task': {a: (None if getattr(self, a) is None else getattr(self, a).copy()) for a in self.TASK_STATE_ATTRS},
+             'have': {'colours': self._ent_colour is not None, 'poses': self._ent_pose is not None, 'goals': self._goal_rect is not None}}
+        return d
+
+    def set_state(self, d):
+        """Inverse of get_state() on an env of the same task / variant / size (any seed, any history)."""
+        import torch
+        assert d['state_p'].shape == self.state_p.shape and d['state_f'].shape == self.state_f.shape and d['state_i'].shape == self.state_i.shape
+        idx = np.arange(self.n_envs)
+        if self.variable_worlds:
+            self.entity_shape_types[:], self.entity_enabled[:] = d['entity_shape_types'], d['entity_enabled']
+            idx32 = np.ascontiguousarray(idx, dtype=np.int32)
+            types = np.ascontiguousarray(self.entity_shape_types, dtype=np.int32)
+            enabled = np.ascontiguousarray(self.entity_enabled, dtype=np.uint8)
+            nat.check(self._lib.mgx_engine_set_env_variants(self._engine, len(idx32), idx32.ctypes.data_as(C.POINTER(C.c_int)),
+                                                            enabled.ctypes.data_as(C.POINTER(C.c_uint8)), types.ctypes.data_as(C.POINTER(C.c_int)),
+                                                            self._stream()))
+        self.state_p.copy_(d['state_p']); self.state_f.copy_(d['state_f']); self.state_i.copy_(d['state_i'])
+        self._steps[:] = d['steps']
+        self.phys_vars[:] = d['phys_vars']
+        if d['have']['colours'] or self._ent_colour is not None:
+            self.set_entity_colours(d['entity_colours'])
+        else:
+            self.entity_colours[:] = d['entity_colours']
+        if d['have']['goals'] or self._goal_rect is not None:
+            self.set_goal_rects(d['goal_xyhw'])
+        else:
+            self.goal_xyhw[:] = d['goal_xyhw']
+        self.entity_poses[:] = d['entity_poses']
+        if d['have']['poses'] or self._ent_pose is not None:      # only the reset kernel reads these
+            self._ent_pose = torch.as_tensor(np.ascontiguousarray(self.entity_poses.reshape(self.n_envs, -1).T),
+                                             device=self.device).to(self.state_p.dtype).contiguous()
+        for r, st in zip(self.rngs, d['rng']):
+            r.set_state(st)
+        for a, v in d['task'].items():
+            setattr(self, a, None if v is None else v.copy())
+
     def get_bodies(self):
         """float64[N, n_bodies, 9] (x y a vx vy w vbx vby wb); non-persistent components are 0."""
         sp = self.state_p.to('cpu').numpy().astype(np.float64)

@@ -25,6 +25,7 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
         self.rand_shape_colour, self.rand_shape_type, self.rand_shape_count = rand_shape_colour, rand_shape_type, rand_shape_count
         self.variable_worlds = bool(rand_shape_type or rand_shape_count)
         self._class_env = None
+        self.TASK_STATE_ATTRS = ('_class_env',)
         super().__init__(**kwargs)
 
     def sample_variation(self, rng, k):   # cluster.py:81-110 (count, colours, types), :148-161 (poses: robot first, then the blocks)

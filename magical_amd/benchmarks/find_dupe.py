@@ -29,6 +29,7 @@ class FindDupeEnv(BaseEnv):
         self.rand_shapes, self.rand_count = rand_shapes, rand_count
         self.variable_worlds = bool(rand_shapes or rand_count)
         self._is_target_env = None
+        self.TASK_STATE_ATTRS = ('_is_target_env',)
         super().__init__(**kwargs)
 
     def sample_variation(self, rng, k):   # find_dupe.py:84-100 (count, colours, shapes), :101-112 (region size), :157-196 (poses)

@@ -26,6 +26,7 @@ class FixColourEnv(BaseEnv):
         self.rand_shapes, self.rand_count = rand_shapes, rand_count
         self.variable_worlds = bool(rand_shapes or rand_count)
         self._keep_env = None
+        self.TASK_STATE_ATTRS = ('_keep_env',)
         super().__init__(**kwargs)
 
     def sample_variation(self, rng, k):   # fix_colour.py:84-94 (colours), :102-113 (region sizes), :143-187 (poses)

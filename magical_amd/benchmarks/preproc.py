@@ -29,6 +29,18 @@ def wrap_preproc(env_cls, preproc):
             self._stack_allo = mk() if preproc == 'LoResStack' else None
             self._ones = torch.ones(self.n_envs, dtype=torch.uint8, device=self.device)
 
+        def get_state(self):
+            d = super().get_state()
+            d['stack'] = self._stack.clone()
+            d['stack_allo'] = None if self._stack_allo is None else self._stack_allo.clone()
+            return d
+
+        def set_state(self, d):
+            super().set_state(d)
+            self._stack.copy_(d['stack'])
+            if self._stack_allo is not None:
+                self._stack_allo.copy_(d['stack_allo'])
+
         def _observation_space(self):
             from .. import spaces
             box = spaces.Box(0, 255, (12, 96, 96) if preproc == 'LoResCHW4E' else (96, 96, 12), 'uint8')

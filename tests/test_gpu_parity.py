@@ -789,3 +789,34 @@ def test_per_env_worlds_full_size_properties_4096():
     assert float(pos[present].abs().max()) < 1.2
     for e in (big, big2, small):
         e.close()
+
+
+@pytest.mark.parametrize('name', ['MoveToCorner-Demo-LoRes4E-v0', 'FixColour-TestAll-LoRes4E-v0', 'ClusterColour-TestJitter-LoResStack-v0'])
+def test_checkpoint_resume(name):
+    """get_state() / set_state(): a snapshot taken mid-episode, restored into a differently seeded env with another
+    history, continues bit for bit -- observations, scores and the draws of the next reset (per-env streams, worlds,
+    colours, layouts, force limits, frame stacks)."""
+    import torch
+    n, ep = 16, 6
+    a = _make(name, n, max_episode_steps=ep); a.seed(5); a.reset()
+    tape = _tape(3, 20, n)
+    for s in range(4):
+        a.step(tape[s])
+    snap = a.get_state()
+    def run(env):
+        out = []
+        for s in range(4, 14):                       # crosses two episode ends
+            obs, _, done, info = env.step(tape[s])
+            obs = obs if isinstance(obs, dict) else {'obs': obs}
+            out.append(({k: v.clone() for k, v in obs.items()}, done.copy(), info['eval_score'].copy()))
+        return out
+    want = run(a)
+    b = _make(name, n, max_episode_steps=ep); b.seed(99); b.reset()
+    for s in range(3):
+        b.step(tape[15 + s])
+    b.set_state(snap)
+    got = run(b)
+    for (ow, dw, sw), (og, dg, sg) in zip(want, got):
+        assert all(torch.equal(ow[k], og[k]) for k in ow) and np.array_equal(dw, dg) and np.array_equal(sw, sg)
+    assert torch.equal(a.state_p, b.state_p) and torch.equal(a.state_f, b.state_f)
+    a.close(); b.close()
