@@ -89,9 +89,9 @@ template <typename R, typename P> struct Env {
     MGX_HD R cst(int k) const { return tr[to.consts + k]; }
 };
 
-#define E_R(field, i) e.wr[e.wo.field + (i)]
-#define E_P(field, i) e.wp[e.wo.field + (i)]
-#define E_I(field, i) e.wi[e.wo.field + (i)]
+#define E_R(field, i) e.wr[e.wo.field + (i) * WorkOff::S_##field]
+#define E_P(field, i) e.wp[e.wo.field + (i) * WorkOff::S_##field]
+#define E_I(field, i) e.wi[e.wo.field + (i) * WorkOff::S_##field]
 #define T_R(field, i) e.tr[e.to.field + (i)]
 #define T_P(field, i) e.tp[e.to.field + (i)]
 #define T_I(field, i) e.ti[e.to.field + (i)]

@@ -120,7 +120,12 @@ struct TmplOff {
 // misc int slots per env
 enum MiscIdx { M_NOV = 0, M_NK, M_NARB, M_NCACHE, M_NNCACHE, M_OVERFLOW, M_ACTION, M_STEPS, M_N };
 
-// per-env LDS working set: offsets in real-sized words (R region) and 32-bit words (int region)
+// per-env LDS working set: offsets in real-sized words (R region) and 32-bit words (int region).
+// The per-body, per-joint and per-contact fields are RECORDS (array of structs): field f of element i sits at
+// wo.f + i * WorkOff::S_f, where wo.f = record base + the field's position.  One base register and immediate offsets then
+// address a whole record (the solver reads all 13 fields of a contact, all 6 velocities of a body), instead of one
+// scalar offset per field held live across the kernel.  Record strides are odd (or lanes walk them with distinct banks)
+// so that lanes working on consecutive elements do not collide in LDS.
 struct WorkOff {
     // bodies: poses live in the pose-precision region (P words), velocities in the R region
     int px, py, ang, c, s, n_p;
@@ -139,23 +144,37 @@ struct WorkOff {
     // int region
     int ov, mcnt, mhash, koff, kab, kfirst, chead, nchead, cmatched, misc, flag, cnt;
     int n_i;
+    // element strides of the fields (1 = plain array)
+#ifndef MGX_AOS
+#define MGX_AOS 11      // bit 0 body poses, 1 body velocities, 2 joints, 3 contacts (joint records measured slower)
+#endif
+    static constexpr bool AOS_BP = MGX_AOS & 1, AOS_BR = MGX_AOS & 2, AOS_J = MGX_AOS & 4, AOS_K = MGX_AOS & 8;
+    static constexpr int BODY_P = AOS_BP ? 5 : 1, BODY_R = AOS_BR ? 6 : 1, JOINT_R = AOS_J ? 15 : 1, CONTACT_R = AOS_K ? 13 : 1;
+    static constexpr int S_px = BODY_P, S_py = BODY_P, S_ang = BODY_P, S_c = BODY_P, S_s = BODY_P;
+    static constexpr int S_vx = BODY_R, S_vy = BODY_R, S_w = BODY_R, S_vbx = BODY_R, S_vby = BODY_R, S_wb = BODY_R;
+    static constexpr int S_wx = 1, S_wy = 1, S_wnx = 1, S_wny = 1, S_bbl = 1, S_bbb = 1, S_bbr = 1, S_bbt = 1;
+    static constexpr int S_jr1x = JOINT_R, S_jr1y = JOINT_R, S_jr2x = JOINT_R, S_jr2y = JOINT_R, S_jk0 = JOINT_R, S_jk1 = JOINT_R, S_jk2 = JOINT_R,
+                         S_jk3 = JOINT_R, S_jb0 = JOINT_R, S_jb1 = JOINT_R, S_ja0 = JOINT_R, S_ja1 = JOINT_R, S_jrate = JOINT_R, S_jlim = JOINT_R;
+    static constexpr int S_knx = CONTACT_R, S_kny = CONTACT_R, S_kr1x = CONTACT_R, S_kr1y = CONTACT_R, S_kr2x = CONTACT_R, S_kr2y = CONTACT_R,
+                         S_knm = CONTACT_R, S_ktm = CONTACT_R, S_kbias = CONTACT_R, S_kjb = CONTACT_R, S_kjn = CONTACT_R, S_kjt = CONTACT_R, S_kmu = CONTACT_R;
+    static constexpr int S_mn = 1, S_mp = 1, S_cj = 1, S_ncj = 1;
+    static constexpr int S_ov = 1, S_mcnt = 1, S_mhash = 1, S_koff = 1, S_kab = 1, S_kfirst = 1, S_chead = 1, S_nchead = 1, S_cmatched = 1,
+                         S_misc = 1, S_flag = 1, S_cnt = 1;
     MGX_HD explicit WorkOff(const TmplHeader &h) {
         int nb = h.n_bodies, nv = h.n_verts, ns = h.n_shapes, nj = h.n_joints;
         int nk = h.max_contacts, nov = h.max_overlaps, nc = h.cache_slots;
         int o = 0;
-        px = o; o += nb; py = o; o += nb; ang = o; o += nb; c = o; o += nb; s = o; o += nb;
+        const int sbp = AOS_BP ? 1 : nb, sbr = AOS_BR ? 1 : nb, sj = AOS_J ? 1 : nj, sk = AOS_K ? 1 : nk;     // distance between a record's fields
+        px = o; py = o + sbp; ang = o + 2 * sbp; c = o + 3 * sbp; s = o + 4 * sbp; o += 5 * nb;
         n_p = o;
         o = 0;
-        vx = o; o += nb; vy = o; o += nb; w = o; o += nb;
-        vbx = o; o += nb; vby = o; o += nb; wb = o; o += nb;
+        vx = o; vy = o + sbr; w = o + 2 * sbr; vbx = o + 3 * sbr; vby = o + 4 * sbr; wb = o + 5 * sbr; o += 6 * nb;
         wx = o; o += nv; wy = o; o += nv; wnx = o; o += nv; wny = o; o += nv;
         bbl = o; o += ns; bbb = o; o += ns; bbr = o; o += ns; bbt = o; o += ns;
-        jr1x = o; o += nj; jr1y = o; o += nj; jr2x = o; o += nj; jr2y = o; o += nj;
-        jk0 = o; o += nj; jk1 = o; o += nj; jk2 = o; o += nj; jk3 = o; o += nj;
-        jb0 = o; o += nj; jb1 = o; o += nj; ja0 = o; o += nj; ja1 = o; o += nj; jrate = o; o += nj; jlim = o; o += nj;
-        knx = o; o += nk; kny = o; o += nk; kr1x = o; o += nk; kr1y = o; o += nk; kr2x = o; o += nk; kr2y = o; o += nk;
-        knm = o; o += nk; ktm = o; o += nk; kbias = o; o += nk; kjb = o; o += nk; kjn = o; o += nk; kjt = o; o += nk;
-        kmu = o; o += nk;
+        jr1x = o; jr1y = o + sj; jr2x = o + 2 * sj; jr2y = o + 3 * sj; jk0 = o + 4 * sj; jk1 = o + 5 * sj; jk2 = o + 6 * sj; jk3 = o + 7 * sj;
+        jb0 = o + 8 * sj; jb1 = o + 9 * sj; ja0 = o + 10 * sj; ja1 = o + 11 * sj; jrate = o + 12 * sj; jlim = o + 13 * sj; o += 15 * nj;
+        knx = o; kny = o + sk; kr1x = o + 2 * sk; kr1y = o + 3 * sk; kr2x = o + 4 * sk; kr2y = o + 5 * sk; knm = o + 6 * sk; ktm = o + 7 * sk;
+        kbias = o + 8 * sk; kjb = o + 9 * sk; kjn = o + 10 * sk; kjt = o + 11 * sk; kmu = o + 12 * sk; o += 13 * nk;
         mn = o; o += nov * 2; mp = o; o += nov * 8;
         cj = o; o += nc * 4; ncj = o; o += nc * 4;
         n_r = o;
