@@ -15,3 +15,15 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def has_reference():
     return os.path.isdir('/root/reference/images')
+
+
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs a kernel must not hold the box until the outer limit: every gpu test gets a timeout
+    (pytest-timeout, thread method: the process is terminated, a signal cannot interrupt a blocked HIP call)."""
+    try:
+        import pytest_timeout  # noqa: F401
+    except ImportError:
+        return
+    for item in items:
+        if item.get_closest_marker('gpu') is not None and item.get_closest_marker('timeout') is None:
+            item.add_marker(pytest.mark.timeout(180, method='thread'))
