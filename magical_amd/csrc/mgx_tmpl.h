@@ -146,20 +146,24 @@ struct WorkOff {
     int n_i;
     // element strides of the fields (1 = plain array)
 #ifndef MGX_AOS
-#define MGX_AOS 11      // bit 0 body poses, 1 body velocities, 2 joints, 3 contacts (joint records measured slower)
+#define MGX_AOS 27      // bit 0 body poses, 1 body velocities, 2 joints, 3 contacts (joint records measured slower), 4.. below
 #endif
     static constexpr bool AOS_BP = MGX_AOS & 1, AOS_BR = MGX_AOS & 2, AOS_J = MGX_AOS & 4, AOS_K = MGX_AOS & 8;
+    // 4 world vertices (x y nx ny: -1.4 %), 5 shape boxes, 6 overlap records (pair count hash offset), 7 contact ints, 8 cache ints
+    // (5..8 measured: no change, left as arrays)
+    static constexpr bool AOS_V = MGX_AOS & 16, AOS_BB = MGX_AOS & 32, AOS_OV = MGX_AOS & 64, AOS_KI = MGX_AOS & 128, AOS_C = MGX_AOS & 256;
     static constexpr int BODY_P = AOS_BP ? 5 : 1, BODY_R = AOS_BR ? 6 : 1, JOINT_R = AOS_J ? 15 : 1, CONTACT_R = AOS_K ? 13 : 1;
     static constexpr int S_px = BODY_P, S_py = BODY_P, S_ang = BODY_P, S_c = BODY_P, S_s = BODY_P;
     static constexpr int S_vx = BODY_R, S_vy = BODY_R, S_w = BODY_R, S_vbx = BODY_R, S_vby = BODY_R, S_wb = BODY_R;
-    static constexpr int S_wx = 1, S_wy = 1, S_wnx = 1, S_wny = 1, S_bbl = 1, S_bbb = 1, S_bbr = 1, S_bbt = 1;
+    static constexpr int VERT_R = AOS_V ? 4 : 1, BOX_R = AOS_BB ? 4 : 1, OV_I = AOS_OV ? 4 : 1, KI_I = AOS_KI ? 2 : 1, C_I = AOS_C ? 3 : 1;
+    static constexpr int S_wx = VERT_R, S_wy = VERT_R, S_wnx = VERT_R, S_wny = VERT_R, S_bbl = BOX_R, S_bbb = BOX_R, S_bbr = BOX_R, S_bbt = BOX_R;
     static constexpr int S_jr1x = JOINT_R, S_jr1y = JOINT_R, S_jr2x = JOINT_R, S_jr2y = JOINT_R, S_jk0 = JOINT_R, S_jk1 = JOINT_R, S_jk2 = JOINT_R,
                          S_jk3 = JOINT_R, S_jb0 = JOINT_R, S_jb1 = JOINT_R, S_ja0 = JOINT_R, S_ja1 = JOINT_R, S_jrate = JOINT_R, S_jlim = JOINT_R;
     static constexpr int S_knx = CONTACT_R, S_kny = CONTACT_R, S_kr1x = CONTACT_R, S_kr1y = CONTACT_R, S_kr2x = CONTACT_R, S_kr2y = CONTACT_R,
                          S_knm = CONTACT_R, S_ktm = CONTACT_R, S_kbias = CONTACT_R, S_kjb = CONTACT_R, S_kjn = CONTACT_R, S_kjt = CONTACT_R, S_kmu = CONTACT_R;
     static constexpr int S_mn = 1, S_mp = 1, S_cj = 1, S_ncj = 1;
-    static constexpr int S_ov = 1, S_mcnt = 1, S_mhash = 1, S_koff = 1, S_kab = 1, S_kfirst = 1, S_chead = 1, S_nchead = 1, S_cmatched = 1,
-                         S_misc = 1, S_flag = 1, S_cnt = 1;
+    static constexpr int S_ov = OV_I, S_mcnt = OV_I, S_mhash = OV_I, S_koff = OV_I, S_kab = KI_I, S_kfirst = KI_I, S_chead = C_I, S_nchead = C_I,
+                         S_cmatched = C_I, S_misc = 1, S_flag = 1, S_cnt = 1;
     MGX_HD explicit WorkOff(const TmplHeader &h) {
         int nb = h.n_bodies, nv = h.n_verts, ns = h.n_shapes, nj = h.n_joints;
         int nk = h.max_contacts, nov = h.max_overlaps, nc = h.cache_slots;
@@ -169,8 +173,9 @@ struct WorkOff {
         n_p = o;
         o = 0;
         vx = o; vy = o + sbr; w = o + 2 * sbr; vbx = o + 3 * sbr; vby = o + 4 * sbr; wb = o + 5 * sbr; o += 6 * nb;
-        wx = o; o += nv; wy = o; o += nv; wnx = o; o += nv; wny = o; o += nv;
-        bbl = o; o += ns; bbb = o; o += ns; bbr = o; o += ns; bbt = o; o += ns;
+        const int sv = AOS_V ? 1 : nv, sbb = AOS_BB ? 1 : ns;
+        wx = o; wy = o + sv; wnx = o + 2 * sv; wny = o + 3 * sv; o += 4 * nv;
+        bbl = o; bbb = o + sbb; bbr = o + 2 * sbb; bbt = o + 3 * sbb; o += 4 * ns;
         jr1x = o; jr1y = o + sj; jr2x = o + 2 * sj; jr2y = o + 3 * sj; jk0 = o + 4 * sj; jk1 = o + 5 * sj; jk2 = o + 6 * sj; jk3 = o + 7 * sj;
         jb0 = o + 8 * sj; jb1 = o + 9 * sj; ja0 = o + 10 * sj; ja1 = o + 11 * sj; jrate = o + 12 * sj; jlim = o + 13 * sj; o += 15 * nj;
         knx = o; kny = o + sk; kr1x = o + 2 * sk; kr1y = o + 3 * sk; kr2x = o + 4 * sk; kr2y = o + 5 * sk; knm = o + 6 * sk; ktm = o + 7 * sk;
@@ -179,9 +184,10 @@ struct WorkOff {
         cj = o; o += nc * 4; ncj = o; o += nc * 4;
         n_r = o;
         o = 0;
-        ov = o; o += nov; mcnt = o; o += nov; mhash = o; o += nov; koff = o; o += nov;
-        kab = o; o += nk; kfirst = o; o += nk;
-        chead = o; o += nc; nchead = o; o += nc; cmatched = o; o += nc;
+        const int sov = AOS_OV ? 1 : nov, ski = AOS_KI ? 1 : nk, sc = AOS_C ? 1 : nc;
+        ov = o; mcnt = o + sov; mhash = o + 2 * sov; koff = o + 3 * sov; o += 4 * nov;
+        kab = o; kfirst = o + ski; o += 2 * nk;
+        chead = o; nchead = o + sc; cmatched = o + 2 * sc; o += 3 * nc;
         misc = o; o += M_N;
         flag = o; o += (h.n_pairs + 3) / 4;   // one byte per candidate pair
         cnt = o; o += 64;                      // per-lane counters for ordered compaction
