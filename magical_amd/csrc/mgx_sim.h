@@ -92,9 +92,9 @@ template <typename R, typename P> struct Env {
 #define E_R(field, i) e.wr[e.wo.field + (i) * WorkOff::S_##field]
 #define E_P(field, i) e.wp[e.wo.field + (i) * WorkOff::S_##field]
 #define E_I(field, i) e.wi[e.wo.field + (i) * WorkOff::S_##field]
-#define T_R(field, i) e.tr[e.to.field + (i)]
-#define T_P(field, i) e.tp[e.to.field + (i)]
-#define T_I(field, i) e.ti[e.to.field + (i)]
+#define T_R(field, i) e.tr[e.to.field + (i) * TmplOff::S_##field]
+#define T_P(field, i) e.tp[e.to.field + (i) * TmplOff::S_##field]
+#define T_I(field, i) e.ti[e.to.field + (i) * TmplOff::S_##field]
 
 // ---------------------------------------------------------------- phase: action decode + Robot.update
 // entities.py:148-190 (id = 9*[close] + 3*lr + ud), :439-457 (set_action), :459-479 (update)

@@ -60,7 +60,20 @@ enum ConstIdx {
 };
 
 // offsets into the template's int / real arrays
+#ifndef MGX_TAOS
+#define MGX_TAOS 15     // template records (all four together: -6 %): bit 0 body (minv iinv), 1 shape ints (kind body voff nv), 2 shape reals (r u), 3 local verts (x y nx ny)
+#endif
 struct TmplOff {
+    static constexpr bool A_B = MGX_TAOS & 1, A_SI = MGX_TAOS & 2, A_SR = MGX_TAOS & 4, A_V = MGX_TAOS & 8;
+    static constexpr int S_body_minv = A_B ? 2 : 1, S_body_iinv = A_B ? 2 : 1;
+    static constexpr int S_shape_kind = A_SI ? 4 : 1, S_shape_body = A_SI ? 4 : 1, S_shape_voff = A_SI ? 4 : 1, S_shape_nv = A_SI ? 4 : 1;
+    static constexpr int S_shape_r = A_SR ? 2 : 1, S_shape_u = A_SR ? 2 : 1;
+    static constexpr int S_lvx = A_V ? 4 : 1, S_lvy = A_V ? 4 : 1, S_lnx = A_V ? 4 : 1, S_lny = A_V ? 4 : 1;
+    // every other field is a plain array
+    static constexpr int S_body_type = 1, S_body_parent = 1, S_body_ent = 1, S_joint_kind = 1, S_joint_a = 1, S_joint_b = 1, S_joint_acc = 1,
+                         S_joint_pv = 1, S_pair = 1, S_state_map = 1, S_prim_i = 1, S_pv_prim = 1, S_body_prow = 1, S_island_j = 1,
+                         S_body_init = 1, S_body_anchor = 1, S_joint_p = 1, S_prim_r = 1, S_pvx = 1, S_pvy = 1, S_consts = 1,
+                         S_p_body_init = 1, S_p_body_anchor = 1, S_p_body_aoff = 1, S_p_joint = 1, S_p_dt = 1;
     // ints
     int body_type, body_parent, body_ent, shape_kind, shape_body, shape_voff, shape_nv;
     int joint_kind, joint_a, joint_b, joint_acc, joint_pv, pair, state_map, prim_i, pv_prim, body_prow, island_j, n_i;
@@ -74,10 +87,7 @@ struct TmplOff {
         body_type = o; o += h.n_bodies;
         body_parent = o; o += h.n_bodies;
         body_ent = o; o += h.n_bodies;        // entity of the body (per-env reset poses), -1 for the static body
-        shape_kind = o; o += h.n_shapes;
-        shape_body = o; o += h.n_shapes;
-        shape_voff = o; o += h.n_shapes;
-        shape_nv = o; o += h.n_shapes;
+        { const int d = A_SI ? 1 : h.n_shapes; shape_kind = o; shape_body = o + d; shape_voff = o + 2 * d; shape_nv = o + 3 * d; o += 4 * h.n_shapes; }
         joint_kind = o; o += h.n_joints;
         joint_a = o; o += h.n_joints;
         joint_b = o; o += h.n_joints;
@@ -91,16 +101,11 @@ struct TmplOff {
         island_j = o; o += h.n_islands;
         n_i = o;
         o = 0;
-        body_minv = o; o += h.n_bodies;
-        body_iinv = o; o += h.n_bodies;
+        { const int d = A_B ? 1 : h.n_bodies; body_minv = o; body_iinv = o + d; o += 2 * h.n_bodies; }
         body_init = o; o += h.n_bodies * 3;
         body_anchor = o; o += h.n_bodies * 2;
-        shape_r = o; o += h.n_shapes;
-        shape_u = o; o += h.n_shapes;
-        lvx = o; o += h.n_verts;
-        lvy = o; o += h.n_verts;
-        lnx = o; o += h.n_verts;
-        lny = o; o += h.n_verts;
+        { const int d = A_SR ? 1 : h.n_shapes; shape_r = o; shape_u = o + d; o += 2 * h.n_shapes; }
+        { const int d = A_V ? 1 : h.n_verts; lvx = o; lvy = o + d; lnx = o + 2 * d; lny = o + 3 * d; o += 4 * h.n_verts; }
         joint_p = o; o += h.n_joints * JOINT_PARAMS;
         prim_r = o; o += h.n_prims * PRIM_RWORDS;
         pvx = o; o += h.n_pverts;

@@ -598,7 +598,7 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
         const BodyDef &B = bodies[b];
         iw[o.body_type + b] = B.type; iw[o.body_parent + b] = B.parent; iw[o.body_ent + b] = B.ent;
         pw[o.p_body_aoff + b] = B.aoff;
-        rw[o.body_minv + b] = B.m_inv; rw[o.body_iinv + b] = B.i_inv;
+        rw[o.body_minv + (b) * TmplOff::S_body_minv] = B.m_inv; rw[o.body_iinv + (b) * TmplOff::S_body_iinv] = B.i_inv;
         rw[o.body_init + 3 * b] = B.x; rw[o.body_init + 3 * b + 1] = B.y; rw[o.body_init + 3 * b + 2] = B.a;
         rw[o.body_anchor + 2 * b] = B.ax; rw[o.body_anchor + 2 * b + 1] = B.ay;
         pw[o.p_body_init + 3 * b] = B.x; pw[o.p_body_init + 3 * b + 1] = B.y; pw[o.p_body_init + 3 * b + 2] = B.a;
@@ -608,26 +608,26 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
     for (int s = 0; s < h.n_shapes; s++) {
         const ShapeDef &S = shapes[s];
         int nv = (S.kind == SH_CIRCLE) ? 1 : (int)S.verts.size();
-        iw[o.shape_kind + s] = S.kind; iw[o.shape_body + s] = S.body;
-        iw[o.shape_voff + s] = voff; iw[o.shape_nv + s] = nv;
-        rw[o.shape_r + s] = S.radius; rw[o.shape_u + s] = S.friction;
+        iw[o.shape_kind + (s) * TmplOff::S_shape_kind] = S.kind; iw[o.shape_body + (s) * TmplOff::S_shape_body] = S.body;
+        iw[o.shape_voff + (s) * TmplOff::S_shape_voff] = voff; iw[o.shape_nv + (s) * TmplOff::S_shape_nv] = nv;
+        rw[o.shape_r + (s) * TmplOff::S_shape_r] = S.radius; rw[o.shape_u + (s) * TmplOff::S_shape_u] = S.friction;
         if (S.kind == SH_CIRCLE) {
-            rw[o.lvx + voff] = 0; rw[o.lvy + voff] = 0;
+            rw[o.lvx + (voff) * TmplOff::S_lvx] = 0; rw[o.lvy + (voff) * TmplOff::S_lvy] = 0;
         } else {
-            for (int i = 0; i < nv; i++) { rw[o.lvx + voff + i] = S.verts[i].x; rw[o.lvy + voff + i] = S.verts[i].y; }
+            for (int i = 0; i < nv; i++) { rw[o.lvx + (voff + i) * TmplOff::S_lvx] = S.verts[i].x; rw[o.lvy + (voff + i) * TmplOff::S_lvy] = S.verts[i].y; }
             if (S.kind == SH_SEGMENT) {
                 // a segment is treated as a 2-vertex polygon: plane 1 = edge (a -> b) carries
                 // cpSegmentShape's n = rperp(normalize(b - a)), plane 0 = edge (b -> a) carries -n
                 double dx = S.verts[1].x - S.verts[0].x, dy = S.verts[1].y - S.verts[0].y;
                 double len = std::sqrt(dx * dx + dy * dy);
-                rw[o.lnx + voff + 1] = dy / len; rw[o.lny + voff + 1] = -dx / len;
-                rw[o.lnx + voff] = -dy / len; rw[o.lny + voff] = dx / len;
+                rw[o.lnx + (voff + 1) * TmplOff::S_lnx] = dy / len; rw[o.lny + (voff + 1) * TmplOff::S_lny] = -dx / len;
+                rw[o.lnx + (voff) * TmplOff::S_lnx] = -dy / len; rw[o.lny + (voff) * TmplOff::S_lny] = dx / len;
             } else {
                 // cpPolyShape SetVerts: plane i = edge (i-1 -> i), outward normal rperp(b - a)/|b - a|
                 for (int i = 0; i < nv; i++) {
                     Vec2 a = S.verts[(i - 1 + nv) % nv], b = S.verts[i];
                     double ex = b.x - a.x, ey = b.y - a.y, len = std::sqrt(ex * ex + ey * ey);
-                    rw[o.lnx + voff + i] = ey / len; rw[o.lny + voff + i] = -ex / len;
+                    rw[o.lnx + (voff + i) * TmplOff::S_lnx] = ey / len; rw[o.lny + (voff + i) * TmplOff::S_lny] = -ex / len;
                 }
             }
         }
