@@ -32,12 +32,19 @@ struct RasterOff {
     // fp32 classification items (8 words each) in FRONT-TO-BACK prim order + per-prim (start | count << 16)
     int items, pitem, n_items;
     int n_i;
+#ifndef MGX_RAOS
+#define MGX_RAOS 1      // records: bit 0 per draw-list vertex (7 doubles: -1.6 %), 1 per primitive (5: slower), 2 per body (5: no change)
+#endif
+    static constexpr bool A_V = MGX_RAOS & 1, A_P = MGX_RAOS & 2, A_B = MGX_RAOS & 4;
+    static constexpr int S_bx = A_B ? 5 : 1, S_by = S_bx, S_ba = S_bx, S_bc = S_bx, S_bs = S_bx;
+    static constexpr int S_svx = A_V ? 7 : 1, S_svy = S_svx, S_ea = S_svx, S_eb = S_svx, S_ec = S_svx, S_elen = S_svx, S_earc = S_svx;
+    static constexpr int S_pcx = A_P ? 5 : 1, S_pcy = S_pcx, S_prad = S_pcx, S_papo = S_pcx, S_pphi = S_pcx;
+    static constexpr int S_prgb = 1, S_items = 1, S_pitem = 1;
     MGX_HD explicit RasterOff(const TmplHeader &h) {
         int o = 0;
-        bx = o; o += h.n_bodies; by = o; o += h.n_bodies; ba = o; o += h.n_bodies; bc = o; o += h.n_bodies; bs = o; o += h.n_bodies;
-        svx = o; o += h.n_pverts; svy = o; o += h.n_pverts; ea = o; o += h.n_pverts; eb = o; o += h.n_pverts; ec = o; o += h.n_pverts;
-        elen = o; o += h.n_pverts; earc = o; o += h.n_pverts;
-        pcx = o; o += h.n_prims; pcy = o; o += h.n_prims; prad = o; o += h.n_prims; papo = o; o += h.n_prims; pphi = o; o += h.n_prims;
+        { const int d = A_B ? 1 : h.n_bodies; bx = o; by = o + d; ba = o + 2 * d; bc = o + 3 * d; bs = o + 4 * d; o += 5 * h.n_bodies; }
+        { const int d = A_V ? 1 : h.n_pverts; svx = o; svy = o + d; ea = o + 2 * d; eb = o + 3 * d; ec = o + 4 * d; elen = o + 5 * d; earc = o + 6 * d; o += 7 * h.n_pverts; }
+        { const int d = A_P ? 1 : h.n_prims; pcx = o; pcy = o + d; prad = o + 2 * d; papo = o + 3 * d; pphi = o + 4 * d; o += 5 * h.n_prims; }
         n_d = o;
         o = 0;
         prgb = o; o += h.n_prims;
@@ -75,9 +82,8 @@ struct Raster {
     MGX_HD double pvy(int v) const { return tq[h->n_prims * PRIM_RWORDS + h->n_pverts + v]; }
 };
 
-#define RD(field, k) rs.d[rs.ro.field + (k)]
-#define RI(field, k) rs.i[rs.ro.field + (k)]
-#define RF(field, k) reinterpret_cast<float *>(rs.i)[rs.ro.field + (k)]
+#define RD(field, k) rs.d[rs.ro.field + (k) * RasterOff::S_##field]
+#define RI(field, k) rs.i[rs.ro.field + (k) * RasterOff::S_##field]
 
 MGX_HD double rz_floor(double x) { return floor(x); }
 
