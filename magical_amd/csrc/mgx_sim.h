@@ -724,8 +724,8 @@ template <typename R> MGX_HD void reg_apply_joint(int kind, R *f, R lim, R ma, R
         avx -= jx * ma; avy -= jy * ma; aw -= ia * (f[0] * jy - f[1] * jx);
         bvx += jx * mb; bvy += jy * mb; bw += ib * (f[2] * jy - f[3] * jx);
     } break;
-    case J_GEAR: {    // f: imass bias acc ratio
-        R ratio = f[3], ratio_inv = R(1) / ratio;
+    case J_GEAR: {    // f: imass bias acc ratio 1/ratio
+        R ratio = f[3], ratio_inv = f[4];
         R wr = bw * ratio - aw;
         R jj = (f[1] - wr) * f[0];
         R jold = f[2];
@@ -898,7 +898,7 @@ template <typename R, typename P> MGX_HD void solve_begin(Env<R, P> &e, SolveCtx
                     f[4] = E_R(jk0, jj); f[5] = E_R(jk1, jj); f[6] = E_R(jk2, jj); f[7] = E_R(jb0, jj); f[8] = E_R(ja0, jj);
                 }
             } else if (kind == J_GEAR) {
-                f[0] = p[0]; f[1] = E_R(jb0, jj); f[2] = E_R(ja0, jj); f[3] = p[5];
+                f[0] = p[0]; f[1] = E_R(jb0, jj); f[2] = E_R(ja0, jj); f[3] = p[5]; f[4] = R(1) / p[5];      // 1 / ratio once per substep, not per iteration
             } else if (kind == J_SPRING) {
                 f[0] = p[0]; f[1] = p[6]; f[2] = R(0);
                 // spring torque, applied right here exactly as cpDampedRotarySpring's preStep does
