@@ -111,6 +111,7 @@ def main():
     env.set_timing(8)       # HIP events around every 8th launch of each kernel inside the timed region
     last_score = torch.zeros(n, dtype=torch.float64, device=device)      # per-env result of the rollout
     n_eps = 0
+    gather_rollout_results(last_score, n * world)      # warm-up of the collective (RCCL sets its channels up on first use)
     barrier()
     t0 = time.perf_counter()
     for s in range(W, W + K):

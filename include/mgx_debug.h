@@ -22,6 +22,9 @@ int mgx_engine_debug_raster_stop(mgx_engine *e, int phase);
 /* k_step, -DMGX_STEP_PROBE builds only: DEVICE u64 [workgroups][32] shader cycles per phase; NULL = off.
  * tools/step_phase_probe.py */
 int mgx_engine_debug_step_clocks(mgx_engine *e, void *buf);
+/* k_raster: force the occupancy variant (3, 4 or 5 workgroups per CU = VGPR caps 168 / 128 / 96) instead of the one the
+ * world's LDS footprint selects; the world must still fit that many workgroups.  tools/raster_probe.py */
+int mgx_engine_debug_raster_waves(mgx_engine *e, int n);
 /* k_step: override the solver iteration count (-1 = the reference's 10).  tools/step_probe.py */
 int mgx_engine_debug_iterations(mgx_engine *e, int it);
 

@@ -573,6 +573,7 @@ int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_
     HIP_OK(hipGetLastError());
     return MGX_OK;
 }
+int mgx_engine_debug_raster_waves(mgx_engine *e, int n) { if (e && n >= 3 && n <= 5) e->raster_waves = n; return MGX_OK; }
 int mgx_engine_debug_raster_ecap(mgx_engine *e, int n) { if (e) e->rdev.ecap = n < 1 ? 1 : (n > ECAP ? ECAP : n); return MGX_OK; }
 int mgx_engine_debug_raster_qcap(mgx_engine *e, int n) { if (e) e->rdev.qcap = n < 1 ? 1 : (n > QCAP ? QCAP : n); return MGX_OK; }
 int mgx_engine_debug_raster_stop(mgx_engine *e, int phase) { if (e) e->rdev.dbg_stop = phase; return MGX_OK; }

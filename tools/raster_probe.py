@@ -16,6 +16,8 @@ task = sys.argv[1] if len(sys.argv) > 1 else 'MoveToCorner-Demo-v0'
 N = 4096
 env = magical_amd.make(task, n_envs=N, device='cuda:0')
 env.reset()
+if len(sys.argv) > 2:
+    env._lib.mgx_engine_debug_raster_waves(env._engine, int(sys.argv[2]))
 print('LDS per workgroup: k_raster %d B, k_step %d B' % (env._lib.mgx_engine_lds_bytes(env._engine, 1), env._lib.mgx_engine_lds_bytes(env._engine, 0)))
 frame = torch.zeros((N, 96, 96, 3), dtype=torch.uint8, device='cuda:0')
 stack = torch.zeros((N, 96, 96, 12), dtype=torch.uint8, device='cuda:0')
