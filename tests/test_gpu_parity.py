@@ -822,3 +822,24 @@ def test_checkpoint_resume(name):
         assert all(torch.equal(ow[k], og[k]) for k in ow) and np.array_equal(dw, dg) and np.array_equal(sw, sg)
     assert torch.equal(a.state_p, b.state_p) and torch.equal(a.state_f, b.state_f)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize('name', ['MatchRegions-Demo-LoRes4E-v0', 'ClusterShape-TestAll-LoRes4E-v0'])
+def test_native_render_box_filtered_equals_lores_observation(name):
+    """render() of one env at the reference's native 384x384 (point samples, k_raster_native), reduced with the 4x4 box
+    filter of the demo preprocessing (saved_trajectories.area_resize_4x = cv2 INTER_AREA), equals the newest frame of that
+    env's LoRes4E observation byte for byte -- also when every env has its own world."""
+    from magical_amd.saved_trajectories import area_resize_4x
+    n = 6
+    env = _make(name, n)
+    env.seed(21)
+    obs = env.reset()
+    tape = _tape(9, 4, n)
+    for s in range(4):
+        obs, _, _, _ = env.step(tape[s])
+    obs = obs.cpu().numpy()
+    for k in range(n):
+        full = env.render(env=k)['ego']
+        assert full.shape == (384, 384, 3)
+        assert np.array_equal(area_resize_4x(full), obs[k, :, :, 9:12]), (name, k)
+    env.close()
