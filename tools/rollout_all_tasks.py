@@ -44,6 +44,7 @@ def main():
         # the action tape of the whole job, every rank takes its slice (same results for any number of GPUs)
         tape = np.random.RandomState(args.seed).randint(0, 18, size=(T, args.envs)).astype(np.int32)[:, lo:hi]
         tape = torch.as_tensor(tape, device=env.device)
+        env.seed(args.seed + lo)      # env k of the job draws from RandomState(seed + k) whatever the number of GPUs
         env.reset()
         if world > 1:
             dist.barrier()
