@@ -98,7 +98,10 @@ __global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *_
 #define SYNC(stmt) { constexpr int pid_ = probe_phase_id(#stmt); const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); \
                      stmt; __syncthreads(); pacc[pid_] += __builtin_amdgcn_s_memtime() - t0_; }
 #else
-#define SYNC(stmt) stmt; __syncthreads();
+// The workgroup is ONE wavefront: its LDS operations execute in program order, so what a phase boundary needs is only that
+// the compiler keeps the phases' LDS accesses in order -- a wavefront-scope fence, not s_waitcnt + s_barrier.
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define SYNC(stmt) stmt; WAVE_SYNC();
 #endif
     SYNC(ph_init_work(e, lane, nl))
     SYNC(ph_load_state(e, sp, sf, si, stride, env, lane, nl))
