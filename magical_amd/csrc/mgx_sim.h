@@ -708,11 +708,18 @@ template <typename R> struct SolveCtx {
     int has_contacts;
 };
 
-template <typename R> MGX_HD void reg_apply_joint(int kind, R *f, R lim, R ma, R ia, R mb, R ib,
-                                                  R &avx, R &avy, R &aw, R &bvx, R &bvy, R &bw) {
+// ZA / ZB: the joint's anchor on body a / b is the body origin (r = 0, so the r x j terms vanish); KA: body a is the
+// kinematic control body (inverse mass and inertia 0: impulses leave it unchanged).  What is skipped is x - 0 * y and
+// x + 0 * y on finite values, i.e. x: Robot.setup's pivot / gear to the control body and the finger pins (entities.py:
+// 255-263,334-341) have exactly these shapes.
+template <typename R, bool ZA = false, bool ZB = false, bool KA = false>
+MGX_HD void reg_apply_joint(int kind, R *f, R lim, R ma, R ia, R mb, R ib,
+                            R &avx, R &avy, R &aw, R &bvx, R &bvy, R &bw) {
     switch (kind) {
     case J_PIVOT: {   // f: r1x r1y r2x r2y k0 k1 k2 k3 bias0 bias1 acc0 acc1
-        R vrx = (bvx - f[3] * bw) - (avx - f[1] * aw), vry = (bvy + f[2] * bw) - (avy + f[0] * aw);
+        R vbx_ = ZB ? bvx : bvx - f[3] * bw, vby_ = ZB ? bvy : bvy + f[2] * bw;
+        R vax_ = ZA ? avx : avx - f[1] * aw, vay_ = ZA ? avy : avy + f[0] * aw;
+        R vrx = vbx_ - vax_, vry = vby_ - vay_;
         R dx = f[8] - vrx, dy = f[9] - vry;
         R jx = dx * f[4] + dy * f[5], jy = dx * f[6] + dy * f[7];
         R ox = f[10], oy = f[11];
@@ -721,8 +728,8 @@ template <typename R> MGX_HD void reg_apply_joint(int kind, R *f, R lim, R ma, R
         if (l2 > lim * lim) { R sc = lim / (r_sqrt(l2) + r_tiny<R>()); nxv *= sc; nyv *= sc; }
         f[10] = nxv; f[11] = nyv;
         jx = nxv - ox; jy = nyv - oy;
-        avx -= jx * ma; avy -= jy * ma; aw -= ia * (f[0] * jy - f[1] * jx);
-        bvx += jx * mb; bvy += jy * mb; bw += ib * (f[2] * jy - f[3] * jx);
+        if (!KA) { avx -= jx * ma; avy -= jy * ma; if (!ZA) aw -= ia * (f[0] * jy - f[1] * jx); }
+        bvx += jx * mb; bvy += jy * mb; if (!ZB) bw += ib * (f[2] * jy - f[3] * jx);
     } break;
     case J_GEAR: {    // f: imass bias acc ratio 1/ratio
         R ratio = f[3], ratio_inv = f[4];
@@ -731,7 +738,8 @@ template <typename R> MGX_HD void reg_apply_joint(int kind, R *f, R lim, R ma, R
         R jold = f[2];
         R jn = r_clamp(jold + jj, -lim, lim);
         f[2] = jn; jj = jn - jold;
-        aw = aw - jj * ia * ratio_inv; bw = bw + jj * ib;
+        if (!KA) aw = aw - jj * ia * ratio_inv;
+        bw = bw + jj * ib;
     } break;
     case J_SPRING: {  // f: imass w_coef target_wrn
         R wrn = aw - bw;
@@ -741,7 +749,7 @@ template <typename R> MGX_HD void reg_apply_joint(int kind, R *f, R lim, R ma, R
         aw = aw + j_damp * ia; bw = bw - j_damp * ib;
     } break;
     case J_PIN: {     // f: r1x r1y r2x r2y nx ny nmass bias acc
-        R vrx = (bvx - f[3] * bw) - (avx - f[1] * aw), vry = (bvy + f[2] * bw) - (avy + f[0] * aw);
+        R vrx = (ZB ? bvx : bvx - f[3] * bw) - (avx - f[1] * aw), vry = (ZB ? bvy : bvy + f[2] * bw) - (avy + f[0] * aw);
         R vrn = vrx * f[4] + vry * f[5];
         R jn = (f[7] - vrn) * f[6];
         R jold = f[8];
@@ -749,7 +757,7 @@ template <typename R> MGX_HD void reg_apply_joint(int kind, R *f, R lim, R ma, R
         f[8] = jnew; jn = jnew - jold;
         R jx = f[4] * jn, jy = f[5] * jn;
         avx -= jx * ma; avy -= jy * ma; aw -= ia * (f[0] * jy - f[1] * jx);
-        bvx += jx * mb; bvy += jy * mb; bw += ib * (f[2] * jy - f[3] * jx);
+        bvx += jx * mb; bvy += jy * mb; if (!ZB) bw += ib * (f[2] * jy - f[3] * jx);
     } break;
     case J_LIMIT: {   // f: imass bias acc
         R bias = f[1];
@@ -978,12 +986,14 @@ template <typename R, typename P> MGX_HD void solve_iter_joints(Env<R, P> &e, So
             if (!c.has_contacts) { /* LDS copy of block velocities is current: blocks never enter the robot's registers */ }
             for (int k = 0; k < e.h->n_islands; k++) { int jp = T_I(island_j, k); joint_apply_impulse(e, jp); joint_apply_impulse(e, jp + 1); }
         }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int j = 0; j < RI_JOINTS; j++)
-            reg_apply_joint<R>(RI_KIND(j), c.f[j], c.lim[j], c.minv[RI_SA(j)], c.iinv[RI_SA(j)], c.minv[RI_SB(j)], c.iinv[RI_SB(j)],
-                               c.vx[RI_SA(j)], c.vy[RI_SA(j)], c.w[RI_SA(j)], c.vx[RI_SB(j)], c.vy[RI_SB(j)], c.w[RI_SB(j)]);
+#define MGX_RI_APPLY(j, ZA, ZB, KA) reg_apply_joint<R, ZA, ZB, KA>(RI_KIND(j), c.f[j], c.lim[j], c.minv[RI_SA(j)], c.iinv[RI_SA(j)], \
+            c.minv[RI_SB(j)], c.iinv[RI_SB(j)], c.vx[RI_SA(j)], c.vy[RI_SA(j)], c.w[RI_SA(j)], c.vx[RI_SB(j)], c.vy[RI_SB(j)], c.w[RI_SB(j)])
+        // Robot.setup order: pivot + gear from the kinematic control body (anchors at both origins), two eye springs, then per
+        // finger {pin (anchored at the finger's origin), limit, motor}
+        MGX_RI_APPLY(0, true, true, true); MGX_RI_APPLY(1, false, false, true); MGX_RI_APPLY(2, false, false, false); MGX_RI_APPLY(3, false, false, false);
+        MGX_RI_APPLY(4, false, true, false); MGX_RI_APPLY(5, false, false, false); MGX_RI_APPLY(6, false, false, false);
+        MGX_RI_APPLY(7, false, true, false); MGX_RI_APPLY(8, false, false, false); MGX_RI_APPLY(9, false, false, false);
+#undef MGX_RI_APPLY
     }
     bi_iterate(c);
 }
