@@ -48,8 +48,14 @@ constexpr int probe_phase_id(const char *s) {
     return 19;
 }
 #endif
+// One env per wavefront (L = 64, the per-env-world mode) launches as many waves as envs: capping its registers for
+// MGX_L64_WAVES waves per SIMD keeps more of them resident (the narrower groups run one wave per SIMD at 4096 envs and are
+// fastest with all the registers)
+#ifndef MGX_L64_WAVES
+#define MGX_L64_WAVES 2
+#endif
 template <typename R, typename P, int L>
-__global__ __launch_bounds__(64) void k_step(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
+__global__ __launch_bounds__(64, (L == 64 ? MGX_L64_WAVES : 1)) void k_step(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
                                              const int32_t *__restrict__ actions, uint8_t *__restrict__ done,
                                              int n_envs, int n_sub, int count_step, int iterations) {
     extern __shared__ __align__(16) uint32_t lds[];
