@@ -337,12 +337,22 @@ static void make_blobs_t(const World &w, WorldBlobs &b) {
     {
         w.serialise(b.h, iw, rw, pw);
         TmplOff o(b.h);
-        const int off_i = HDR_WORDS, off_q = raster_off_q(b.h, off_i), nq = b.h.n_prims * PRIM_RWORDS + 2 * b.h.n_pverts;
-        b.raster.assign(raster_blob_words(b.h, off_i), 0);
-        std::memcpy(b.raster.data(), &b.h, sizeof(TmplHeader));
-        std::memcpy(b.raster.data() + off_i, iw.data(), iw.size() * 4);
+        // the rasteriser's copy keeps only what it reads: body tables, the draw list and the bodies' pose rows -- not the
+        // shapes, joints, candidate pairs (hundreds to thousands of words in worlds with stars) and state map of the physics
+        TmplHeader hr = b.h;
+        hr.n_shapes = hr.n_verts = hr.n_joints = hr.n_pairs = hr.n_state = hr.n_islands = 0;
+        TmplOff orr(hr);
+        hr.n_words_i = orr.n_i;
+        std::vector<int32_t> ir(orr.n_i, 0);
+        auto keep = [&](int from, int to, int n) { std::memcpy(ir.data() + to, iw.data() + from, (size_t)n * 4); };
+        keep(o.body_type, orr.body_type, b.h.n_bodies); keep(o.body_parent, orr.body_parent, b.h.n_bodies); keep(o.body_ent, orr.body_ent, b.h.n_bodies);
+        keep(o.prim_i, orr.prim_i, b.h.n_prims * PRIM_IWORDS); keep(o.pv_prim, orr.pv_prim, b.h.n_pverts); keep(o.body_prow, orr.body_prow, 3 * b.h.n_bodies);
+        const int off_i = HDR_WORDS, off_q = raster_off_q(hr, off_i), nq = b.h.n_prims * PRIM_RWORDS + 2 * b.h.n_pverts;
+        b.raster.assign(raster_blob_words(hr, off_i), 0);
+        std::memcpy(b.raster.data(), &hr, sizeof(TmplHeader));
+        std::memcpy(b.raster.data() + off_i, ir.data(), ir.size() * 4);
         std::memcpy(b.raster.data() + off_q, rw.data() + o.prim_r, (size_t)nq * 8);
-        RasterOff ro(b.h);
+        RasterOff ro(hr);
         b.raster_scratch_d = ro.n_d;
         b.raster_off_tiles = even(2 * ro.n_d + ro.n_i);
     }
