@@ -44,7 +44,7 @@ struct WorldBlobs {
     std::vector<uint32_t> raster;    // [header][ints][prim reals + prim verts, fp64]
     int step_env_stride = 0;         // LDS words of the per-env working set
     int step_off_r = 0, step_off_p = 0, step_env_off_r = 0, step_env_off_i = 0;
-    int raster_scratch_d = 0, raster_off_tiles = 0;
+    int raster_scratch_d = 0, raster_n_i = 0;      // doubles / ints of the rasteriser's per-env scratch
 };
 
 struct mgx_engine {
@@ -64,7 +64,7 @@ struct mgx_engine {
     std::unordered_map<std::string, std::weak_ptr<World>> world_by_sig;  // live variants, shared between envs
     int step_stride = 0, raster_stride = 0;                             // words per env in the two blob tables
     // footprints of the envs' current worlds: the launch geometry follows their maxima, not the capacity world's
-    std::vector<int> fp_step_words, fp_env_stride, fp_raster_words, fp_scratch_d, fp_off_tiles;
+    std::vector<int> fp_step_words, fp_env_stride, fp_raster_words, fp_scratch_d, fp_raster_n_i;
     uint32_t *d_stage = nullptr; size_t stage_words = 0;                 // upload staging (device)
     uint32_t *h_stage = nullptr; size_t h_stage_words = 0;               // upload staging (pinned host memory)
     int32_t *d_stage_idx = nullptr; size_t stage_idx_n = 0;       // (env, offsets, sizes) rows of an upload
@@ -354,7 +354,7 @@ static void make_blobs_t(const World &w, WorldBlobs &b) {
         std::memcpy(b.raster.data() + off_q, rw.data() + o.prim_r, (size_t)nq * 8);
         RasterOff ro(hr);
         b.raster_scratch_d = ro.n_d;
-        b.raster_off_tiles = even(2 * ro.n_d + ro.n_i);
+        b.raster_n_i = ro.n_i;
     }
 }
 static void make_blobs(int dtype, const World &w, WorldBlobs &b) {
@@ -365,7 +365,10 @@ static void make_blobs(int dtype, const World &w, WorldBlobs &b) {
 
 static size_t step_lds_bytes(const mgx_engine *e, int L) { return (size_t)(e->tdev.lds_tmpl_words + (64 / L) * e->tdev.env_stride_words) * 4; }
 // size the launch geometry (lanes per env, LDS, raster variant) for blobs of the given sizes
-static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, int raster_words, int scratch_d, int off_tiles) {
+// (scratch_d and raster_n_i may be maxima taken from different worlds: the int region starts after the LARGEST double region,
+// so the tile / queue area has to start after the largest double region plus the largest int region)
+static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, int raster_words, int scratch_d, int raster_n_i) {
+    const int off_tiles = even(2 * scratch_d + raster_n_i);
     e->tdev.off_i = HDR_WORDS; e->tdev.lds_tmpl_words = even(step_words); e->tdev.env_stride_words = step_env_stride;
     // lanes per env: caller's choice, else the widest group (most narrowphase parallelism) that still lets
     // two workgroups share a CU's LDS; worlds too big for that take the narrowest group that fits at all
@@ -456,7 +459,7 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
     make_blobs(dtype, e->w, b);
     e->h = b.h;
     e->rows_p = state_rows_p(b.h); e->rows_f = state_rows_f(b.h); e->rows_i = state_rows_i(b.h);
-    int rc = configure_launch(e, (int)b.step.size(), b.step_env_stride, (int)b.raster.size(), b.raster_scratch_d, b.raster_off_tiles);
+    int rc = configure_launch(e, (int)b.step.size(), b.step_env_stride, (int)b.raster.size(), b.raster_scratch_d, b.raster_n_i);
     if (rc) { delete e; return rc; }
     int32_t pal[12];
     for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) pal[4 * r + c] = palette_rgb(c, r);
@@ -629,7 +632,7 @@ int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world)
     make_blobs(e->dtype, capacity_world->w, cb);
     make_blobs(e->dtype, e->w, db);
     if (db.step.size() > cb.step.size() || db.raster.size() > cb.raster.size() || db.step_env_stride > cb.step_env_stride ||
-        db.raster_scratch_d > cb.raster_scratch_d || db.raster_off_tiles > cb.raster_off_tiles)
+        db.raster_scratch_d > cb.raster_scratch_d || db.raster_n_i > cb.raster_n_i)
         return fail(MGX_ERR_ARG, "the capacity world must be at least as large as the engine's world");
     if (cb.h.n_prims > 64) return fail(MGX_ERR_CAPACITY, "draw list longer than 64 primitives");
     const int step_stride = even((int)cb.step.size()), raster_stride = even((int)cb.raster.size());
@@ -648,14 +651,14 @@ int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world)
     e->rdev.words = tab_r; e->rdev.tmpl_stride_words = raster_stride;
     e->env_world.assign(e->n_envs, std::shared_ptr<World>());
     {   // the capacity world itself must be launchable
-        int rc = configure_launch(e, (int)cb.step.size(), cb.step_env_stride, (int)cb.raster.size(), cb.raster_scratch_d, cb.raster_off_tiles);
+        int rc = configure_launch(e, (int)cb.step.size(), cb.step_env_stride, (int)cb.raster.size(), cb.raster_scratch_d, cb.raster_n_i);
         if (rc) return rc;
         if (e->lds_raster > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "capacity world's draw list does not fit LDS");
     }
     e->fp_step_words.assign(e->n_envs, (int)db.step.size()); e->fp_env_stride.assign(e->n_envs, db.step_env_stride);
     e->fp_raster_words.assign(e->n_envs, (int)db.raster.size()); e->fp_scratch_d.assign(e->n_envs, db.raster_scratch_d);
-    e->fp_off_tiles.assign(e->n_envs, db.raster_off_tiles);
-    int rc = configure_launch(e, (int)db.step.size(), db.step_env_stride, (int)db.raster.size(), db.raster_scratch_d, db.raster_off_tiles);
+    e->fp_raster_n_i.assign(e->n_envs, db.raster_n_i);
+    int rc = configure_launch(e, (int)db.step.size(), db.step_env_stride, (int)db.raster.size(), db.raster_scratch_d, db.raster_n_i);
     if (rc) return rc;
     e->rows_p = std::max(e->rows_p, state_rows_p(cb.h)); e->rows_f = std::max(e->rows_f, state_rows_f(cb.h)); e->rows_i = std::max(e->rows_i, state_rows_i(cb.h));
     return MGX_OK;
@@ -782,11 +785,11 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         retired[k] = std::move(e->env_world[env]);
         e->env_world[env] = uniq[which[k]].world;
         e->fp_step_words[env] = (int)B.step.size(); e->fp_env_stride[env] = B.step_env_stride;
-        e->fp_raster_words[env] = (int)B.raster.size(); e->fp_scratch_d[env] = B.raster_scratch_d; e->fp_off_tiles[env] = B.raster_off_tiles;
+        e->fp_raster_words[env] = (int)B.raster.size(); e->fp_scratch_d[env] = B.raster_scratch_d; e->fp_raster_n_i[env] = B.raster_n_i;
     }
     {
         auto mx = [](const std::vector<int> &v) { return *std::max_element(v.begin(), v.end()); };
-        int rc = configure_launch(e, mx(e->fp_step_words), mx(e->fp_env_stride), mx(e->fp_raster_words), mx(e->fp_scratch_d), mx(e->fp_off_tiles));
+        int rc = configure_launch(e, mx(e->fp_step_words), mx(e->fp_env_stride), mx(e->fp_raster_words), mx(e->fp_scratch_d), mx(e->fp_raster_n_i));
         if (rc) return rc;
     }
     for (auto &U : uniq) e->world_by_sig[U.sig] = U.world;
