@@ -768,7 +768,8 @@ def test_per_env_worlds_full_size_properties_4096():
     observations through two resets), so an env does not depend on what the rest of the batch holds or on how the
     templates were uploaded; two equally seeded engines agree; nothing overflows, nothing escapes the arena."""
     import torch
-    n, m, k0, seed = 4096, 32, 1500, 77
+    import os
+    n, m, k0, seed = 4096, 32, 1500, int(os.environ.get('MGX_TEST_SEED', '77'))
     name = 'ClusterColour-TestAll-LoRes4E-v0'
     big, big2, small = _make(name, n), _make(name, n), _make(name, m)
     big.seed(seed); big2.seed(seed); small.seed(seed + k0)
