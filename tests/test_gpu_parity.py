@@ -295,7 +295,7 @@ def test_rand_dynamics_matches_oracle(task):
     each reset (env k seeded with seed + k); the fp64 engine with those per-env force limits tracks an oracle env built
     with the same draws, across an auto-reset, and differs from the default dynamics."""
     from oracle.env_ref import RefEnv
-    n, ep, seed = 3, 4, 1234
+    n, ep, seed = 3, 4, int(__import__('os').environ.get('MGX_TEST_SEED', '1234'))
     env = _make(f'{task}-TestDynamics-v0', n, dtype='f64', max_episode_steps=ep)
     assert env.rand_dynamics
     env.seed(seed)
@@ -344,7 +344,7 @@ def test_test_colour_variants_match_oracle(task, flag):
     (move_to_corner.py:42-44, move_to_region.py:47-51, match_regions.py:51-58, make_line.py:105-107); observations equal the oracle env built with the same draw,
     byte for byte, across an auto-reset."""
     from oracle.env_ref import LoRes4ERef, RefEnv
-    n, ep, seed = 6, 3, 77
+    n, ep, seed = 6, 3, int(__import__('os').environ.get('MGX_TEST_SEED', '77'))
     env = _make(f'{task}-TestColour-LoRes4E-v0', n, dtype='f64', max_episode_steps=ep)
     env.seed(seed)
     obs = env.reset().cpu().numpy()
@@ -704,7 +704,7 @@ def test_scores_with_per_env_colours(task, flag):
     expected blocks): product scoring on scrambled poses equals the oracle env that drew the same colours, bit for bit,
     and actually varies between envs."""
     from oracle.env_ref import RefEnv
-    n, seed = 24, 5
+    n, seed = 24, int(__import__('os').environ.get('MGX_TEST_SEED', '5'))
     env = _make(f'{task}-TestColour-v0', n, dtype='f64')
     env.seed(seed)
     env.reset()
