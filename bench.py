@@ -142,7 +142,10 @@ def main():
         state_bytes = rows_p * env.state_p.element_size() + (rows_f - 4 * slots) * env.state_f.element_size() + 12 + 20 * mean_cache
         step_bytes = n * (2 * state_bytes + 4 + 1)
         rast_bytes = n * (96 * 96 * (9 + 12) + rows_p * env.state_p.element_size())
-        kernels = {'k_step': (float(step_ms.mean()), step_bytes), 'k_raster': (float(rast_ms.mean()), rast_bytes)}
+        renders = len(rast_ms) > 0        # a task name without a preprocessor is the state-only configuration
+        kernels = {'k_step': (float(step_ms.mean()), step_bytes)}
+        if renders:
+            kernels['k_raster'] = (float(rast_ms.mean()), rast_bytes)
         dom = max(kernels, key=lambda k: kernels[k][0])
         ach = kernels[dom][1] / (kernels[dom][0] * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters: rocprofv3 cannot run inside this process, so the figure is the
@@ -157,12 +160,14 @@ def main():
             except Exception:
                 pass
         out = {
-            'metric': 'env-steps/sec (incl. 96x96 LoRes4E render) at N_envs=4096', 'value': value, 'unit': 'env-steps/s',
+            'metric': f'env-steps/sec (incl. 96x96 LoRes4E render) at N_envs={n}' if '-LoRes4E-' in args.task else
+                      f'env-steps/sec ({"incl. 96x96 render" if renders else "state-only observation"}) at N_envs={n}', 'value': value, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.dtype == 'f32' else args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{args.task}, {n} envs per GPU, random actions, auto-reset every {env.max_episode_steps} steps, '
-                                   'obs u8[N,96,96,12] (4 ego frames, oldest first)',
+                                   + ('obs u8[N,96,96,12] (4 ego frames, oldest first)' if '-LoRes4E-' in args.task else
+                                      'rendered observation' if renders else 'obs f32[N,n_bodies,3] poses'),
                        'n_envs_per_gpu': n, 'lanes_per_env': env.lanes_per_env, 'episodes_finished': n_eps * world,
                        'mean_eval_score': float(all_scores.mean().item()),
                        'arith': 'fp32 velocities/impulses/contacts + fp64 poses; fp64 rasteriser' if args.dtype == 'f32' else args.dtype},

@@ -213,6 +213,7 @@ class BaseEnv(abc.ABC):
         # pose-blob row of (x, y, angle) per body, -1 where the body is not persistent
         n = nat.check(L.mgx_world_n_state_entries(w))
         self._pose_rows = -np.ones((self.n_bodies, 3), dtype=np.int64)
+        self._pose_sel = None       # device copy of the row table (get_poses_tensor)
         self._motion_rows = -np.ones((self.n_bodies, 9), dtype=np.int64)
         for k in range(n):
             b, c, r = C.c_int(), C.c_int(), C.c_int()
@@ -466,9 +467,12 @@ class BaseEnv(abc.ABC):
 
     def get_poses_tensor(self):
         import torch
-        rows = torch.as_tensor(np.where(self._pose_rows >= 0, self._pose_rows, 0).reshape(-1), device=self.device)
-        valid = torch.as_tensor((self._pose_rows >= 0).reshape(-1), device=self.device)
-        p = self.state_p.index_select(0, rows) * valid[:, None].to(self.state_p.dtype)
+        sel = getattr(self, '_pose_sel', None)
+        if sel is None:     # the row table is fixed once the world is built: upload it once, not per step
+            rows = torch.as_tensor(np.where(self._pose_rows >= 0, self._pose_rows, 0).reshape(-1), device=self.device)
+            valid = torch.as_tensor((self._pose_rows >= 0).reshape(-1), device=self.device)[:, None].to(self.state_p.dtype)
+            sel = self._pose_sel = (rows, valid)
+        p = self.state_p.index_select(0, sel[0]) * sel[1]
         return p.reshape(self.n_bodies, 3, self.n_envs).permute(2, 0, 1).to(torch.float32)
 
     def get_poses(self, env_idx=None):
