@@ -3,7 +3,7 @@ import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, cProfile, pstats
 import magical_amd
-N = 4096
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 env = magical_amd.make('MoveToCorner-Demo-LoRes4E-v0', n_envs=N, device='cuda:0')
 env.reset()
 tape = torch.as_tensor(np.random.RandomState(0).randint(0, 18, size=(400, N)).astype(np.int32), device='cuda:0')
