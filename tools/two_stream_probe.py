@@ -4,9 +4,11 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import magical_amd
-name = sys.argv[1] if len(sys.argv) > 1 else 'MoveToCorner-Demo-LoRes4E-v0'
+args = [a for a in sys.argv[1:] if not a.startswith('--')]
+name = args[0] if args else 'MoveToCorner-Demo-LoRes4E-v0'
+JOIN = '--join' in sys.argv      # all parts wait for each other after every step (one caller consuming the whole batch)
 N, T, W = 4096, 300, 20
-for K in (1, 2, 4):
+for K in (1, 2, 4, 8):
     n = N // K
     streams = [torch.cuda.Stream() for _ in range(K)]
     envs = []
@@ -21,6 +23,12 @@ for K in (1, 2, 4):
             for k in range(K):
                 with torch.cuda.stream(streams[k]):
                     envs[k].step(acts[k][s])
+            if JOIN and K > 1:
+                evs = [torch.cuda.Event() for _ in range(K)]
+                for k in range(K): evs[k].record(streams[k])
+                for k in range(K):
+                    for j in range(K):
+                        if j != k: streams[k].wait_event(evs[j])
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f'{name} K={K} engines x {n} envs: {N * T / dt / 1e6:.2f} M env-steps/s, {dt / T * 1e3:.3f} ms per full-batch step', flush=True)
+    print(f'{name}{" (joined every step)" if JOIN else ""} K={K} engines x {n} envs: {N * T / dt / 1e6:.2f} M env-steps/s, {dt / T * 1e3:.3f} ms per full-batch step', flush=True)
     for e in envs: e.close()
