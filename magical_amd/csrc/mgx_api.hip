@@ -376,11 +376,19 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     if (L == 0 && !e->env_worlds) {
         L = 16;
         while (L < 64 && step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES / 2) L *= 2;
+        // batches that give every SIMD two wavefronts even at eight envs per wavefront, in the smallest worlds (robot + one
+        // block / one region: few overlapping pairs, so the extra lanes of a 16-group mostly idle through the serial parts
+        // of the solve).  Measured at 16384 envs: MoveToCorner k_step 0.80 -> 0.73 ms, MoveToRegion 0.65 -> 0.56 ms, but
+        // FixColour (72 KB of LDS at eight envs per workgroup) 0.96 -> 1.19 ms and larger worlds lose more
+        if (L == 16 && e->n_envs >= 16384 && step_lds_bytes(e, 8) <= (size_t)60 * 1024) L = 8;
     } else if (L == 0) {
         L = 64;      // per-env templates: one env per wavefront, so that its template copy in LDS is shared by all lanes
     }
     if (L != 4 && L != 8 && L != 16 && L != 32 && L != 64) return fail(MGX_ERR_ARG, "lanes_per_env must be 0, 4, 8, 16, 32 or 64");
     if (step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "world working set does not fit LDS at this lanes_per_env");
+    if (getenv("MGX_DEBUG_LAUNCH"))
+        fprintf(stderr, "mgx: lanes_per_env %d, k_step LDS bytes at 8 / 16 / 32 / 64 lanes: %zu / %zu / %zu / %zu\n", L,
+                step_lds_bytes(e, 8), step_lds_bytes(e, 16), step_lds_bytes(e, 32), step_lds_bytes(e, 64));
     e->L = L; e->lds_step = step_lds_bytes(e, L);
     e->rdev.off_i = HDR_WORDS; e->rdev.lds_tmpl_words = even(raster_words); e->rdev.scratch_d = scratch_d; e->rdev.off_tiles = off_tiles;
     // per-tile (u64 mask + i32 base) + queue (u64 mask + 2 x i32) + counters + overflow bitmap + phase E records (u64 sums, u16 entry)
