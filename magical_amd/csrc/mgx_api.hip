@@ -380,7 +380,8 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
         // block / one region: few overlapping pairs, so the extra lanes of a 16-group mostly idle through the serial parts
         // of the solve).  Measured at 16384 envs: MoveToCorner k_step 0.80 -> 0.73 ms, MoveToRegion 0.65 -> 0.56 ms, but
         // FixColour (72 KB of LDS at eight envs per workgroup) 0.96 -> 1.19 ms and larger worlds lose more
-        if (L == 16 && e->n_envs >= 16384 && step_lds_bytes(e, 8) <= (size_t)60 * 1024) L = 8;
+        // (only where every block island still has a lane of its own, i.e. the same register-resident joint code runs)
+        if (L == 16 && e->n_envs >= 16384 && step_lds_bytes(e, 8) <= (size_t)60 * 1024 && e->h.n_islands <= 7) L = 8;
     } else if (L == 0) {
         L = 64;      // per-env templates: one env per wavefront, so that its template copy in LDS is shared by all lanes
     }

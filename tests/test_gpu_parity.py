@@ -860,3 +860,49 @@ def test_native_render_box_filtered_equals_lores_observation(name):
         assert full.shape == (384, 384, 3)
         assert np.array_equal(area_resize_4x(full), obs[k, :, :, 9:12]), (name, k)
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('task', ['MoveToCorner', 'FixColour', 'ClusterColour'])
+def test_result_independent_of_lanes_per_env(task):
+    """The lanes-per-env launch geometry is the engine's choice (by world size and batch size), so the physics result
+    must not depend on it: bitwise equal pose / motion blobs and observations after a rollout at every width that gives
+    each block island a lane of its own.  A narrower group (ClusterColour's eight blocks at eight lanes) solves the block
+    islands' joints through LDS with the generic joint code instead of the register-resident one: the same operations in
+    another association, so there the first step agrees to fp32 rounding (the engine never picks that width by itself)."""
+    import torch
+    n, T = 64, 40
+    tape = _tape(9, T, n)
+    outs = {}
+    for L in (4, 8, 16, 32, 64):
+        try:
+            env = _make(f'{task}-Demo-LoRes4E-v0', n, lanes_per_env=L)
+        except Exception as ex:          # a world whose working set does not fit LDS at this width
+            assert 'LDS' in str(ex), ex
+            continue
+        assert env.lanes_per_env == L
+        env.reset()
+        for s in range(T):
+            obs, _, _, _ = env.step(tape[s])
+            if s == 0:
+                first = env.state_p.clone()
+        outs[L] = (env.state_p.clone(), env.state_f[:int(env._motion_rows.max()) + 1].clone(), obs.clone(), first)
+        env.close()
+    assert len(outs) >= 3, sorted(outs)
+    ref = outs[16]
+    for L, o in outs.items():
+        if task == 'ClusterColour' and L <= 8:
+            assert float((o[3] - ref[3]).abs().max()) < 1e-6, (task, L)
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(o[:3], ref[:3])), (task, L)
+
+
+@pytest.mark.gpu
+def test_large_batches_of_small_worlds_run_eight_lanes_per_env():
+    env = _make('MoveToCorner-Demo-LoRes4E-v0', 16384)
+    assert env.lanes_per_env == 8
+    env.reset(); env.step(_tape(1, 1, 16384)[0]); env.close()
+    for name, n in (('MoveToCorner-Demo-LoRes4E-v0', 4096), ('ClusterColour-Demo-LoRes4E-v0', 16384)):
+        env = _make(name, n)
+        assert env.lanes_per_env == 16
+        env.close()
