@@ -376,12 +376,13 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     if (L == 0 && !e->env_worlds) {
         L = 16;
         while (L < 64 && step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES / 2) L *= 2;
-        // batches that give every SIMD two wavefronts even at eight envs per wavefront, in the smallest worlds (robot + one
-        // block / one region: few overlapping pairs, so the extra lanes of a 16-group mostly idle through the serial parts
-        // of the solve).  Measured at 16384 envs: MoveToCorner k_step 0.80 -> 0.73 ms, MoveToRegion 0.65 -> 0.56 ms, but
-        // FixColour (72 KB of LDS at eight envs per workgroup) 0.96 -> 1.19 ms and larger worlds lose more
+        // bigger batches of the smallest worlds (robot + one block / one region: few overlapping pairs, so the extra lanes of
+        // a 16-group mostly idle through the serial parts of the solve) run eight lanes per env: fewer, fuller wavefronts.
+        // Measured, MoveToCorner k_step at 16 -> 8 lanes: 6144 envs 0.44 -> 0.36 ms, 8192 0.51 -> 0.49, 16384 0.80 -> 0.73,
+        // 65536 2.60 -> 2.32 (4096 envs: 0.34 -> 0.36, one wavefront per SIMD either way); MoveToRegion 16384: 0.65 -> 0.56;
+        // but FixColour (72 KB of LDS at eight envs per workgroup) 0.96 -> 1.19 ms and larger worlds lose more
         // (only where every block island still has a lane of its own, i.e. the same register-resident joint code runs)
-        if (L == 16 && e->n_envs >= 16384 && step_lds_bytes(e, 8) <= (size_t)60 * 1024 && e->h.n_islands <= 7) L = 8;
+        if (L == 16 && e->n_envs >= 6144 && step_lds_bytes(e, 8) <= (size_t)60 * 1024 && e->h.n_islands <= 7) L = 8;
     } else if (L == 0) {
         L = 64;      // per-env templates: one env per wavefront, so that its template copy in LDS is shared by all lanes
     }

@@ -899,9 +899,10 @@ def test_result_independent_of_lanes_per_env(task):
 
 @pytest.mark.gpu
 def test_large_batches_of_small_worlds_run_eight_lanes_per_env():
-    env = _make('MoveToCorner-Demo-LoRes4E-v0', 16384)
-    assert env.lanes_per_env == 8
-    env.reset(); env.step(_tape(1, 1, 16384)[0]); env.close()
+    for n in (8192, 16384):
+        env = _make('MoveToCorner-Demo-LoRes4E-v0', n)
+        assert env.lanes_per_env == 8
+        env.reset(); env.step(_tape(1, 1, n)[0]); env.close()
     for name, n in (('MoveToCorner-Demo-LoRes4E-v0', 4096), ('ClusterColour-Demo-LoRes4E-v0', 16384)):
         env = _make(name, n)
         assert env.lanes_per_env == 16
