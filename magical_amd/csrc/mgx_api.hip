@@ -396,9 +396,12 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     // per-tile (u64 mask + i32 base) + queue (u64 mask + 2 x i32) + counters + overflow bitmap + phase E records (u64 sums, u16 entry)
     int extra = N_TILES * 3 + QCAP * 4 + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2;
     e->lds_raster = (size_t)(e->rdev.lds_tmpl_words + off_tiles + extra) * 4;
-    // as many workgroups per CU as LDS allows (512 B allocation slack), between 3 and 5
-    int fit = (int)((size_t)MAX_LDS_BYTES / (e->lds_raster + 512));
+    // as many workgroups per CU as LDS allows (allocations round up to 512 B), between 3 and 5
+    int fit = (int)((size_t)MAX_LDS_BYTES / ((e->lds_raster + 511) & ~(size_t)511));
     e->raster_waves = fit >= 5 ? 5 : (fit == 4 ? 4 : 3);
+    if (getenv("MGX_DEBUG_LAUNCH"))
+        fprintf(stderr, "mgx: k_raster LDS bytes %zu (draw list %d words, per-env scratch %d words, tiles / queues %d words): %d workgroups per CU\n",
+                e->lds_raster, e->rdev.lds_tmpl_words, off_tiles, extra, e->raster_waves);
     return MGX_OK;
 }
 
