@@ -138,3 +138,32 @@ def test_episode_counter_and_done_flags():
     assert list(em.si[0]) == [40, 40, 40]
     em.reset(mask=[1, 0, 1])
     assert list(em.si[0]) == [0, 40, 0]
+
+
+@pytest.mark.parametrize('task', TASKS)
+def test_shipped_precision_drift_within_perturbation_envelope(task):
+    """The CPU twin of tests/test_gpu_parity.py::test_f32_drift_within_perturbation_envelope: the kernel phases compiled for the
+    host in the shipped precision (fp32 velocities / impulses, fp64 poses), free running against the oracle, next to the oracle's
+    own spread under a 1e-7 pose perturbation (two replicas per env).  Gate: at env-steps 1, 5, 20, 80 the drift quantiles
+    (median, p90 over the action tapes) stay within 2x the replicas'; at step 1 the median stays within 10x that of a replica
+    that only stores its velocities in fp32."""
+    from tests.util import EPS_F32, OracleEnvelope, masked_err, quantiles, velround_step
+    n, steps = 32, (1, 5, 20, 80)
+    tape = np.random.RandomState(7).randint(0, 18, size=(steps[-1], n)).astype(np.int32)
+    orc = OracleEnvelope([lambda: new_ref(task)] * n, K=2, eps=EPS_F32, seed=2)
+    em = EmuBatch(ref_entities_as_tuples(orc.base[0]), 1000, n, mode='mixed')
+    em.reset()
+    vround = [new_ref(task) for _ in range(n)]
+    for s in range(steps[-1]):
+        em.run(tape[s], nl=16)
+        got = em.bodies()[:, 1:, :3]
+        want, _ = orc.step(tape[s])
+        if s + 1 in steps:
+            (m, p), (em_, ep) = quantiles(np.array([masked_err(got[k], want[k], orc.mask) for k in range(n)])), quantiles(orc.all)
+            assert m <= 2 * em_ and p <= 2 * ep, (task, s + 1, m, p, em_, ep)
+        if s == 0:
+            for k, r in enumerate(vround):
+                velround_step(r, tape[0, k])
+            v1 = np.median([masked_err(r.bodies()[orc.idx][:, :3], want[k], orc.mask) for k, r in enumerate(vround)])
+            assert m <= 10 * v1, (task, m, v1)
+    assert int(em.si[2].sum()) == 0

@@ -7,7 +7,8 @@ amplify 1e-16 perturbations to 1e-3 within ~20 env-steps).
 import numpy as np
 import pytest
 
-from tests.util import TASKS, comparable_mask, new_ref, ref_body_index
+from tests.util import (EPS_F32, EPS_F64, TASKS, OracleEnvelope, comparable_mask, masked_err, new_ref, perturb_bodies, quantiles, ref_body_index,
+                        velround_step)
 
 pytestmark = pytest.mark.gpu
 
@@ -38,78 +39,110 @@ def test_native_library_is_loaded():
 
 @pytest.mark.parametrize('task', TASKS)
 def test_f64_engine_tracks_oracle(task):
-    """All-fp64 build, free running from reset: identical algorithm => agreement to round-off over the first
-    env-step.  Later steps only get a loose gate: whenever the robot changes velocity after a steady phase, the
-    reference's zero-length PinJoints take their direction from a round-off-level vector, so two
-    correct implementations part by ~1e-4 at once (DESIGN.md 'Numerical sensitivity')."""
-    n, t = 8, 4
+    """All-fp64 build, free running from reset: identical algorithm => agreement to round-off over the first env-step
+    (typical body), and at every step no further from the oracle than the oracle's own perturbed replicas are (8 per env,
+    poses perturbed by 1e-13): whenever the robot changes velocity after a steady phase the reference's zero-length
+    PinJoints take their direction from a round-off-level vector, so two correct implementations -- or
+    the oracle and its replica -- part by ~1e-4 at once (DESIGN.md 'Numerical sensitivity')."""
+    n, t = 8, 6
     tape = _tape(3, t, n)
     env = _make(f'{task}-Demo-v0', n, dtype='f64')
     env.reset()
-    refs = [new_ref(task) for _ in range(n)]
-    idx, mask = ref_body_index(refs[0]), comparable_mask(refs[0])
+    orc = OracleEnvelope([lambda: new_ref(task)] * n, K=8, eps=EPS_F64, seed=1)
+    first = []
     for s in range(t):
         env.step(tape[s])
         got = env.get_bodies()[:, 1:, :3]
-        for k, r in enumerate(refs):
-            r.step(tape[s, k])
-            want = r.bodies()[idx][:, :3]
-            assert np.abs(got[k] - want)[mask].max() < (1e-8 if s == 0 else 5e-3), (task, s, k)
+        want, _ = orc.step(tape[s])
+        errs = np.array([masked_err(got[k], want[k], orc.mask) for k in range(n)])
+        if s == 0:
+            first = errs
+        assert (errs <= 2 * orc.running + 1e-12).all(), (task, s, errs, orc.running)
+    assert np.median(first) < 1e-10, (task, first)
     env.close()
 
 
-@pytest.mark.parametrize('task', ['MoveToCorner', 'ClusterColour', 'FindDupe'])
+@pytest.mark.parametrize('task', TASKS)
 def test_f32_engine_one_step_error(task):
-    """Shipped precision (fp32 velocities/impulses, fp64 poses): starting each env-step from the oracle's
-    body state, the pose error after one full env-step (10 substeps) is ~3e-8 typical, < 1e-4 at p99."""
+    """Shipped precision (fp32 velocities / impulses / contacts, fp64 poses), `k_step<float, double, L>`: every env-step starts
+    from the oracle's body state (teacher forcing).  The one-step pose error is compared with two envelopes of the oracle
+    itself, measured on the same states and actions:
+      * a replica whose poses are perturbed by 1e-7 (one fp32 rounding at unit scale): p90 and p99 of the engine's error stay
+        within 2x the replica's;
+      * a replica whose velocity state is rounded to fp32 after every substep (the engine's storage format; the engine also
+        rounds each of the ~100 operations a velocity sees per substep, a random walk of ~10 roundings): the engine's
+        median stays within 10x the replica's."""
     n, t = 32, 40
     tape = _tape(5, t, n)
     env = _make(f'{task}-Demo-v0', n)
     env.reset()
     refs = [new_ref(task) for _ in range(n)]
+    pert = [new_ref(task) for _ in range(n)]
+    vround = [new_ref(task) for _ in range(n)]
     idx, mask = ref_body_index(refs[0]), comparable_mask(refs[0])
-    errs = []
+    rs = np.random.RandomState(17)
+    errs, env_p, env_v = [], [], []
     for s in range(t):
         b = env.get_bodies()
         for k, r in enumerate(refs):
-            b[k, 1:, :] = r.bodies()[idx]
+            state = r.bodies()
+            b[k, 1:, :] = state[idx]
+            pert[k].set_bodies(state); perturb_bodies(pert[k], EPS_F32, rs)
+            vround[k].set_bodies(state)
         env.set_bodies(b)
         env.step(tape[s])
         got = env.get_bodies()[:, 1:, :3]
         for k, r in enumerate(refs):
-            r.step(tape[s, k])
-            errs.append(np.abs(got[k] - r.bodies()[idx][:, :3])[mask].max())
-    errs = np.array(errs)
-    print(f'{task}: one-step pose error median {np.median(errs):.2e} p99 {np.percentile(errs, 99):.2e} max {errs.max():.2e}')
-    assert np.median(errs) < 1e-6
-    assert np.percentile(errs, 99) < 1e-4
-    # rare: an env whose pin-joint separation sits at round-off level turns an fp32 rounding into up to ~1e-2 within ONE
-    # env-step (DESIGN.md section 5; which sample it hits moves with every change of instruction selection)
-    assert np.sort(errs)[-3] < 5e-3 and errs.max() < 5e-2
+            r.step(tape[s, k]); pert[k].step(tape[s, k]); velround_step(vround[k], tape[s, k])
+            want = r.bodies()[idx][:, :3]
+            errs.append(masked_err(got[k], want, mask))
+            env_p.append(masked_err(pert[k].bodies()[idx][:, :3], want, mask))
+            env_v.append(masked_err(vround[k].bodies()[idx][:, :3], want, mask))
+    errs, env_p, env_v = np.array(errs), np.array(env_p), np.array(env_v)
+    pc = lambda x: (np.median(x), np.percentile(x, 90), np.percentile(x, 99), x.max())
+    print(f'{task}: one-step pose error  median / p90 / p99 / max')
+    for name, x in (('engine (fp32)', errs), ('oracle, poses +-1e-7', env_p), ('oracle, fp32 velocity state', env_v)):
+        print(f'  {name:28s} ' + ' / '.join(f'{v:.2e}' for v in pc(x)))
+    assert np.median(errs) <= 10 * np.median(env_v)
+    assert np.percentile(errs, 90) <= 2 * np.percentile(env_p, 90) and np.percentile(errs, 99) <= 2 * np.percentile(env_p, 99)
     env.close()
 
 
-def test_f32_free_running_drift_report():
-    """Free-running drift of the shipped engine vs the oracle on MoveToCorner (BASELINE.json asks for <1e-3
-    'over 200 steps'; the oracle itself moves by 4e-4 after ONE env-step under a 1e-13 perturbation, so this
-    is reported, with a loose gate)."""
-    n, t = 64, 20
-    tape = _tape(7, t, n)
-    env = _make('MoveToCorner-Demo-v0', n)
+DRIFT_STEPS = (1, 5, 20, 80)
+
+
+@pytest.mark.parametrize('task', TASKS)
+def test_f32_drift_within_perturbation_envelope(task):
+    """Free-running drift of the shipped engine vs the oracle, next to the oracle's own spread: per env one replica whose poses
+    start 1e-7 off (two replicas per env, U(-1e-7, 1e-7) on x, y, angle of every body: one fp32 rounding at unit scale).  BASELINE.json asks for
+    drift < 1e-3 over 200 steps; the reference dynamics themselves turn 1e-7 into > 1e-4 within ONE env-step (the table this
+    prints; tools/drift_table.py goes to env-step 200), so the criterion that can be met -- and is gated -- is: at
+    env-steps 1, 5, 20 and 80 the engine's drift quantiles (median, p90 over 48 action tapes) stay within 2x of the
+    replicas'.  At step 1 the median is also held to 10x that of a replica that merely stores fp32 velocities."""
+    n, T = 48, DRIFT_STEPS[-1]
+    tape = _tape(7, T, n)
+    env = _make(f'{task}-Demo-v0', n, max_episode_steps=1000)
     env.reset()
-    refs = [new_ref('MoveToCorner') for _ in range(n)]
-    idx, mask = ref_body_index(refs[0]), comparable_mask(refs[0])
-    drift = np.zeros((t, n))
-    for s in range(t):
+    orc = OracleEnvelope([lambda: new_ref(task)] * n, K=2, eps=EPS_F32, seed=2)
+    vround = [new_ref(task) for _ in range(n)]
+    drift, spread = np.zeros((T, n)), np.zeros((T, 2 * n))
+    for s in range(T):
         env.step(tape[s])
         got = env.get_bodies()[:, 1:, :3]
-        for k, r in enumerate(refs):
-            r.step(tape[s, k])
-            drift[s, k] = np.abs(got[k] - r.bodies()[idx][:, :3])[mask].max()
-    for s in (0, 1, 4, 9, 19):
-        print(f'env-step {s + 1:3d} (substep {10 * (s + 1)}): drift median {np.median(drift[s]):.2e} max {drift[s].max():.2e}')
-    assert np.median(drift[0]) < 1e-5
-    assert np.median(drift[19]) < 5e-2
+        want, _ = orc.step(tape[s])
+        drift[s] = [masked_err(got[k], want[k], orc.mask) for k in range(n)]
+        spread[s] = orc.all
+        if s == 0:
+            for k, r in enumerate(vround):
+                velround_step(r, tape[0, k])
+            v1 = np.array([masked_err(r.bodies()[orc.idx][:, :3], want[k], orc.mask) for k, r in enumerate(vround)])
+    print(f'{task}: env-step | engine drift median / p90 | oracle replica (poses +-1e-7) median / p90')
+    for s in DRIFT_STEPS:
+        (m, p), (em, ep) = quantiles(drift[s - 1]), quantiles(spread[s - 1])
+        print(f'  {s:3d} (substep {10 * s:4d}) | {m:.2e} / {p:.2e} | {em:.2e} / {ep:.2e}')
+        assert m <= 2 * em and p <= 2 * ep, (task, s, m, p, em, ep)
+    assert np.median(drift[0]) <= 10 * np.median(v1), (task, np.median(drift[0]), np.median(v1))
+    assert int(env.state_i[2].sum()) == 0
     env.close()
 
 
@@ -300,30 +333,37 @@ def test_rand_dynamics_matches_oracle(task):
     assert env.rand_dynamics
     env.seed(seed)
     env.reset()
-    refs = [RefEnv(task, max_episode_steps=ep, rand_dynamics=True, seed=seed + k) for k in range(n)]
-    for r in refs:
+    def mk(k):
+        r = RefEnv(task, max_episode_steps=ep, rand_dynamics=True, seed=seed + k)
         r.reset()
+        return r
+    refs = [mk(k) for k in range(n)]
     want = np.array([[getattr(r.world.phys_vars, nm) for nm, _ in type(r.world.phys_vars).BOUNDS] for r in refs])
     assert np.array_equal(env.phys_vars, want)                     # same draws, bit for bit
     assert len(np.unique(want[:, 0])) == n
     tape = _tape(31, 2 * ep, n)
     idx = ref_body_index(refs[0])
     mask = comparable_mask(refs[0])
+    # the oracle's own spread: 8 replicas per env (same draws), poses perturbed by 1e-13
+    orc = OracleEnvelope([lambda k=k: mk(k) for k in range(n)], K=8, eps=EPS_F64, seed=3, base=refs)
     for s in range(2 * ep):
         _, _, done, _ = env.step(tape[s])
         for k, r in enumerate(refs):
             _, d, _ = r.step(tape[s, k])
             assert d == done[k]
-            if d:
-                r.reset()
+        _, _ = orc.step(tape[s])
         if done.all():
+            for r in refs:
+                r.reset()
+            orc.reset()
             want = np.array([[getattr(r.world.phys_vars, nm) for nm, _ in type(r.world.phys_vars).BOUNDS] for r in refs])
             assert np.array_equal(env.phys_vars, want)             # second draw of each env's stream
             continue
         got = env.get_bodies()
-        for k, r in enumerate(refs):
-            err = np.abs(got[k, 1:, :3] - r.bodies()[idx][:, :3])[mask[:, :3]].max()
-            assert err < (1e-8 if s % ep == 0 else 5e-3), (task, s, k, err)
+        errs = np.array([masked_err(got[k, 1:, :3], r.bodies()[idx][:, :3], mask[:, :3]) for k, r in enumerate(refs)])
+        assert (errs <= 2 * orc.running + 1e-12).all(), (task, s, errs, orc.running)
+        if s % ep == 0:
+            assert np.median(errs) < 1e-10, (task, s, errs)
     # the limits matter: default dynamics give different poses after one step
     dflt = _make(f'{task}-Demo-v0', n, dtype='f64', max_episode_steps=ep)
     dflt.reset()
@@ -439,20 +479,29 @@ JITTER_CASES = [('MoveToCorner', 'TestJitter', {'rand_poses': True}),
                 ('FixColour', 'TestJitter', {'rand_layout_minor': True}), ('FixColour', 'TestLayout', {'rand_layout_full': True})]
 
 
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
 @pytest.mark.parametrize('task,variant,flags', JITTER_CASES)
-def test_pose_randomisation_matches_oracle(task, variant, flags):
+def test_pose_randomisation_matches_oracle(task, variant, flags, dtype):
     """Test*Jitter / TestLayout: every env draws its entity poses from its own stream with the reference's rejection
     sampling (geom.py:116-341: product = host sampler over mgx_world_placement_collides, oracle = the same procedure
-    over its GJK/EPA narrowphase).  Same draws -> identical initial poses and first observations; the fp64 engine
-    then tracks the oracle; the second episode draws again."""
+    over its GJK/EPA narrowphase).  Same draws -> identical initial poses and first observations (both builds keep fp64
+    poses); the engine then stays as close to the oracle as the oracle's own perturbed replicas do (8 per env; poses
+    perturbed by 1e-13 for the all-fp64 build, by 1e-7 = one fp32 rounding for the shipped build); the second episode
+    draws again."""
     from oracle.env_ref import LoRes4ERef, RefEnv
     import os
     n, ep, seed = 6, 3, int(os.environ.get('MGX_TEST_SEED', '321'))
-    env = _make(f'{task}-{variant}-LoRes4E-v0', n, dtype='f64', max_episode_steps=ep)
+    f64 = dtype == 'f64'
+    env = _make(f'{task}-{variant}-LoRes4E-v0', n, dtype=dtype, max_episode_steps=ep)
     env.seed(seed)
     obs = env.reset().cpu().numpy()
+    def mk(k):
+        r = RefEnv(task, max_episode_steps=ep, seed=seed + k, **flags)
+        r.reset()
+        return r
     refs = [LoRes4ERef(RefEnv(task, max_episode_steps=ep, seed=seed + k, **flags)) for k in range(n)]
     first = [r.reset() for r in refs]
+    orc = OracleEnvelope([lambda k=k: mk(k) for k in range(n)], K=8, eps=EPS_F64 if f64 else EPS_F32, seed=4, base=[r.env for r in refs])
     idx = ref_body_index(refs[0].env)
     mask = comparable_mask(refs[0].env)
     def check_reset(obs_now, firsts):
@@ -469,20 +518,21 @@ def test_pose_randomisation_matches_oracle(task, variant, flags):
         obs, _, done, info = env.step(tape[s])
         obs = obs.cpu().numpy()
         outs = [r.step(tape[s, k]) for k, r in enumerate(refs)]
+        orc.step(tape[s])
         if done.all():
             for k, (_, _, d, inf) in enumerate(outs):           # the score sees this env's own goal rectangle
-                assert d and abs(inf['eval_score'] - info['eval_score'][k]) < 1e-12, (task, k)
+                assert d and (not f64 or abs(inf['eval_score'] - info['eval_score'][k]) < 1e-12), (task, k)
             check_reset(obs, [r.reset() for r in refs])
+            orc.reset()
             continue
         got = env.get_bodies()
         errs = np.array([np.abs(got[k, 1:, :3] - r.env.bodies()[idx][:, :3])[mask[:, :3]].max() for k, r in enumerate(refs)])
-        # first step: rounding only in most envs -- at some drawn robot angles the device's and libm's sin / cos differ in
-        # the last bit, the finger roots' zero-length pins start 1e-17 apart in another direction and the reference
-        # dynamics amplify that within the step, as they do for every env afterwards
-        if s % ep == 0:
-            early = errs > 1e-8                       # the envs whose episode left the oracle's in its first step
+        # rounding only in most envs -- at some drawn robot angles the device's and libm's sin / cos differ in the last bit,
+        # the finger roots' zero-length pins start 1e-17 apart in another direction and the reference dynamics amplify
+        # that within the step: exactly what they do to the replicas
+        assert (errs <= 2 * orc.running + 1e-12).all(), (task, dtype, s, errs, orc.running)
+        if s % ep == 0 and f64:
             assert np.median(errs) < 1e-8, (task, s, errs)
-        assert errs[~early].max(initial=0) < 3e-2 and errs[early].max(initial=0) < 0.15, (task, s, errs)
     env.close()
 
 
@@ -506,26 +556,34 @@ WORLD_CASES = [
 ST_ID = {'triangle': 0, 'square': 1, 'pentagon': 2, 'hexagon': 3, 'octagon': 4, 'circle': 5, 'star': 6}
 
 
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
 @pytest.mark.parametrize('task,variant,flags', WORLD_CASES)
-def test_per_env_worlds_match_oracle(task, variant, flags):
+def test_per_env_worlds_match_oracle(task, variant, flags, dtype):
     """Test*Shape / TestCountPlus / TestAll: every env draws the blocks' shape types and the number of entities from its
-    own stream (e.g. cluster.py:81-110, match_regions.py:101-117) and runs in its own world.  Same draws as the oracle's
-    restatement of the reference's on_reset -> the same entities (compared slot by slot), identical first observations
-    (bit-exact: shapes, colours, counts and poses all show in the frame), identical scores; the fp64 engine tracks the
-    oracle (per-step tolerance as in the other rollout tests); the second episode draws again."""
+    own stream (e.g. cluster.py:81-110, match_regions.py:101-117) and runs in its own world (`k_step<R, P, 64>`, one env per
+    wavefront).  Same draws as the oracle's restatement of the reference's on_reset -> the same entities (compared slot by
+    slot), identical first observations (bit-exact: shapes, colours, counts and poses all show in the frame), identical
+    scores (fp64 build); the engine stays as close to the oracle as the oracle's own perturbed replicas do (8 per env, 1e-13
+    for the all-fp64 build, 1e-7 for the shipped fp32 build); the second episode draws again."""
     from oracle.env_ref import LoRes4ERef, RefEnv
     from oracle.entities_ref import GoalRegion as RefGoal
     import os
     n, ep, seed = 6, 3, int(os.environ.get('MGX_TEST_SEED', '4242'))      # (other seeds: a wider sweep from the command line)
-    env = _make(f'{task}-{variant}-LoRes4E-v0', n, dtype='f64', max_episode_steps=ep)
+    f64 = dtype == 'f64'
+    env = _make(f'{task}-{variant}-LoRes4E-v0', n, dtype=dtype, max_episode_steps=ep)
     env.seed(seed)
     obs = env.reset().cpu().numpy()
+    def mk(k):
+        r = RefEnv(task, max_episode_steps=ep, seed=seed + k, **flags)
+        r.reset()
+        return r
     refs = [LoRes4ERef(RefEnv(task, max_episode_steps=ep, seed=seed + k, **flags)) for k in range(n)]
     first = [r.reset() for r in refs]
+    orc = OracleEnvelope([lambda k=k: mk(k) for k in range(n)], K=8, eps=EPS_F64 if f64 else EPS_F32, seed=5, base=[r.env for r in refs])
     ents = env._entities
-    def compare(tol, what, typical=None, loose=None):
+    def compare(bound, what, typical=None):
         poses = env.get_poses()
-        worst, errs, env_err = 0.0, [], np.zeros(n)
+        errs, env_err = [], np.zeros(n)
         for k, r in enumerate(refs):
             slots = r.env.task.slots
             assert len(slots) == len(ents), (task, len(slots), len(ents))
@@ -538,14 +596,11 @@ def test_per_env_worlds_match_oracle(task, variant, flags):
                 want = np.asarray(r.env.task.main_pose(ref_ent))
                 errs.append(np.abs(poses[k, ent.body] - want).max())
                 env_err[k] = max(env_err[k], errs[-1])
-        # envs in `loose` left the oracle's episode in its first step already (see below): they get the wider bound
-        bound = np.where(loose, 0.15, tol) if loose is not None else np.full(n, tol)
-        assert (env_err < bound).all(), (task, what, env_err)
+        assert (env_err <= bound).all(), (task, dtype, what, env_err, bound)
         if typical is not None:
             assert np.median(errs) < typical, (task, what, np.median(errs))
-        return env_err
     def check_reset(obs_now, firsts):
-        compare(1e-12, 'reset')
+        compare(np.full(n, 1e-12), 'reset')
         for k in range(n):
             assert np.array_equal(obs_now[k], firsts[k]), (task, k)
     check_reset(obs, first)
@@ -555,17 +610,16 @@ def test_per_env_worlds_match_oracle(task, variant, flags):
         obs, _, done, info = env.step(tape[s])
         obs = obs.cpu().numpy()
         outs = [r.step(tape[s, k]) for k, r in enumerate(refs)]
+        orc.step(tape[s])
         if done.all():
             for k, (_, _, d, inf) in enumerate(outs):
-                assert d and abs(inf['eval_score'] - info['eval_score'][k]) < 1e-12, (task, k, inf['eval_score'], info['eval_score'][k])
+                assert d and (not f64 or abs(inf['eval_score'] - info['eval_score'][k]) < 1e-12), (task, k, inf['eval_score'], info['eval_score'][k])
             check_reset(obs, [r.reset() for r in refs])
+            orc.reset()
             continue
-        # first step of an episode: rounding only for the typical body; a random layout may start with a finger against a
-        # block or a wall, where the reference dynamics amplify a rounding to ~1e-4 within one env-step
-        if s % ep == 0:
-            early = compare(3e-2, f'step {s}', typical=1e-8) > 1e-8
-        else:
-            compare(3e-2, f'step {s}', loose=early)
+        # rounding only for the typical body; a random layout may start with a finger against a block or a wall, where the
+        # reference dynamics amplify a rounding to ~1e-4 within one env-step -- in the replicas too
+        compare(2 * orc.running + 1e-12, f'step {s}', typical=1e-8 if (f64 and s % ep == 0) else None)
     env.close()
 
 

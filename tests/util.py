@@ -47,3 +47,82 @@ def new_ref(task):
     e = RefEnv(task)
     e.reset()
     return e
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Perturbation envelopes: how far the ORACLE moves from itself under a perturbation the size of the engine's rounding.
+# The reference dynamics are chaotic by construction (zero-length PinJoints take their direction from a round-off-level
+# vector), so "pose error vs the oracle" only means something next to the oracle's own spread.
+EPS_F32 = 1e-7      # one fp32 rounding of a unit-scale quantity (2^-24 = 6e-8), the shipped engine's resolution
+EPS_F64 = 1e-13     # a few hundred fp64 roundings: what an all-fp64 engine differs from the oracle by (libm, FMA contraction)
+
+
+def perturb_bodies(ref_env, eps, rs):
+    """x, y, angle of every non-static body of an oracle env += U(-eps, eps), independently."""
+    b = ref_env.bodies()
+    for k in ref_body_index(ref_env):
+        b[k, :3] += rs.uniform(-eps, eps, 3)
+    ref_env.set_bodies(b)
+
+
+def masked_err(a, b, mask):
+    return float(np.abs(a - b)[mask].max())
+
+
+class OracleEnvelope:
+    """n oracle envs + K perturbed replicas of each.  step(actions) advances them and returns
+    (poses[n, n_dyn, 3] of the unperturbed envs, spread[n]) with spread[k] = the largest pose deviation of env k's replicas
+    from env k after this step; `running` keeps the maximum over the steps of the episode (a bound that only widens).
+    `factories` build an env ready to step (already reset); `base` = the caller's own unperturbed envs (then the caller
+    steps them, and step() only reads their poses)."""
+
+    def __init__(self, factories, K, eps, seed=0, base=None):
+        self.own_base = base is None
+        self.base = [f() for f in factories] if base is None else list(base)
+        self.rs, self.eps = np.random.RandomState(seed), eps
+        self.reps = [[f() for _ in range(K)] for f in factories]
+        for row in self.reps:
+            for q in row:
+                perturb_bodies(q, eps, self.rs)
+        self.idx, self.mask = ref_body_index(self.base[0]), comparable_mask(self.base[0])
+        self.running = np.zeros(len(self.base))
+
+    def reset(self):
+        """Next episode: every replica resets (drawing what its base env draws) and is perturbed afresh."""
+        for row in self.reps:
+            for q in row:
+                q.reset()
+                perturb_bodies(q, self.eps, self.rs)
+        self.idx, self.mask = ref_body_index(self.base[0]), comparable_mask(self.base[0])
+        self.running[:] = 0
+
+    def step(self, actions):
+        want, now, self.all = [], np.zeros(len(self.base)), []
+        for k, r in enumerate(self.base):
+            if self.own_base:
+                r.step(actions[k])
+            idx = ref_body_index(r)
+            w = r.bodies()[idx][:, :3]
+            want.append(w)
+            for q in self.reps[k]:
+                q.step(actions[k])
+                self.all.append(masked_err(q.bodies()[idx][:, :3], w, comparable_mask(r)))
+                now[k] = max(now[k], self.all[-1])
+        self.running = np.maximum(self.running, now)
+        self.all = np.array(self.all)           # every replica's deviation after this step (pooled quantiles)
+        return want, now
+
+
+def velround_step(ref_env, action):
+    """One env-step of the oracle with its velocity state rounded to fp32 after every substep: the reference dynamics under
+    the shipped engine's STORAGE precision alone (the engine also rounds every operation in between)."""
+    ref_env.set_action(action)
+    for _ in range(10):
+        ref_env.substep()
+        b = ref_env.bodies()
+        b[:, 3:] = b[:, 3:].astype(np.float32)
+        ref_env.set_bodies(b)
+
+
+def quantiles(x):
+    return float(np.median(x)), float(np.percentile(x, 90))
