@@ -97,9 +97,18 @@ def main():
     import magical_amd
     env = magical_amd.make(args.task, n_envs=args.envs, device=device, lanes_per_env=args.lanes, dtype=args.dtype)
     n, K, W = args.envs, args.steps, args.warmup
+    # The metric includes auto-reset + scoring at episode ends.  A timed region shorter than an episode
+    # (the driver's 20 steps vs 80) would never see one, so the envs are first rolled, untimed, to K // 2 steps before their
+    # episode ends, so that the K timed steps contain one episode end of every env (one per 80 env-steps is the long-run rate:
+    # a 20-step window carries four times its share of that cost, a 400-step window exactly its share).
+    ep = env.max_episode_steps
+    preroll = (ep - K // 2 - W) % ep if K < ep else 0
     # synthetic input: A = RandomState(seed).randint(0, 18, (T, N)) uploaded once; each rank its own slice
-    tape = torch.as_tensor(np.random.RandomState(rank).randint(0, 18, size=(K + W, n)).astype(np.int32), device=device)
+    tape = torch.as_tensor(np.random.RandomState(rank).randint(0, 18, size=(preroll + W + K, n)).astype(np.int32), device=device)
     obs = env.reset()
+    for s in range(preroll):
+        env.step(tape[s])
+    tape = tape[preroll:]
     for s in range(W):
         obs, rew, done, info = env.step(tape[s])
 
@@ -112,6 +121,7 @@ def main():
     last_score = torch.zeros(n, dtype=torch.float64, device=device)      # per-env result of the rollout
     n_eps = 0
     gather_rollout_results(last_score, n * world)      # warm-up of the collective (RCCL sets its channels up on first use)
+    last_score[torch.arange(n, device=device)] = torch.zeros(n, dtype=torch.float64, device=device)   # ... and of the loop's index_put
     barrier()
     t0 = time.perf_counter()
     for s in range(W, W + K):
@@ -152,13 +162,21 @@ def main():
         # committed summary of the separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command
         # (profiles/, produced by tools/pmc_summary.py; FETCH_SIZE doubled per MI355X_MICROARCH.md); default workload only
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_mtc_lores4e.json')
-        if args.task == TASK and n == N_ENVS and args.dtype == 'f32' and os.path.exists(pmc):
-            try:
-                traffic = float(json.load(open(pmc))[dom]['hbm_traffic_bytes_per_launch'])
-                traffic_src = 'profiles/r01_pmc_traffic_mtc_lores4e.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, median per launch)'
-            except Exception:
-                pass
+        key = {TASK: 'mtc_lores4e', 'ClusterColour-Demo-LoRes4E-v0': 'cc_lores4e'}.get(args.task)
+        if key and n == N_ENVS and args.dtype == 'f32':
+            for rnd in ('r02', 'r01'):
+                pmc = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_traffic_{key}.json')
+                try:
+                    traffic = float(json.load(open(pmc))[dom]['hbm_traffic_bytes_per_launch'])
+                    traffic_src = f'profiles/{rnd}_pmc_traffic_{key}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, median per launch)'
+                    break
+                except Exception:
+                    continue
+        # SURVEY.md §8(d) has two byte rows for the LoRes4E env-step: the headline one (state + ONE new 96x96x3 frame,
+        # 28.3 KB: what a ring of frames would move) and the parenthetical one this layout really needs (the contiguous
+        # [96,96,12] stack re-materialised: 9 B read + 12 B written per pixel, 194 KB).  `frac` prices the kernel against the
+        # layout it implements; `frac_new_frame_row` is the same launch priced against the headline row.
+        ring_bytes = n * (96 * 96 * 3 + rows_p * env.state_p.element_size())
         out = {
             'metric': f'env-steps/sec (incl. 96x96 LoRes4E render) at N_envs={n}' if '-LoRes4E-' in args.task else
                       f'env-steps/sec ({"incl. 96x96 render" if renders else "state-only observation"}) at N_envs={n}', 'value': value, 'unit': 'env-steps/s',
@@ -170,9 +188,15 @@ def main():
                                       'rendered observation' if renders else 'obs f32[N,n_bodies,3] poses'),
                        'n_envs_per_gpu': n, 'lanes_per_env': env.lanes_per_env, 'episodes_finished': n_eps * world,
                        'mean_eval_score': float(all_scores.mean().item()),
-                       'arith': 'fp32 velocities/impulses/contacts + fp64 poses; fp64 rasteriser' if args.dtype == 'f32' else args.dtype},
+                       'untimed_preroll_steps': preroll,
+                       'arith': 'fp32 velocities/impulses/contacts + fp64 poses; fp64 rasteriser' if args.dtype == 'f32' else args.dtype,
+                       'broadphase': 'pre-filtered candidate-pair list, AABB-tested brute force, compacted in pair order through LDS counters '
+                                     '(<= 27 shapes per env: measured faster than sort-and-sweep; DESIGN.md 3.1)',
+                       'roofline_bytes_row': 'SURVEY.md 8(d) parenthetical row: [96,96,12] stack re-materialised each step (9 B read + 12 B '
+                                             'written per pixel + pose rows); frac_new_frame_row uses the 28.3 KB headline row'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'frac_new_frame_row': (ring_bytes / (kernels[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom == 'k_raster' else None,
                          'avg_launch_ms': kernels[dom][0], 'algorithmic_bytes_per_launch': kernels[dom][1],
                          'other_kernels': {k: {'avg_launch_ms': v[0], 'algorithmic_bytes_per_launch': v[1],
                                                'achieved_GBs': v[1] / (v[0] * 1e-3) / 1e9} for k, v in kernels.items() if k != dom}},

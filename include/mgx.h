@@ -187,6 +187,16 @@ int mgx_engine_env_world_info(const mgx_engine *e, int env, int key, int *out);
  * = x, y (top-left corner), h, w per goal in entity order (entities.py:769-819), caller-owned, read by every later
  * render call (NULL = the world's own rectangles again).  Goal regions are sensors: physics never sees them */
 int mgx_engine_set_goal_rects(mgx_engine *e, const double *goal_xyhw);
+/* GoalRegion.get_overlapping_ents(com_overlap=True) (entities.py:821-881) for every goal region x every entity x every env,
+ * from the pose blob: out = DEVICE u8 [n_goals][n_entities][N] (goals in entity order, mgx_engine_n_goals of them), bit 0 =
+ * the entity's body position lies inside the region's box (bb.contains_vect; for the robot this is MoveToRegion's
+ * score, move_to_region.py:85-94), bit 1 = every collision shape of the block overlaps the region's rectangle
+ * (space.shape_query(...) non-empty for each shape).  An entity counts for a region iff both are set.  Per-env goal
+ * rectangles (mgx_engine_set_goal_rects) and per-env worlds (shape types, absent entities) are honoured; mask (DEVICE
+ * u8[N] or NULL): envs with mask == 0 get 0.  The tasks' score arithmetic on these sets stays with the caller
+ * (match_regions.py:193-213, find_dupe.py:203-216, fix_colour.py:193-202). */
+int mgx_engine_score_overlaps(mgx_engine *e, const void *state_p, const uint8_t *mask, uint8_t *out, void *stream);
+int mgx_engine_n_goals(const mgx_engine *e);
 int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t env_stride, int view, int layout,
                       const uint8_t *fill_mask, void *stream);
 /* native-resolution (384x384x3, no box filter) render of ONE env, for tests against the oracle/images */

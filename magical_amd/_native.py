@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, 'csrc')
 LIB_PATH = os.path.join(_PKG, 'libmagical_hip.so')
 _SOURCES = ['mgx_api.hip', 'mgx_world.cpp']
-_DEPS = _SOURCES + ['mgx_step.hip', 'mgx_raster.hip', 'mgx_sim.h', 'mgx_raster.h', 'mgx_tmpl.h', 'mgx_world.h']
+_DEPS = _SOURCES + ['mgx_step.hip', 'mgx_raster.hip', 'mgx_score.hip', 'mgx_sim.h', 'mgx_raster.h', 'mgx_tmpl.h', 'mgx_world.h']
 
 # enums (include/mgx.h)
 MGX_F32, MGX_F64, MGX_F32_PURE = 0, 1, 2
@@ -25,6 +25,10 @@ INFO = {k: i for i, k in enumerate([
 
 class MgxError(RuntimeError):
     pass
+
+
+class MgxCapacityWarning(RuntimeWarning):
+    """An env's contacts / overlapping pairs did not fit its fixed-size working set (BaseEnv._check_capacity)."""
 
 
 def needs_build():
@@ -93,6 +97,8 @@ def lib():
                                                      dp, dp, i32, C.POINTER(C.c_uint64), dp],
         'mgx_engine_env_world_info': [vp, i32, i32, ip],
         'mgx_engine_set_goal_rects': [vp, vp],
+        'mgx_engine_score_overlaps': [vp, vp, vp, vp, vp],
+        'mgx_engine_n_goals': [vp],
         'mgx_engine_create': [vp, i32, i32, i32, i32, C.POINTER(vp)],
         'mgx_engine_state_shape': [vp, ip, ip, ip, ip, ip],
         'mgx_engine_lanes_per_env': [vp],
@@ -129,7 +135,7 @@ EXPORTED_SYMBOLS = [
     'mgx_world_add_robot', 'mgx_world_add_shape', 'mgx_world_add_goal', 'mgx_world_finalize', 'mgx_world_info',
     'mgx_world_entity', 'mgx_world_body_table', 'mgx_world_n_state_entries', 'mgx_world_state_entry',
     'mgx_world_goal_bb', 'mgx_world_entity_shapes', 'mgx_world_prim_table', 'mgx_world_palette', 'mgx_world_placement_collides', 'mgx_world_randomise_all_poses', 'mgx_world_randomise_all_poses_batch',
-    'mgx_engine_create', 'mgx_engine_destroy', 'mgx_engine_set_entity_colours', 'mgx_engine_set_goal_rects',
+    'mgx_engine_create', 'mgx_engine_destroy', 'mgx_engine_set_entity_colours', 'mgx_engine_set_goal_rects', 'mgx_engine_score_overlaps', 'mgx_engine_n_goals',
     'mgx_world_variant', 'mgx_engine_enable_env_worlds', 'mgx_engine_set_env_variants', 'mgx_engine_env_randomise_all_poses_batch', 'mgx_engine_env_world_info',
     'mgx_engine_state_shape', 'mgx_engine_lanes_per_env', 'mgx_engine_lds_bytes', 'mgx_engine_reset', 'mgx_engine_reset_poses',
     'mgx_engine_step', 'mgx_engine_substeps', 'mgx_engine_render', 'mgx_engine_render_native',

@@ -12,7 +12,15 @@ step() returns (obs, reward, done, info) like the reference (base_env.py:255-292
   done   : numpy bool[N]
   info   : {'eval_score': numpy float64[N]}  (0.0 until done, base_env.py:285-288)
 With auto_reset=True (default, SB3 VecEnv semantics) finished envs are reset inside step()
-and their returned obs is the first observation of the next episode.
+and their returned obs is the first observation of the next episode (the terminal observation
+is overwritten; a caller that needs it steps with auto_reset=False and resets itself).
+
+OWNERSHIP OF OBSERVATIONS.  The reference returns a fresh numpy array per step; here the frame
+stack is ONE persistent device tensor that the raster kernel shifts in place, and step() /
+reset() return that same tensor every time (LoResCHW4E: a permuted view of it).  A collector
+that keeps references (`buf.append(obs)`) ends up with T aliases of the newest stack: copy
+what you keep (`obs.clone()`), or construct the env with `copy_obs=True`, which hands out a
+clone per call (one extra 110 KB/env device copy per step).
 """
 import abc
 import ctypes as C
@@ -65,10 +73,14 @@ class BaseEnv(abc.ABC):
     # TestCountPlus / TestAll): on_reset() then lists every entity an episode can have, sample_variation() says which
     # are present ('enabled') and of what type ('shape_types'), and the engine keeps one world per env
     variable_worlds = False
+    # False in the tasks whose score is a function of the goal regions' overlap sets alone (MoveToRegion, MatchRegions, FindDupe,
+    # FixColour): step() then hands score_on_end_of_traj() no poses -- the sets come from the device (k_score,
+    # mgx_engine_score_overlaps), one byte per region x entity x env instead of the pose rows
+    score_needs_poses = True
 
     def __init__(self, *, n_envs=1, device='cuda:0', res_hw=(384, 384), fps=8, phys_steps=10, phys_iter=10,
                  max_episode_steps=None, rand_dynamics=False, ego_view=True, allo_view=True,
-                 dtype='f32', lanes_per_env=0, auto_reset=True):
+                 dtype='f32', lanes_per_env=0, auto_reset=True, copy_obs=False, strict_capacity=False):
         import torch
         if fps != 8 or phys_steps != 10 or phys_iter != 10:
             raise NotImplementedError('the engine is built for the registered rates: fps=8, 10 substeps, 10 iterations '
@@ -77,10 +89,13 @@ class BaseEnv(abc.ABC):
         self.n_envs, self.fps, self.phys_steps, self.phys_iter = int(n_envs), fps, phys_steps, phys_iter
         self.res_hw, self.max_episode_steps = tuple(res_hw), max_episode_steps
         self.ego_view, self.allo_view, self.rand_dynamics = ego_view, allo_view, rand_dynamics
-        self.auto_reset = auto_reset
+        self.auto_reset, self.copy_obs, self.strict_capacity = auto_reset, bool(copy_obs), bool(strict_capacity)
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise nat.MgxError('magical_amd runs on an MI355X (torch device "cuda:N"); there is no CPU fallback')
+        if self.device.index is None:      # 'cuda' = torch's current device, pinned now (the engine lives on one GPU)
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.capacity_overflows = 0        # contacts / overlapping pairs the fixed-size working set dropped (see step())
         self.dtype_name = dtype
         self._dtype = {'f32': nat.MGX_F32, 'f64': nat.MGX_F64, 'f32_pure': nat.MGX_F32_PURE}[dtype]
         self._lanes = lanes_per_env
@@ -169,7 +184,7 @@ class BaseEnv(abc.ABC):
                 nat.check(L.mgx_world_goal_bb(w, ent.ent_id, bb))
                 ent.bb = tuple(bb)       # l b r t
         eng = C.c_void_p()
-        nat.check(L.mgx_engine_create(w, self.n_envs, self.device.index or 0, self._dtype, self._lanes, C.byref(eng)))
+        nat.check(L.mgx_engine_create(w, self.n_envs, self.device.index, self._dtype, self._lanes, C.byref(eng)))
         self._engine = eng
         ne = len(self._entities)
         self._default_shape_types = np.array([en.SHAPE_TYPE_ID[e.shape_type] if isinstance(e, en.Shape) else -1 for e in self._entities], dtype=np.int32)
@@ -248,8 +263,15 @@ class BaseEnv(abc.ABC):
             idx = np.arange(self.n_envs)
             self._scoring_envs = idx
             self.score_on_end_of_traj(self.get_poses(idx))      # likewise the scoring path (numpy / BLAS / shape-table set-up)
+            if not self.score_needs_poses:
+                self._overlap = self.region_overlaps(None)
+                self.score_on_end_of_traj(None)
+            self._check_capacity(None, 0)
             self._warm = True
-        return self._observe(fill_all=True)
+        obs = self._observe(fill_all=True)
+        if self.copy_obs:
+            obs = {k: v.clone() for k, v in obs.items()} if isinstance(obs, dict) else obs.clone()
+        return obs
 
     def step(self, actions):
         import torch
@@ -269,14 +291,39 @@ class BaseEnv(abc.ABC):
         if done.any():
             idx = np.nonzero(done)[0]
             self._scoring_envs = idx          # which envs the poses belong to (per-env task state of Test* variants)
-            eval_score[idx] = self.score_on_end_of_traj(self.get_poses(idx))
+            sel = None if len(idx) == self.n_envs else idx      # lockstep batches finish together: no gather then
+            if self.score_needs_poses:
+                eval_score[idx] = self.score_on_end_of_traj(self.get_poses(sel))
+            else:
+                self._overlap = self.region_overlaps(sel, mask_dev=self._done_dev)
+                eval_score[idx] = self.score_on_end_of_traj(None)
             assert np.all((eval_score >= 0) & (eval_score <= 1)), 'eval score out of range'
+            self._check_capacity(sel, len(idx))
             if self.auto_reset:
                 # the device-side done flags written by the step kernel double as reset + frame-fill masks
                 self._reset_envs(idx, self._done_dev)
                 fill = self._done_dev
         obs = self._observe(fill_mask=fill)
+        if self.copy_obs:
+            obs = {k: v.clone() for k, v in obs.items()} if isinstance(obs, dict) else obs.clone()
         return obs, self._reward, done, {'eval_score': eval_score}
+
+    def _check_capacity(self, idx, n_finished):
+        """Chipmunk never drops a contact (base_env.py:243); this engine's per-env working set is sized from the world
+        (every shape pair that can touch) and counts what did not fit in state_i[2].  The counter of the envs whose episode
+        just ended is read here -- the stream is already drained by the pose download, so no extra synchronisation -- and a
+        non-zero count is reported: a warning by default, an MgxError with strict_capacity=True."""
+        import torch
+        import warnings
+        row = self.state_i[2] if idx is None else self.state_i[2, torch.as_tensor(idx, device=self.device)]
+        n = int(row.sum())
+        if n:
+            self.capacity_overflows += n
+            msg = (f'{n} contact(s) / overlapping pair(s) exceeded the per-env working set in {n_finished} finished episode(s) and were '
+                   'dropped (the reference never drops contacts): results for those envs deviate from the reference')
+            if self.strict_capacity:
+                raise nat.MgxError(msg)
+            warnings.warn(msg, nat.MgxCapacityWarning, stacklevel=3)
 
     # ------------------------------------------------------------------ per-env variation (Test* variants)
     def sample_variation(self, rng, k):
@@ -290,6 +337,13 @@ class BaseEnv(abc.ABC):
         hook returns, for all envs in one native call."""
         return None
 
+    def sample_variation_is_active(self):
+        """Does sample_variation() draw anything for this task variant?  (The reference's on_reset branches on constructor
+        flags only, so the answer is the same for every env and episode; asked on a scratch stream.)"""
+        if getattr(self, '_variation_active', None) is None:
+            self._variation_active = self.sample_variation(np.random.RandomState(0), 0) is not None
+        return self._variation_active
+
     def default_entity_poses(self):
         """float64[n_entities, 3] copy of the Demo layout, indexed like self._entities (= ent_id order)."""
         return self._default_poses.copy()
@@ -300,7 +354,9 @@ class BaseEnv(abc.ABC):
         the reset kernel -- with the drawn entity poses if any -- then the drawn force limits and colours."""
         import torch
         pvs, colour_rows, pose_rows, pose_spec, hw_rows, world_rows = [], [], [], None, {}, []
-        for k in env_idx:
+        # a task without per-episode draws (the Demo variants) returns None for every env and touches no stream: ask once
+        draws = self.rand_dynamics or self.variable_worlds or (len(env_idx) > 0 and self.sample_variation_is_active())
+        for k in (env_idx if draws else ()):
             rng = self.rngs[k]
             if self.rand_dynamics:
                 pvs.append(PhysicsVariables.sample(rng))
@@ -417,6 +473,19 @@ class BaseEnv(abc.ABC):
         else:
             self._goal_rect[:, torch.as_tensor(idx, device=self.device)] = torch.as_tensor(
                 np.ascontiguousarray(xyhw.reshape(len(idx), -1).T), device=self.device)
+
+    def region_overlaps(self, env_idx=None, mask_dev=None):
+        """GoalRegion.get_overlapping_ents(com_overlap=True) (entities.py:821-881) on the device for the envs `env_idx`
+        (default all): numpy u8 [n_goals, n_entities, M], bit 0 = body position inside the region's box, bit 1 = every shape of
+        the block overlaps the region (goals in entity order; mgx_engine_score_overlaps).  Synchronises (one small copy)."""
+        import torch
+        ng, ne = len(self._goal_ent_idx), len(self._entities)
+        if getattr(self, '_overlap_dev', None) is None:
+            self._overlap_dev = torch.zeros((ng, ne, self.n_envs), dtype=torch.uint8, device=self.device)
+        nat.check(self._lib.mgx_engine_score_overlaps(self._engine, self.state_p.data_ptr(), None if mask_dev is None else mask_dev.data_ptr(),
+                                                      self._overlap_dev.data_ptr(), self._stream()))
+        out = self._overlap_dev if env_idx is None else self._overlap_dev[:, :, torch.as_tensor(env_idx, device=self.device)]
+        return out.cpu().numpy()
 
     def goal_bb(self, goal):
         """Sensor box (l, b, r, t) of a goal region for the envs being scored: scalars while every env has the

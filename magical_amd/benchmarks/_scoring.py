@@ -13,15 +13,38 @@ from .. import _native as nat
 from .. import entities as en
 
 
-def row_norm(d):
-    """np.linalg.norm(v) for each row v of d[M, 2].  The reference calls the 1-D form, which numpy
-    evaluates as sqrt(v.dot(v)) through BLAS ddot (FMA on most builds); elementwise x*x + y*y can
-    differ in the last bit, so go through the same primitive row by row."""
+def _row_norm_loop(d):
     out = np.empty(len(d), dtype=np.float64)
     dot, sqrt = np.dot, math.sqrt
     for k, r in enumerate(d):
         out[k] = sqrt(dot(r, r))
     return out
+
+
+_ROW_NORM_BATCHED = [
+    # stacked (1 x 2) @ (2 x 1): numpy routes this through the same dot kernel on the builds seen so far
+    lambda d: np.sqrt(np.matmul(d[:, None, :], d[:, :, None])[:, 0, 0]),
+    # no FMA in the BLAS in use
+    lambda d: np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]),
+]
+_row_norm_impl = None
+
+
+def row_norm(d):
+    """np.linalg.norm(v) for each row v of d[M, 2].  The reference calls the 1-D form, which numpy evaluates as
+    sqrt(v.dot(v)) through BLAS ddot -- with or without FMA depending on the BLAS kernel the CPU selects, so elementwise
+    x*x + y*y can differ in the last bit.  The row-by-row call is the definition (3 ms per 4096 rows); a batched
+    expression is used instead once it has reproduced the row-by-row results bit for bit on 2048 probe rows in this
+    process (a wrong candidate differs on ~8 % of rows), so the result is the reference's either way."""
+    global _row_norm_impl
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    if _row_norm_impl is None:
+        rs = np.random.RandomState(20260928)
+        probe = rs.uniform(-2.0, 2.0, size=(2048, 2))
+        probe[:256] *= rs.uniform(1e-6, 1.0, size=(256, 1))
+        want = _row_norm_loop(probe)
+        _row_norm_impl = next((f for f in _ROW_NORM_BATCHED if np.array_equal(f(probe), want)), _row_norm_loop)
+    return _row_norm_impl(d) if len(d) else np.empty(0, dtype=np.float64)
 
 
 def entity_shapes(env, ent):
@@ -89,6 +112,11 @@ def overlapping_ents(env, goal, ents, poses):
     bool[M, len(ents)] -- an entity counts iff EVERY one of its shapes overlaps the sensor AND its
     body position lies inside the sensor's bounding box.  In tasks with per-env worlds a block has the shape type of
     its env's episode, and blocks the episode does not have never count."""
+    if poses is None:
+        # the engine's own episode ends: the sets were computed on the device (k_score; per-env rectangles, worlds, shape
+        # types and absent entities included) -- env._overlap = u8 [n_goals, n_entities, M], both bits set = counts
+        g = env._goal_ent_idx.index(goal.ent_id)
+        return (env._overlap[g][[e.ent_id for e in ents]] == 3).T
     bb = env.goal_bb(goal)
     l, b, r, t = bb
     out = np.zeros((poses.shape[0], len(ents)), dtype=bool)

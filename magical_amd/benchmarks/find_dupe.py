@@ -20,6 +20,8 @@ DEFAULT_QUERY_BLOCK_POSE = ((-0.33, -0.49), -0.51)
 
 
 class FindDupeEnv(BaseEnv):
+    score_needs_poses = False      # the score is a function of the goal regions' overlap sets (k_score on the device)
+
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
         assert not (rand_layout_minor and rand_layout_full)

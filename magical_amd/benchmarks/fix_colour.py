@@ -17,6 +17,8 @@ MIN_REGIONS, MAX_REGIONS = 2, 3             # fix_colour.py:9-10
 
 
 class FixColourEnv(BaseEnv):
+    score_needs_poses = False      # the score is a function of the goal regions' overlap sets (k_score on the device)
+
     def __init__(self, rand_colours=False, rand_shapes=False, rand_count=False, rand_layout_minor=False,
                  rand_layout_full=False, **kwargs):
         assert not (rand_layout_minor and rand_layout_full)

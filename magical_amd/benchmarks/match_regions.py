@@ -10,6 +10,8 @@ from ._scoring import overlapping_ents
 
 
 class MatchRegionsEnv(BaseEnv):
+    score_needs_poses = False      # the score is a function of the goal regions' overlap sets (k_score on the device)
+
     def __init__(self, rand_target_colour=False, rand_shape_type=False, rand_shape_count=False,
                  rand_layout_minor=False, rand_layout_full=False, **kwargs):
         assert not (rand_layout_minor and rand_layout_full)

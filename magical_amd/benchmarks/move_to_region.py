@@ -11,6 +11,8 @@ DEFAULT_GOAL_XYHW = (-0.62, -0.17, 0.76, 0.75)
 
 
 class MoveToRegionEnv(BaseEnv):
+    score_needs_poses = False      # the score is a function of the goal regions' overlap sets (k_score on the device)
+
     def __init__(self, rand_poses_minor=False, rand_poses_full=False, rand_goal_colour=False, **kwargs):
         assert not (rand_poses_minor and rand_poses_full), "cannot specify both 'rand_poses_minor' and 'rand_poses_full'"
         self.rand_poses_minor, self.rand_poses_full, self.rand_goal_colour = rand_poses_minor, rand_poses_full, rand_goal_colour
@@ -42,6 +44,9 @@ class MoveToRegionEnv(BaseEnv):
 
     def score_on_end_of_traj(self, poses):   # move_to_region.py:85-94
         # goal_shape.point_query(robot_pos)[0] <= 0  <=>  not strictly outside any face of the box
+        if poses is None:      # the engine's own episode ends: bit 0 of the device's overlap flags is exactly this test
+            g = self._goal_ent_idx.index(self.__goal_ref.ent_id)
+            return np.where(self._overlap[g, self._robot.ent_id] & 1, 1.0, 0.0)
         x, y = poses[:, self._robot.body, 0], poses[:, self._robot.body, 1]
         l, b, r, t = self.goal_bb(self.__goal_ref)
         outside = (x - r > 0.0) | (y - t > 0.0) | (l - x > 0.0) | (b - y > 0.0)

@@ -16,6 +16,7 @@
 
 #include "../../include/mgx.h"
 #include "mgx_raster.hip"
+#include "mgx_score.hip"
 #include "mgx_step.hip"
 #include "mgx_world.h"
 
@@ -33,6 +34,32 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 constexpr int BG_RGB = 231 | (231 << 8) | (234 << 16);   // lighten_rgb(grey, 4), base_env.py:186
 constexpr int MAX_LDS_BYTES = 160 * 1024;
 constexpr int TIMING_RING = 4096;
+constexpr int MAX_DEVICES = 64;
+
+// Every entry point that touches the device runs on the ENGINE's device and leaves the caller's current device as it
+// found it (a process may drive several GPUs, one engine each).
+struct DeviceGuard {
+    int prev = -1; bool ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define ON_DEVICE(e) DeviceGuard guard__((e)->device); if (!guard__.ok) return fail(MGX_ERR_HIP, "hipSetDevice failed")
+
+// Dynamic LDS above 64 KB needs an opt-in per kernel function AND per device: remember the largest size granted so far for
+// each (instantiation, device) -- `Tag` makes the table one per kernel.
+template <typename Tag> int ensure_lds(const void *kern, size_t lds, int device) {
+    static thread_local size_t granted[MAX_DEVICES] = {0};
+    if (lds > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "kernel working set does not fit the CU's 160 KB of LDS");
+    const int d = device >= 0 && device < MAX_DEVICES ? device : 0;
+    if (lds > 65536 && lds > granted[d]) {
+        HIP_OK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        granted[d] = lds;
+    }
+    return MGX_OK;
+}
 }  // namespace
 
 struct mgx_world { World w; };
@@ -68,6 +95,13 @@ struct mgx_engine {
     uint32_t *d_stage = nullptr; size_t stage_words = 0;                 // upload staging (device)
     uint32_t *h_stage = nullptr; size_t h_stage_words = 0;               // upload staging (pinned host memory)
     int32_t *d_stage_idx = nullptr; size_t stage_idx_n = 0;       // (env, offsets, sizes) rows of an upload
+    // k_score (goal-region overlap sets): fp64 shape library, entity / body / goal tables of the engine's world, and with
+    // per-env worlds the envs' shape types and presence flags
+    ScoreLib *d_score_lib = nullptr;
+    int32_t *d_score_ent = nullptr, *d_score_prow = nullptr, *d_score_goal_ent = nullptr;
+    double *d_score_goal_xyhw = nullptr;
+    int8_t *d_ent_type_env = nullptr; uint8_t *d_ent_present_env = nullptr;
+    int n_goals = 0;
     int timing = 0;             // 0 = off, n = bracket every n-th launch of each kind with HIP events
     int launch_count[2] = {0, 0};
     int dbg_iterations = -1;    // development probe: override the solver iteration count
@@ -410,11 +444,8 @@ static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const i
                          int count_step, hipStream_t st) {
     auto kern = k_step<R, P, L>;
     size_t lds = step_lds_bytes(e, L);
-    static thread_local size_t configured = 0;   // per-instantiation, per-thread: the largest LDS size asked for so far
-    if (lds > configured) {
-        HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds > 65536 ? (int)lds : 65536));
-        configured = lds;
-    }
+    struct Tag { char c; };
+    if (int rc = ensure_lds<Tag>((const void *)kern, lds, e->device)) return rc;
     int epb = 64 / L, blocks = (e->n_envs + epb - 1) / epb;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, st, e->tdev, (P *)sp, (R *)sf, si, actions, done, e->n_envs, n_sub,
                        count_step, e->dbg_iterations >= 0 ? e->dbg_iterations : PHYS_ITER);
@@ -433,6 +464,53 @@ static int launch_step(mgx_engine *e, void *sp, void *sf, int32_t *si, const int
         case 64: return launch_step_L<R, P, 64>(e, sp, sf, si, actions, done, n_sub, count_step, st);
     }
     return fail(MGX_ERR_ARG, "lanes_per_env must be 4, 8, 16, 32 or 64");
+}
+
+// k_score's constant tables: the block shapes of every shape type in fp64 (from variants of the engine's world in which every
+// block has that type: all blocks share SHAPE_RAD, entities.py:614-711), the entity list, the bodies' pose rows, the goals
+static int build_score_tables(mgx_engine *e) {
+    const World &w = e->w;
+    const int ne = (int)w.entities.size();
+    std::vector<ScoreLib> lib(1);
+    std::memset(&lib[0], 0, sizeof(ScoreLib));
+    int first_block = -1;
+    for (int i = 0; i < ne; i++) if (w.entities[i].kind == 1) { first_block = i; break; }
+    if (first_block >= 0) {
+        for (int t = 0; t < SC_TYPES; t++) {
+            std::vector<int> types(ne, -1);
+            for (int i = 0; i < ne; i++) if (w.entities[i].kind == 1) types[i] = t;
+            std::vector<uint8_t> on(ne, 1);
+            World v; std::string err;
+            int rc = w.variant(on.data(), types.data(), v, err);
+            if (rc) return fail(rc == -2 ? MGX_ERR_CAPACITY : MGX_ERR_ARG, "score library: " + err);
+            const EntityDef &E = v.entities[first_block];
+            if ((int)E.shapes.size() > SC_MAX_PARTS) return fail(MGX_ERR_CAPACITY, "score library: block with more than 8 collision shapes");
+            lib[0].n_parts[t] = (int)E.shapes.size();
+            for (size_t p = 0; p < E.shapes.size(); p++) {
+                const ShapeDef &S = v.shapes[E.shapes[p]];
+                if ((int)S.verts.size() > SC_MAX_VERTS) return fail(MGX_ERR_CAPACITY, "score library: collision polygon with more than 8 vertices");
+                lib[0].kind[t][p] = S.kind; lib[0].nv[t][p] = (int)S.verts.size(); lib[0].radius[t][p] = S.radius;
+                for (size_t k = 0; k < S.verts.size(); k++) { lib[0].xy[t][p][2 * k] = S.verts[k].x; lib[0].xy[t][p][2 * k + 1] = S.verts[k].y; }
+            }
+        }
+    }
+    std::vector<int32_t> ent(4 * (size_t)ne), prow(3 * w.bodies.size(), -1), goal_ent;
+    std::vector<double> goal_xyhw;
+    for (int i = 0; i < ne; i++) {
+        const EntityDef &E = w.entities[i];
+        ent[4 * i] = E.kind; ent[4 * i + 1] = E.body; ent[4 * i + 2] = E.kind == 1 ? E.shape_type : -1; ent[4 * i + 3] = E.enabled ? 1 : 0;
+        if (E.kind == 2) { goal_ent.push_back(i); goal_xyhw.insert(goal_xyhw.end(), {E.x, E.y, E.h, E.w}); }
+    }
+    for (int m : w.state_map) { const int comp = m & 15, b = (m >> 4) & 0xFF, row = m >> 12; if (comp < 3) prow[3 * b + comp] = row; }
+    e->n_goals = (int)goal_ent.size();
+    auto up = [&](auto **dst, const void *src, size_t bytes) -> bool {
+        if (bytes == 0) { *dst = nullptr; return true; }
+        return hipMalloc(reinterpret_cast<void **>(dst), bytes) == hipSuccess && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!up(&e->d_score_lib, lib.data(), sizeof(ScoreLib)) || !up(&e->d_score_ent, ent.data(), ent.size() * 4) || !up(&e->d_score_prow, prow.data(), prow.size() * 4) ||
+        !up(&e->d_score_goal_ent, goal_ent.data(), goal_ent.size() * 4) || !up(&e->d_score_goal_xyhw, goal_xyhw.data(), goal_xyhw.size() * 8))
+        return fail(MGX_ERR_HIP, "score table upload failed");
+    return MGX_OK;
 }
 
 static bool timing_this_launch(const mgx_engine *e, int which) { return e->timing > 0 && e->launch_count[which] % e->timing == 0; }
@@ -465,7 +543,8 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MGX_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return fail(MGX_ERR_ARG, "device index out of range");
-    HIP_OK(hipSetDevice(device));
+    DeviceGuard guard__(device);
+    if (!guard__.ok) return fail(MGX_ERR_HIP, "hipSetDevice failed");
     mgx_engine *e = new mgx_engine();
     e->w = w->w; e->n_envs = n_envs; e->device = device; e->dtype = dtype; e->L_request = lanes_per_env;
     WorldBlobs b;
@@ -485,11 +564,17 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
     e->tdev.off_r = b.step_off_r; e->tdev.off_p = b.step_off_p; e->tdev.env_off_r = b.step_env_off_r; e->tdev.env_off_i = b.step_env_off_i;
     e->rdev.words = e->d_raster; e->rdev.n_words = (int)b.raster.size(); e->rdev.tmpl_stride_words = 0;
     e->rdev.bg_rgb = BG_RGB; e->rdev.qcap = QCAP; e->rdev.ecap = ECAP; e->rdev.palette = e->d_palette;
+    rc = build_score_tables(e);
+    if (rc) { mgx_engine_destroy(e); return rc; }
     *out = e;
     return MGX_OK;
 }
 void mgx_engine_destroy(mgx_engine *e) {
     if (!e) return;
+    DeviceGuard guard__(e->device);
+    for (void *p : {(void *)e->d_score_lib, (void *)e->d_score_ent, (void *)e->d_score_prow, (void *)e->d_score_goal_ent,
+                    (void *)e->d_score_goal_xyhw, (void *)e->d_ent_type_env, (void *)e->d_ent_present_env})
+        if (p) (void)hipFree(p);
     if (e->d_step) (void)hipFree(e->d_step);
     if (e->d_raster) (void)hipFree(e->d_raster);
     if (e->d_palette) (void)hipFree(e->d_palette);
@@ -513,9 +598,17 @@ int mgx_engine_lds_bytes(const mgx_engine *e, int which) { return e ? (int)(whic
 
 static int reset_common(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const uint8_t *mask, const void *ent_pose, void *stream) {
     if (!e || !state_p || !state_f || !state_i) return fail(MGX_ERR_ARG, "NULL argument");
+    ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     size_t lds = e->env_worlds ? 0 : (size_t)e->tdev.n_words * 4;
     int blocks = (e->n_envs + 63) / 64;
+    {
+        struct TagA { char c; }; struct TagB { char c; }; struct TagC { char c; };
+        int rc = e->dtype == MGX_F32 ? ensure_lds<TagA>((const void *)k_reset<float, double>, lds, e->device)
+               : e->dtype == MGX_F64 ? ensure_lds<TagB>((const void *)k_reset<double, double>, lds, e->device)
+                                     : ensure_lds<TagC>((const void *)k_reset<float, float>, lds, e->device);
+        if (rc) return rc;
+    }
     if (e->dtype == MGX_F32) hipLaunchKernelGGL((k_reset<float, double>), dim3(blocks), dim3(64), lds, st, e->tdev, (double *)state_p, (float *)state_f, state_i, mask, (const double *)ent_pose, e->n_envs);
     else if (e->dtype == MGX_F64) hipLaunchKernelGGL((k_reset<double, double>), dim3(blocks), dim3(64), lds, st, e->tdev, (double *)state_p, (double *)state_f, state_i, mask, (const double *)ent_pose, e->n_envs);
     else hipLaunchKernelGGL((k_reset<float, float>), dim3(blocks), dim3(64), lds, st, e->tdev, (float *)state_p, (float *)state_f, state_i, mask, (const float *)ent_pose, e->n_envs);
@@ -532,6 +625,7 @@ int mgx_engine_reset_poses(mgx_engine *e, void *state_p, void *state_f, int32_t 
 static int step_common(mgx_engine *e, void *sp, void *sf, int32_t *si, const int32_t *actions, uint8_t *done, int n_sub, int count_step, void *stream) {
     if (!e || !sp || !sf || !si || !actions) return fail(MGX_ERR_ARG, "NULL argument");
     if (n_sub < 0) return fail(MGX_ERR_ARG, "negative substep count");
+    ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     int rc = timing_begin(e, 0, st);
     if (rc) return rc;
@@ -550,11 +644,18 @@ int mgx_engine_substeps(mgx_engine *e, void *state_p, void *state_f, int32_t *st
 
 }  // extern "C"
 
+// what both rasteriser entry points need of the world(s) currently loaded
+static int raster_capacity_ok(const mgx_engine *e) {
+    if (e->h.n_prims > 64) return fail(MGX_ERR_CAPACITY, "draw list longer than 64 primitives");
+    if (e->lds_raster > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "draw list does not fit LDS");
+    return MGX_OK;
+}
 template <typename P>
 static int launch_raster(mgx_engine *e, const void *sp, uint8_t *out, int64_t env_stride, int view, int layout, const uint8_t *fill, hipStream_t st) {
     size_t lds = e->lds_raster;
     auto go = [&](auto kern) -> int {
-        if (lds > 65536) HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        struct Tag { char c; };       // (a local type of this generic lambda: one table per instantiation)
+        if (int rc = ensure_lds<Tag>((const void *)kern, lds, e->device)) return rc;
         hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, fill, e->n_envs);
         return MGX_OK;
     };
@@ -578,8 +679,8 @@ int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t 
     if (layout < MGX_OBS_FRAME || layout > MGX_OBS_SLOT_LO) return fail(MGX_ERR_ARG, "bad layout");
     int64_t need = (int64_t)LORES * LORES * (layout == MGX_OBS_FRAME ? 3 : 12);
     if (env_stride < need || (env_stride & 3)) return fail(MGX_ERR_ARG, "env_stride too small or not a multiple of 4");
-    if (e->h.n_prims > 64) return fail(MGX_ERR_CAPACITY, "draw list longer than 64 primitives");
-    if (e->lds_raster > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "draw list does not fit LDS");
+    if (int rc = raster_capacity_ok(e)) return rc;
+    ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     int rc = timing_begin(e, 1, st);
     if (rc) return rc;
@@ -591,9 +692,18 @@ int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t 
 int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_t *out, int view, void *stream) {
     if (!e || !state_p || !out) return fail(MGX_ERR_ARG, "NULL argument");
     if (env < 0 || env >= e->n_envs) return fail(MGX_ERR_ARG, "env index out of range");
+    if (view != MGX_VIEW_EGO && view != MGX_VIEW_ALLO) return fail(MGX_ERR_ARG, "bad view");
+    if (int rc = raster_capacity_ok(e)) return rc;
+    ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     size_t lds = e->lds_raster;
     int blocks = (NATIVE_RES * NATIVE_RES + 255) / 256;
+    {
+        struct TagA { char c; }; struct TagB { char c; };
+        int rc = e->dtype == MGX_F32_PURE ? ensure_lds<TagA>((const void *)k_raster_native<float>, lds, e->device)
+                                          : ensure_lds<TagB>((const void *)k_raster_native<double>, lds, e->device);
+        if (rc) return rc;
+    }
     if (e->dtype == MGX_F32_PURE) hipLaunchKernelGGL((k_raster_native<float>), dim3(blocks), dim3(256), lds, st, e->rdev, (const float *)state_p, out, view, (long)env, e->n_envs);
     else hipLaunchKernelGGL((k_raster_native<double>), dim3(blocks), dim3(256), lds, st, e->rdev, (const double *)state_p, out, view, (long)env, e->n_envs);
     HIP_OK(hipGetLastError());
@@ -617,6 +727,23 @@ int mgx_engine_set_goal_rects(mgx_engine *e, const double *goal_xyhw) {
     e->rdev.goal_xyhw_env = goal_xyhw;
     return MGX_OK;
 }
+int mgx_engine_score_overlaps(mgx_engine *e, const void *state_p, const uint8_t *mask, uint8_t *out, void *stream) {
+    if (!e || !state_p || !out) return fail(MGX_ERR_ARG, "NULL argument");
+    if (e->n_goals == 0) return MGX_OK;
+    ON_DEVICE(e);
+    ScoreDev s{};
+    s.lib = e->d_score_lib; s.ent = e->d_score_ent; s.body_prow = e->d_score_prow; s.goal_ent = e->d_score_goal_ent;
+    s.goal_xyhw = e->d_score_goal_xyhw; s.goal_xyhw_env = e->rdev.goal_xyhw_env;
+    s.ent_type_env = e->d_ent_type_env; s.ent_present_env = e->d_ent_present_env;
+    s.n_entities = (int)e->w.entities.size(); s.n_goals = e->n_goals;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (e->n_envs + 63) / 64;
+    if (e->dtype == MGX_F32_PURE) hipLaunchKernelGGL((k_score<float>), dim3(blocks), dim3(64), 0, st, s, (const float *)state_p, mask, out, e->n_envs);
+    else hipLaunchKernelGGL((k_score<double>), dim3(blocks), dim3(64), 0, st, s, (const double *)state_p, mask, out, e->n_envs);
+    HIP_OK(hipGetLastError());
+    return MGX_OK;
+}
+int mgx_engine_n_goals(const mgx_engine *e) { return e ? e->n_goals : 0; }
 }  // extern "C"
 
 // dst row idx[r] (or r) <- src row r (src_stride 0: the same row for all)
@@ -640,7 +767,7 @@ int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world)
     if (!capacity_world->w.finalized) return fail(MGX_ERR_STATE, "capacity world not finalized");
     if (e->env_worlds) return fail(MGX_ERR_STATE, "per-env worlds already enabled");
     if (capacity_world->w.entities.size() != e->w.entities.size()) return fail(MGX_ERR_ARG, "capacity world must have the engine world's entities");
-    HIP_OK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     WorldBlobs cb, db;
     make_blobs(e->dtype, capacity_world->w, cb);
     make_blobs(e->dtype, e->w, db);
@@ -663,6 +790,18 @@ int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world)
     e->tdev.words = tab_s; e->tdev.tmpl_stride_words = step_stride;
     e->rdev.words = tab_r; e->rdev.tmpl_stride_words = raster_stride;
     e->env_world.assign(e->n_envs, std::shared_ptr<World>());
+    {   // k_score: every env's shape types / presence flags, the engine world's to begin with
+        const int ne = (int)e->w.entities.size();
+        std::vector<int8_t> ty(ne); std::vector<uint8_t> on(ne);
+        for (int i = 0; i < ne; i++) { ty[i] = (int8_t)(e->w.entities[i].kind == 1 ? e->w.entities[i].shape_type : -1); on[i] = e->w.entities[i].enabled ? 1 : 0; }
+        int8_t *d_ty = nullptr; uint8_t *d_on = nullptr;
+        HIP_OK(hipMalloc(&e->d_ent_type_env, (size_t)ne * e->n_envs)); HIP_OK(hipMalloc(&e->d_ent_present_env, (size_t)ne * e->n_envs));
+        HIP_OK(hipMalloc(&d_ty, ne)); HIP_OK(hipMalloc(&d_on, ne));
+        HIP_OK(hipMemcpy(d_ty, ty.data(), ne, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_on, on.data(), ne, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_scatter_ent_rows, dim3(e->n_envs), dim3(64), 0, 0, e->d_ent_type_env, e->d_ent_present_env, d_ty, d_on, (const int32_t *)nullptr, ne, (long)e->n_envs);
+        HIP_OK(hipDeviceSynchronize());
+        (void)hipFree(d_ty); (void)hipFree(d_on);
+    }
     {   // the capacity world itself must be launchable
         int rc = configure_launch(e, (int)cb.step.size(), cb.step_env_stride, (int)cb.raster.size(), cb.raster_scratch_d, cb.raster_n_i);
         if (rc) return rc;
@@ -681,7 +820,7 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     if (!e || !env_idx || m < 0) return fail(MGX_ERR_ARG, "bad argument");
     if (!e->env_worlds) return fail(MGX_ERR_STATE, "call mgx_engine_enable_env_worlds first");
     if (m == 0) return MGX_OK;
-    HIP_OK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     const int ne = (int)e->w.entities.size();
     for (int k = 0; k < m; k++) if (env_idx[k] < 0 || env_idx[k] >= e->n_envs) return fail(MGX_ERR_ARG, "env index out of range");
     // unique signatures of this call; worlds that are still alive are reused
@@ -790,7 +929,21 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     HIP_OK(hipMemcpyAsync(e->d_stage_idx, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_place_blobs, dim3(m), dim3(256), 0, st, e->d_step, (long)e->step_stride, e->d_raster, (long)e->raster_stride, e->d_stage, e->d_stage_idx);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(st));        // the staging buffer and `rows` are read by the copies above
+    // k_score's per-env entity tables (shape type / presence of every entity of these envs)
+    std::vector<int8_t> ent_ty((size_t)m * ne); std::vector<uint8_t> ent_on((size_t)m * ne);
+    for (int k = 0; k < m; k++) {
+        const std::string &sig = uniq[which[k]].sig;
+        for (int i = 0; i < ne; i++) { ent_on[(size_t)k * ne + i] = (uint8_t)sig[i]; ent_ty[(size_t)k * ne + i] = (int8_t)(e->w.entities[i].kind == 1 ? (int)sig[ne + i] - 1 : -1); }
+    }
+    int8_t *d_ty = nullptr; uint8_t *d_on = nullptr; int32_t *d_idx = nullptr;
+    HIP_OK(hipMalloc(&d_ty, ent_ty.size())); HIP_OK(hipMalloc(&d_on, ent_on.size())); HIP_OK(hipMalloc(&d_idx, (size_t)m * 4));
+    HIP_OK(hipMemcpyAsync(d_ty, ent_ty.data(), ent_ty.size(), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_on, ent_on.data(), ent_on.size(), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_idx, env_idx, (size_t)m * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_scatter_ent_rows, dim3(m), dim3(64), 0, st, e->d_ent_type_env, e->d_ent_present_env, d_ty, d_on, (const int32_t *)d_idx, ne, (long)e->n_envs);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));        // the staging buffer, `rows` and the entity rows are read by the copies above
+    (void)hipFree(d_ty); (void)hipFree(d_on); (void)hipFree(d_idx);
     std::vector<std::shared_ptr<World>> retired(m);      // the envs' previous worlds: freed below, a few threads wide
     for (int k = 0; k < m; k++) {
         const int env = env_idx[k];
@@ -858,6 +1011,7 @@ int mgx_engine_set_timing(mgx_engine *e, int enable) {
 }
 int mgx_engine_timing_read(mgx_engine *e, int which, float *ms, int max) {
     if (!e || !ms || which < 0 || which > 1) return fail(MGX_ERR_ARG, "bad argument");
+    ON_DEVICE(e);
     int n = e->ev_count[which] < TIMING_RING ? e->ev_count[which] : TIMING_RING;
     if (n > max) n = max;
     int first = e->ev_count[which] - n;

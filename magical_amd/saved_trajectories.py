@@ -5,8 +5,8 @@ The reference's demonstrations (`magical-data`, `.pkl.gz`) are gzip'ed pickles o
 observations `obs = {'allo': u8[T + 1, 384, 384, 3], 'ego': ...}` (saved_trajectories.py:14-47).  This module
 
   * reads them (`load_demos`, :36-47) without the `magical` / `imitation` packages: the trajectory class is found under
-    every module path the reference's own unpickler accepts (:24-33) plus the reference's own, and nothing else than
-    numpy arrays and builtin containers is allowed to unpickle;
+    every module path the reference's own unpickler accepts (:24-33) plus the reference's own; apart from those, only an
+    explicit allow-list of (module, name) pairs -- numpy array / scalar / dtype reconstruction, builtin containers -- may unpickle;
   * applies a preprocessor to the recorded frames (`preprocess_demos_with_wrapper`, :81-149) -- what the reference
     does by replaying the frames through its gym wrappers: FlattenFrameStack / EagerDictFrameStack + a 384 -> 96
     INTER_AREA resize (benchmarks/__init__.py:80-136,139-169,208-274), i.e. for every step the exact 4x4 box mean of
@@ -36,17 +36,25 @@ class MAGICALTrajectory(NamedTuple):
 
 _TRAJ_CLASSES = {('magical.saved_trajectories', 'MAGICALTrajectory'), ('imitation.util.rollout', 'Trajectory'),
                  ('milbench.baselines.saved_trajectories', 'MILBenchTrajectory'), (__name__, 'MAGICALTrajectory')}
-_SAFE_PREFIXES = ('numpy', 'builtins', 'collections', 'copyreg', '_codecs')
+# everything else a demo file may reference, by exact (module, name): what numpy arrays / scalars / dtypes and builtin
+# containers pickle to (numpy >= 1.x `numpy.core`, numpy 2 `numpy._core`; `_codecs.encode` rebuilds the byte strings of
+# protocol-2 array pickles).  No prefixes: `numpy.testing`, `numpy.distutils`, `builtins.eval` ... are all refused.
+_ALLOWED_GLOBALS = {(m, n) for m in ('numpy.core.multiarray', 'numpy._core.multiarray') for n in ('_reconstruct', 'scalar')} | {
+    ('numpy.core.numeric', '_frombuffer'), ('numpy._core.numeric', '_frombuffer'), ('numpy', 'ndarray'), ('numpy', 'dtype'),
+    ('collections', 'OrderedDict'), ('_codecs', 'encode'), ('copyreg', '_reconstructor'),
+} | {('builtins', n) for n in ('dict', 'list', 'tuple', 'set', 'frozenset', 'int', 'float', 'complex', 'str', 'bytes', 'bytearray',
+                               'bool', 'slice', 'range', 'object')}
 
 
 class _TrajRewriteUnpickler(pickle.Unpickler):
-    """saved_trajectories.py:24-33, restricted: trajectory classes map to MAGICALTrajectory, numpy / builtin containers
-    load as they are, anything else is refused (a demo file holds nothing else)."""
+    """saved_trajectories.py:24-33, restricted: trajectory classes map to MAGICALTrajectory; the globals on the explicit
+    allow-list above (numpy array / scalar / dtype reconstruction, builtin containers) load as they are; anything else is
+    refused (a demo file holds nothing else)."""
 
     def find_class(self, module, name):
         if (module, name) in _TRAJ_CLASSES:
             return MAGICALTrajectory
-        if module.split('.')[0] in _SAFE_PREFIXES and not (module == 'builtins' and name in ('eval', 'exec', 'compile', 'open', '__import__', 'getattr')):
+        if (module, name) in _ALLOWED_GLOBALS:
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f'demo files may not reference {module}.{name}')
 

@@ -7,7 +7,7 @@ amplify 1e-16 perturbations to 1e-3 within ~20 env-steps).
 import numpy as np
 import pytest
 
-from tests.util import (EPS_F32, EPS_F64, TASKS, OracleEnvelope, comparable_mask, masked_err, new_ref, perturb_bodies, quantiles, ref_body_index,
+from tests.util import (EPS_F32, EPS_F64, F32_OPS_FACTOR, TASKS, OracleEnvelope, comparable_mask, masked_err, new_ref, perturb_bodies, quantiles, ref_body_index,
                         velround_step)
 
 pytestmark = pytest.mark.gpu
@@ -74,7 +74,7 @@ def test_f32_engine_one_step_error(task):
         median stays within 10x the replica's."""
     n, t = 32, 40
     tape = _tape(5, t, n)
-    env = _make(f'{task}-Demo-v0', n)
+    env = _make(f'{task}-Demo-v0', n, max_episode_steps=1000)
     env.reset()
     refs = [new_ref(task) for _ in range(n)]
     pert = [new_ref(task) for _ in range(n)]
@@ -103,7 +103,7 @@ def test_f32_engine_one_step_error(task):
     print(f'{task}: one-step pose error  median / p90 / p99 / max')
     for name, x in (('engine (fp32)', errs), ('oracle, poses +-1e-7', env_p), ('oracle, fp32 velocity state', env_v)):
         print(f'  {name:28s} ' + ' / '.join(f'{v:.2e}' for v in pc(x)))
-    assert np.median(errs) <= 10 * np.median(env_v)
+    assert np.median(errs) <= F32_OPS_FACTOR * np.median(env_v)
     assert np.percentile(errs, 90) <= 2 * np.percentile(env_p, 90) and np.percentile(errs, 99) <= 2 * np.percentile(env_p, 99)
     env.close()
 
@@ -141,7 +141,7 @@ def test_f32_drift_within_perturbation_envelope(task):
         (m, p), (em, ep) = quantiles(drift[s - 1]), quantiles(spread[s - 1])
         print(f'  {s:3d} (substep {10 * s:4d}) | {m:.2e} / {p:.2e} | {em:.2e} / {ep:.2e}')
         assert m <= 2 * em and p <= 2 * ep, (task, s, m, p, em, ep)
-    assert np.median(drift[0]) <= 10 * np.median(v1), (task, np.median(drift[0]), np.median(v1))
+    assert np.median(drift[0]) <= F32_OPS_FACTOR * np.median(v1), (task, np.median(drift[0]), np.median(v1))
     assert int(env.state_i[2].sum()) == 0
     env.close()
 
@@ -501,7 +501,8 @@ def test_pose_randomisation_matches_oracle(task, variant, flags, dtype):
         return r
     refs = [LoRes4ERef(RefEnv(task, max_episode_steps=ep, seed=seed + k, **flags)) for k in range(n)]
     first = [r.reset() for r in refs]
-    orc = OracleEnvelope([lambda k=k: mk(k) for k in range(n)], K=8, eps=EPS_F64 if f64 else EPS_F32, seed=4, base=[r.env for r in refs])
+    orc = OracleEnvelope([lambda k=k: mk(k) for k in range(n)], K=8, eps=EPS_F64 if f64 else EPS_F32, seed=4, base=[r.env for r in refs], fp32_state=not f64)
+    factor = 2.0 if f64 else F32_OPS_FACTOR
     idx = ref_body_index(refs[0].env)
     mask = comparable_mask(refs[0].env)
     def check_reset(obs_now, firsts):
@@ -530,7 +531,7 @@ def test_pose_randomisation_matches_oracle(task, variant, flags, dtype):
         # rounding only in most envs -- at some drawn robot angles the device's and libm's sin / cos differ in the last bit,
         # the finger roots' zero-length pins start 1e-17 apart in another direction and the reference dynamics amplify
         # that within the step: exactly what they do to the replicas
-        assert (errs <= 2 * orc.running + 1e-12).all(), (task, dtype, s, errs, orc.running)
+        assert (errs <= factor * orc.running + 1e-12).all(), (task, dtype, s, errs, orc.running)
         if s % ep == 0 and f64:
             assert np.median(errs) < 1e-8, (task, s, errs)
     env.close()
@@ -563,8 +564,9 @@ def test_per_env_worlds_match_oracle(task, variant, flags, dtype):
     own stream (e.g. cluster.py:81-110, match_regions.py:101-117) and runs in its own world (`k_step<R, P, 64>`, one env per
     wavefront).  Same draws as the oracle's restatement of the reference's on_reset -> the same entities (compared slot by
     slot), identical first observations (bit-exact: shapes, colours, counts and poses all show in the frame), identical
-    scores (fp64 build); the engine stays as close to the oracle as the oracle's own perturbed replicas do (8 per env, 1e-13
-    for the all-fp64 build, 1e-7 for the shipped fp32 build); the second episode draws again."""
+    scores (fp64 build); the engine stays as close to the oracle as the oracle's own perturbed replicas do (8 per env: the
+    all-fp64 build within 2x of replicas perturbed by 1e-13, the shipped build within tests.util.F32_OPS_FACTOR of replicas
+    perturbed by 1e-7 that store fp32 velocities); the second episode draws again."""
     from oracle.env_ref import LoRes4ERef, RefEnv
     from oracle.entities_ref import GoalRegion as RefGoal
     import os
@@ -579,7 +581,8 @@ def test_per_env_worlds_match_oracle(task, variant, flags, dtype):
         return r
     refs = [LoRes4ERef(RefEnv(task, max_episode_steps=ep, seed=seed + k, **flags)) for k in range(n)]
     first = [r.reset() for r in refs]
-    orc = OracleEnvelope([lambda k=k: mk(k) for k in range(n)], K=8, eps=EPS_F64 if f64 else EPS_F32, seed=5, base=[r.env for r in refs])
+    orc = OracleEnvelope([lambda k=k: mk(k) for k in range(n)], K=8, eps=EPS_F64 if f64 else EPS_F32, seed=5, base=[r.env for r in refs], fp32_state=not f64)
+    factor = 2.0 if f64 else F32_OPS_FACTOR
     ents = env._entities
     def compare(bound, what, typical=None):
         poses = env.get_poses()
@@ -619,7 +622,7 @@ def test_per_env_worlds_match_oracle(task, variant, flags, dtype):
             continue
         # rounding only for the typical body; a random layout may start with a finger against a block or a wall, where the
         # reference dynamics amplify a rounding to ~1e-4 within one env-step -- in the replicas too
-        compare(2 * orc.running + 1e-12, f'step {s}', typical=1e-8 if (f64 and s % ep == 0) else None)
+        compare(factor * orc.running + 1e-12, f'step {s}', typical=1e-8 if (f64 and s % ep == 0) else None)
     env.close()
 
 
@@ -961,3 +964,159 @@ def test_large_batches_of_small_worlds_run_eight_lanes_per_env():
         env = _make(name, n)
         assert env.lanes_per_env == 16
         env.close()
+
+
+@pytest.mark.gpu
+def test_capacity_overflow_is_surfaced_at_episode_end():
+    """The device counts contacts / pairs that did not fit an env's working set (state_i[2]); step() reports the counters of
+    the envs whose episode ends: MgxCapacityWarning by default, MgxError with strict_capacity=True.  (No Demo or Test world
+    overflows -- tools/stress_all_tasks.py -- so the counter is planted.)"""
+    import warnings
+    from magical_amd._native import MgxCapacityWarning, MgxError
+    env = _make('MoveToCorner-Demo-v0', 4, max_episode_steps=2)
+    env.reset()
+    a = np.zeros(4, dtype=np.int32)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        env.step(a); env.step(a)                       # a clean episode end: no warning
+    env.state_i[2, 1] = 3
+    env.step(a)
+    with pytest.warns(MgxCapacityWarning):
+        env.step(a)
+    assert env.capacity_overflows == 3
+    assert int(env.state_i[2].sum()) == 0              # the reset cleared it
+    env.close()
+    env = _make('MoveToCorner-Demo-v0', 4, max_episode_steps=1, strict_capacity=True)
+    env.reset()
+    env.state_i[2, 2] = 1
+    with pytest.raises(MgxError):
+        env.step(a)
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('preproc', ['LoRes4E', 'LoResCHW4E', 'LoResStack'])
+def test_copy_obs_hands_out_fresh_tensors(preproc):
+    """Default: step() returns the engine's persistent frame stack (documented aliasing); copy_obs=True returns a clone per call,
+    like the reference's fresh array per step (benchmarks/__init__.py:80-136), so collected observations stay distinct."""
+    import torch
+    a = np.full(2, 4, dtype=np.int32)
+    first = lambda o: o['ego'] if isinstance(o, dict) else o
+    env = _make(f'MoveToCorner-Demo-{preproc}-v0', 2)
+    o0 = first(env.reset()); o1 = first(env.step(a)[0])
+    assert o0.data_ptr() == o1.data_ptr()
+    env.close()
+    env = _make(f'MoveToCorner-Demo-{preproc}-v0', 2, copy_obs=True)
+    kept = [first(env.reset())] + [first(env.step(a)[0]) for _ in range(3)]
+    assert len({o.data_ptr() for o in kept}) == 4
+    assert not torch.equal(kept[0], kept[3])
+    # the kept copies are the observations of their own steps: frame t of copy k+1 == frame t+1 of copy k
+    ch = 1 if preproc == 'LoResCHW4E' else 3
+    for k in range(3):
+        older, newer = kept[k].movedim(ch, 3) if ch == 1 else kept[k], kept[k + 1].movedim(ch, 3) if ch == 1 else kept[k + 1]
+        assert torch.equal(older[..., 3:], newer[..., :9])
+    env.close()
+
+
+def _scatter_blocks(env, rs, near_edges=0.5):
+    """Random poses for every block (and the robot) of every env: uniform over the arena, or close to an edge of one of the env's
+    goal rectangles (where the overlap tests decide)."""
+    from magical_amd import entities as en
+    n = env.n_envs
+    b = env.get_bodies()
+    goals = env.goal_xyhw                                        # [N, n_goals, 4] x, y (top-left), h, w
+    for ent in env._entities:
+        if not isinstance(ent, (en.Shape, en.Robot)):
+            continue
+        xy = rs.uniform(-0.95, 0.95, size=(n, 2))
+        if goals.shape[1]:
+            g = goals[np.arange(n), rs.randint(goals.shape[1], size=n)]
+            cx, cy = g[:, 0] + g[:, 3] / 2, g[:, 1] - g[:, 2] / 2
+            # a point on the rectangle's outline, pushed in or out by up to 1.5 block radii
+            side = rs.randint(4, size=n)
+            u = rs.uniform(-1, 1, size=n)
+            px = np.where(side < 2, cx + (side * 2 - 1) * g[:, 3] / 2, cx + u * g[:, 3] / 2)
+            py = np.where(side < 2, cy + u * g[:, 2] / 2, cy + ((side - 2) * 2 - 1) * g[:, 2] / 2)
+            off = rs.uniform(-0.18, 0.18, size=(n, 2))
+            near = rs.rand(n) < near_edges
+            xy = np.where(near[:, None], np.stack([px, py], axis=1) + off, xy)
+        b[:, ent.body, 0], b[:, ent.body, 1] = xy[:, 0], xy[:, 1]
+        b[:, ent.body, 2] = rs.uniform(-np.pi, np.pi, size=n)
+    env.set_bodies(b)
+
+
+@pytest.mark.parametrize('name,n', [('MatchRegions-Demo-v0', 8192), ('FindDupe-Demo-v0', 8192), ('FixColour-Demo-v0', 8192), ('MoveToRegion-Demo-v0', 8192),
+                                    ('FixColour-TestLayout-v0', 2048), ('MatchRegions-TestAll-v0', 2048), ('FindDupe-TestCountPlus-v0', 2048),
+                                    ('FixColour-TestAll-v0', 1024)])
+def test_k_score_equals_host_overlap_sets(name, n):
+    """mgx_engine_score_overlaps (k_score) against the host restatement of GoalRegion.get_overlapping_ents
+    (benchmarks/_scoring.overlapping_ents, the bit-exact-vs-oracle reference of round 1) on random poses -- > 10^5 (region, block,
+    env) triples over the Demo cases, half of them within 1.5 block radii of a region's outline -- including per-env rectangles
+    (TestLayout), per-env worlds (shape types, absent blocks and regions: TestAll / TestCountPlus); and the scores computed from
+    the device's sets equal the scores computed from downloaded poses."""
+    from magical_amd import entities as en
+    from magical_amd.benchmarks._scoring import overlapping_ents
+    env = _make(name, n, dtype='f32')
+    env.seed(11)
+    env.reset()
+    rs = np.random.RandomState(5)
+    _scatter_blocks(env, rs)
+    flags = env.region_overlaps()                                # [n_goals, n_entities, N]
+    poses = env.get_poses()
+    env._scoring_envs = np.arange(n)
+    blocks = [e for e in env._entities if isinstance(e, en.Shape)]
+    goals = [e for e in env._entities if isinstance(e, en.GoalRegion)]
+    n_true = 0
+    for g, goal in enumerate(goals):
+        want = overlapping_ents(env, goal, blocks, poses) if blocks else np.zeros((n, 0), dtype=bool)
+        if env.variable_worlds:                                  # a region the episode does not have holds nothing
+            want &= env.entity_enabled[:, goal.ent_id][:, None]
+        got = (flags[g][[e.ent_id for e in blocks]] == 3).T
+        assert np.array_equal(got, want), (name, g, int((got != want).sum()))
+        n_true += int(want.sum())
+        # bit 0 alone: the body position inside the box, for every entity with a body
+        l, b, r, t = env.goal_bb(goal)
+        for e in blocks + [env._robot]:
+            x, y = poses[:, e.body, 0], poses[:, e.body, 1]
+            inside = (l <= x) & (r >= x) & (b <= y) & (t >= y)
+            if env.variable_worlds:
+                inside &= env.entity_enabled[:, e.ent_id] & env.entity_enabled[:, goal.ent_id]
+            assert np.array_equal((flags[g, e.ent_id] & 1).astype(bool), inside), (name, g, e.ent_id)
+    assert not blocks or n_true > n // 20, n_true                # the sets are not trivially empty
+    # the task's score from the device's sets == from the poses
+    from_poses = env.score_on_end_of_traj(poses)
+    env._overlap = flags
+    assert np.array_equal(env.score_on_end_of_traj(None), from_poses), name
+    assert len(np.unique(from_poses)) > 1
+    env.close()
+
+
+@pytest.mark.parametrize('task', ['MatchRegions', 'FindDupe', 'FixColour'])
+def test_k_score_equals_oracle_overlap_sets(task):
+    """... and against the oracle's own get_overlapping_ents (its GJK / EPA shape queries) on the same random poses."""
+    from magical_amd import entities as en
+    n = 192
+    env = _make(f'{task}-Demo-v0', n)
+    env.reset()
+    _scatter_blocks(env, np.random.RandomState(8), near_edges=0.7)
+    flags = env.region_overlaps()
+    poses = env.get_poses()
+    ref = new_ref(task)
+    idx = ref_body_index(ref)
+    ref_blocks = [e for e in ref.world.entities if hasattr(e, 'shape_body')]
+    ref_goals = [e for e in ref.world.entities if hasattr(e, 'get_overlapping_ents')]
+    blocks = [e for e in env._entities if isinstance(e, en.Shape)]
+    assert len(blocks) == len(ref_blocks) and len(ref_goals) == flags.shape[0]
+    hits = 0
+    for k in range(n):
+        b = ref.bodies()
+        b[idx, :3] = poses[k, 1:, :]
+        ref.set_bodies(b)
+        for g, goal in enumerate(ref_goals):
+            inside = goal.get_overlapping_ents(ref_blocks)
+            want = [e in inside for e in ref_blocks]
+            got = [(flags[g, e.ent_id, k] == 3) for e in blocks]
+            assert got == want, (task, k, g)
+            hits += sum(want)
+    assert hits > n // 4
+    env.close()

@@ -50,6 +50,15 @@ def test_load_demos_reads_reference_pickles_and_refuses_anything_else(tmp_path):
         pickle.dump({'trajectory': os.path.join}, fp)
     with pytest.raises(pickle.UnpicklingError):
         list(st.load_demos([evil]))
+    # globals inside the packages a demo legitimately uses are refused too: the allow-list is by exact (module, name)
+    import builtins
+    import numpy.testing
+    for k, obj in enumerate((numpy.testing.assert_equal, builtins.setattr, builtins.map, builtins.breakpoint, np.load, np.fromfile)):
+        bad = str(tmp_path / f'evil-{k}.pkl.gz')
+        with gzip.GzipFile(bad, 'wb') as fp:
+            pickle.dump({'trajectory': obj}, fp)
+        with pytest.raises(pickle.UnpicklingError):
+            list(st.load_demos([bad]))
     assert st.splice_in_preproc_name('MoveToCorner-Demo-v0', 'LoResStack') == 'MoveToCorner-Demo-LoResStack-v0'
     with pytest.raises(AssertionError):
         st.splice_in_preproc_name('MoveToCorner-Demo-v0', 'NoSuchPreproc')

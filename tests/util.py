@@ -55,6 +55,10 @@ def new_ref(task):
 # vector), so "pose error vs the oracle" only means something next to the oracle's own spread.
 EPS_F32 = 1e-7      # one fp32 rounding of a unit-scale quantity (2^-24 = 6e-8), the shipped engine's resolution
 EPS_F64 = 1e-13     # a few hundred fp64 roundings: what an all-fp64 engine differs from the oracle by (libm, FMA contraction)
+# Per-env bounds for the shipped fp32 build use replicas that are perturbed by EPS_F32 AND store their velocities in fp32
+# (one rounding per substep); the engine rounds each of the ~100 operations a velocity goes through per substep (10
+# iterations x ~10 constraint rows), a random walk ~sqrt(100) = 10 times wider: that factor, not a tuned constant.
+F32_OPS_FACTOR = 10.0
 
 
 def perturb_bodies(ref_env, eps, rs):
@@ -74,10 +78,11 @@ class OracleEnvelope:
     (poses[n, n_dyn, 3] of the unperturbed envs, spread[n]) with spread[k] = the largest pose deviation of env k's replicas
     from env k after this step; `running` keeps the maximum over the steps of the episode (a bound that only widens).
     `factories` build an env ready to step (already reset); `base` = the caller's own unperturbed envs (then the caller
-    steps them, and step() only reads their poses)."""
+    steps them, and step() only reads their poses).  fp32_state: the replicas also keep their velocity state in fp32
+    (velround_step): the shipped engine's storage format, i.e. rounding noise that keeps coming, not just an initial offset."""
 
-    def __init__(self, factories, K, eps, seed=0, base=None):
-        self.own_base = base is None
+    def __init__(self, factories, K, eps, seed=0, base=None, fp32_state=False):
+        self.own_base, self.fp32_state = base is None, fp32_state
         self.base = [f() for f in factories] if base is None else list(base)
         self.rs, self.eps = np.random.RandomState(seed), eps
         self.reps = [[f() for _ in range(K)] for f in factories]
@@ -105,7 +110,10 @@ class OracleEnvelope:
             w = r.bodies()[idx][:, :3]
             want.append(w)
             for q in self.reps[k]:
-                q.step(actions[k])
+                if self.fp32_state:
+                    velround_step(q, actions[k])
+                else:
+                    q.step(actions[k])
                 self.all.append(masked_err(q.bodies()[idx][:, :3], w, comparable_mask(r)))
                 now[k] = max(now[k], self.all[-1])
         self.running = np.maximum(self.running, now)
