@@ -94,11 +94,12 @@ class FixColourEnv(BaseEnv):
         self.add_entities([robot])
 
     def score_on_end_of_traj(self, poses):   # fix_colour.py:193-202: list(overlap_ents) == expected, per region
-        complete = np.ones(poses.shape[0], dtype=bool)
-        keep = np.tile(np.asarray(self._keep, dtype=bool), (poses.shape[0], 1)) if self._keep_env is None else self._keep_env[self._scoring_envs]
+        M = len(self._scoring_envs) if poses is None else poses.shape[0]      # poses None: the overlap sets come from the device
+        complete = np.ones(M, dtype=bool)
+        keep = np.tile(np.asarray(self._keep, dtype=bool), (M, 1)) if self._keep_env is None else self._keep_env[self._scoring_envs]
         for k, sensor in enumerate(self._sensors):
             ov = overlapping_ents(self, sensor, self._blocks, poses)
-            expected = np.zeros((poses.shape[0], len(self._blocks)), dtype=bool)
+            expected = np.zeros((M, len(self._blocks)), dtype=bool)
             expected[:, k] = keep[:, k]
             ok = (ov == expected).all(axis=1)
             if self.variable_worlds:              # a region the episode does not have asks for nothing
