@@ -199,6 +199,17 @@ int mgx_engine_score_overlaps(mgx_engine *e, const void *state_p, const uint8_t 
 int mgx_engine_n_goals(const mgx_engine *e);
 int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t env_stride, int view, int layout,
                       const uint8_t *fill_mask, void *stream);
+/* BaseEnv.step() physics + its observation in ONE call (base_env.py:255-292 with the wrappers of
+ * benchmarks/__init__.py:80-136,219-256): = mgx_engine_step followed by mgx_engine_render(fill_mask = NULL) on the same
+ * buffers, same results bit for bit, but issued as a producer / consumer pair: the step kernel publishes every env whose
+ * state it has written back, and the raster kernel -- on a stream of the engine's own, joined to `stream` before and after --
+ * rasterises envs in the order they finish, so the long tail of the physics (a few envs with many contacts) runs under the
+ * rasterisation of the others.  Not for steps in which envs are reset between physics and rendering (episode ends:
+ * use the two calls).  Falls back to the two calls in sequence where the producers would not all be resident at once. */
+int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const int32_t *actions, uint8_t *done,
+                           uint8_t *out, int64_t env_stride, int view, int layout, void *stream);
+/* diagnostics of the hand-off (synchronises): consumer workgroups that gave up and were served by the clean-up launch */
+int mgx_engine_handoff_stats(mgx_engine *e, unsigned *deferred, unsigned *timeouts);
 /* native-resolution (384x384x3, no box filter) render of ONE env, for tests against the oracle/images */
 int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_t *out, int view, void *stream);
 /* HIP-event timing: set_timing(e, n) with n > 0 brackets every n-th step (which=0) / render (which=1) launch with

@@ -10,7 +10,7 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, 'csrc')
-LIB_PATH = os.path.join(_PKG, 'libmagical_hip.so')
+LIB_PATH = os.environ.get('MGX_LIB_PATH') or os.path.join(_PKG, 'libmagical_hip.so')      # (override: development builds with other -D knobs)
 _SOURCES = ['mgx_api.hip', 'mgx_world.cpp']
 _DEPS = _SOURCES + ['mgx_step.hip', 'mgx_raster.hip', 'mgx_score.hip', 'mgx_sim.h', 'mgx_raster.h', 'mgx_tmpl.h', 'mgx_world.h']
 
@@ -38,16 +38,16 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(_CSRC, f)) > t for f in _DEPS)
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
-    if not force and not needs_build():
+def build(force=False, verbose=False, defines=(), out=None):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  defines / out: development builds with other -D knobs."""
+    if not force and not defines and not needs_build():
         return LIB_PATH
-    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-Wno-unused-parameter', '-pthread', '-o', LIB_PATH] + [os.path.join(_CSRC, f) for f in _SOURCES]
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-parameter', '-Wno-extern-c-compat',
+           '-pthread', '-o', out or LIB_PATH] + [f'-D{d}' for d in defines] + [os.path.join(_CSRC, f) for f in _SOURCES]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)
-    return LIB_PATH
+    return out or LIB_PATH
 
 
 _lib = None
@@ -108,6 +108,8 @@ def lib():
         'mgx_engine_step': [vp, vp, vp, vp, vp, vp, vp],
         'mgx_engine_substeps': [vp, vp, vp, vp, vp, i32, vp],
         'mgx_engine_render': [vp, vp, vp, i64, i32, i32, vp, vp],
+        'mgx_engine_step_render': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+        'mgx_engine_handoff_stats': [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)],
         'mgx_engine_render_native': [vp, vp, i32, vp, i32, vp],
         'mgx_engine_set_timing': [vp, i32],
         'mgx_engine_timing_read': [vp, i32, C.POINTER(C.c_float), i32],
@@ -138,6 +140,6 @@ EXPORTED_SYMBOLS = [
     'mgx_engine_create', 'mgx_engine_destroy', 'mgx_engine_set_entity_colours', 'mgx_engine_set_goal_rects', 'mgx_engine_score_overlaps', 'mgx_engine_n_goals',
     'mgx_world_variant', 'mgx_engine_enable_env_worlds', 'mgx_engine_set_env_variants', 'mgx_engine_env_randomise_all_poses_batch', 'mgx_engine_env_world_info',
     'mgx_engine_state_shape', 'mgx_engine_lanes_per_env', 'mgx_engine_lds_bytes', 'mgx_engine_reset', 'mgx_engine_reset_poses',
-    'mgx_engine_step', 'mgx_engine_substeps', 'mgx_engine_render', 'mgx_engine_render_native',
+    'mgx_engine_step', 'mgx_engine_substeps', 'mgx_engine_render', 'mgx_engine_step_render', 'mgx_engine_handoff_stats', 'mgx_engine_render_native',
     'mgx_engine_set_timing', 'mgx_engine_timing_read',
 ]

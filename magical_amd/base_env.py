@@ -80,7 +80,7 @@ class BaseEnv(abc.ABC):
 
     def __init__(self, *, n_envs=1, device='cuda:0', res_hw=(384, 384), fps=8, phys_steps=10, phys_iter=10,
                  max_episode_steps=None, rand_dynamics=False, ego_view=True, allo_view=True,
-                 dtype='f32', lanes_per_env=0, auto_reset=True, copy_obs=False, strict_capacity=False):
+                 dtype='f32', lanes_per_env=0, auto_reset=True, copy_obs=False, strict_capacity=False, overlap=True):
         import torch
         if fps != 8 or phys_steps != 10 or phys_iter != 10:
             raise NotImplementedError('the engine is built for the registered rates: fps=8, 10 substeps, 10 iterations '
@@ -95,6 +95,8 @@ class BaseEnv(abc.ABC):
             raise nat.MgxError('magical_amd runs on an MI355X (torch device "cuda:N"); there is no CPU fallback')
         if self.device.index is None:      # 'cuda' = torch's current device, pinned now (the engine lives on one GPU)
             self.device = torch.device('cuda', torch.cuda.current_device())
+        self.overlap = bool(overlap)       # step(): physics + observation as a producer / consumer kernel pair (mgx_engine_step_render)
+        self._obs_ready = False
         self.capacity_overflows = 0        # contacts / overlapping pairs the fixed-size working set dropped (see step())
         self.dtype_name = dtype
         self._dtype = {'f32': nat.MGX_F32, 'f64': nat.MGX_F64, 'f32_pure': nat.MGX_F32_PURE}[dtype]
@@ -279,9 +281,20 @@ class BaseEnv(abc.ABC):
             actions = torch.as_tensor(np.asarray(actions), device=self.device)
         actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
         assert actions.shape == (self.n_envs,)
-        nat.check(self._lib.mgx_engine_step(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
-                                            self.state_i.data_ptr(), actions.data_ptr(), self._done_dev.data_ptr(),
-                                            self._stream()))
+        # a step in which no episode ends (nothing is reset between the physics and the rendering) and whose observation is one
+        # rasteriser pass goes out as ONE fused call: the raster kernel consumes envs as the step kernel finishes them
+        ends = self.max_episode_steps is not None and bool((self._steps + 1 >= self.max_episode_steps).any())
+        target = None if (ends or not self.overlap) else self._fused_target()
+        if target is None:
+            nat.check(self._lib.mgx_engine_step(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
+                                                self.state_i.data_ptr(), actions.data_ptr(), self._done_dev.data_ptr(),
+                                                self._stream()))
+        else:
+            out, view, layout = target
+            nat.check(self._lib.mgx_engine_step_render(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
+                                                       self.state_i.data_ptr(), actions.data_ptr(), self._done_dev.data_ptr(),
+                                                       out.data_ptr(), out.stride(0), view, layout, self._stream()))
+            self._obs_ready = True
         self._steps += 1
         done = np.zeros(self.n_envs, dtype=bool)
         eval_score = np.zeros(self.n_envs, dtype=np.float64)
@@ -529,6 +542,17 @@ class BaseEnv(abc.ABC):
         """Space of ONE env's observation.  Without a preprocessor that is this engine's state-only observation; the
         reference's Dict{'allo','ego': Box(0,255,(384,384,3),u8)} (base_env.py:97-107) is what `render()` returns."""
         return spaces.Box(-np.inf, np.inf, (self.n_bodies, 3), np.float32)
+
+    def _fused_target(self):
+        """(tensor, view, layout) of the single rasteriser pass that makes this env's observation, or None (state-only
+        observation, or a preprocessor that renders two views)."""
+        return None
+
+    def handoff_stats(self):
+        """(deferred, timeouts) of the fused step: consumer workgroups that did not wait and were served by the clean-up launch."""
+        d, t = C.c_uint(), C.c_uint()
+        nat.check(self._lib.mgx_engine_handoff_stats(self._engine, C.byref(d), C.byref(t)))
+        return d.value, t.value
 
     def _observe(self, fill_all=False, fill_mask=None):
         """Default (no preprocessor): state-only observation f32[N, n_bodies, 3] = (x, y, angle)."""

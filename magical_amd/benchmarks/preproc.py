@@ -46,7 +46,16 @@ def wrap_preproc(env_cls, preproc):
             box = spaces.Box(0, 255, (12, 96, 96) if preproc == 'LoResCHW4E' else (96, 96, 12), 'uint8')
             return spaces.Dict([('allo', box), ('ego', box)]) if preproc == 'LoResStack' else box
 
+        def _fused_target(self):
+            from .. import _native as nat
+            if preproc in ('LoRes3EA', 'LoResStack'):
+                return None
+            return self._stack, (nat.VIEW_ALLO if preproc == 'LoRes4A' else nat.VIEW_EGO), nat.OBS_STACK4
+
         def _observe(self, fill_all=False, fill_mask=None):
+            if self._obs_ready:            # this step's frame is already in the stack (fused step + render)
+                self._obs_ready = False
+                return self._stack.permute(0, 3, 1, 2) if preproc == 'LoResCHW4E' else self._stack
             if fill_all:
                 fill_mask = self._ones
             if preproc == 'LoRes3EA':

@@ -102,6 +102,10 @@ struct mgx_engine {
     double *d_score_goal_xyhw = nullptr;
     int8_t *d_ent_type_env = nullptr; uint8_t *d_ent_present_env = nullptr;
     int n_goals = 0;
+    // step -> raster hand-off (mgx_engine_step_render): second stream + events, the queue of finished envs and its counters
+    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned long long *d_queue = nullptr; unsigned *d_hand = nullptr, *d_deferred = nullptr;   // d_hand: tail, started, stats[2]
+    unsigned hand_tail = 0, hand_started = 0, hand_epoch = 0;                                    // host mirrors of the monotonic counters
     int timing = 0;             // 0 = off, n = bracket every n-th launch of each kind with HIP events
     int launch_count[2] = {0, 0};
     int dbg_iterations = -1;    // development probe: override the solver iteration count
@@ -441,27 +445,28 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
 
 template <typename R, typename P, int L>
 static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const int32_t *actions, uint8_t *done, int n_sub,
-                         int count_step, hipStream_t st) {
+                         int count_step, hipStream_t st, const StepHandoff &ho) {
     auto kern = k_step<R, P, L>;
     size_t lds = step_lds_bytes(e, L);
     struct Tag { char c; };
     if (int rc = ensure_lds<Tag>((const void *)kern, lds, e->device)) return rc;
     int epb = 64 / L, blocks = (e->n_envs + epb - 1) / epb;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, st, e->tdev, (P *)sp, (R *)sf, si, actions, done, e->n_envs, n_sub,
-                       count_step, e->dbg_iterations >= 0 ? e->dbg_iterations : PHYS_ITER);
+                       count_step, e->dbg_iterations >= 0 ? e->dbg_iterations : PHYS_ITER, ho);
     HIP_OK(hipGetLastError());
     return MGX_OK;
 }
+static int step_blocks(const mgx_engine *e) { const int epb = 64 / e->L; return (e->n_envs + epb - 1) / epb; }
 template <typename R, typename P>
 static int launch_step(mgx_engine *e, void *sp, void *sf, int32_t *si, const int32_t *actions, uint8_t *done, int n_sub,
-                       int count_step, hipStream_t st) {
+                       int count_step, hipStream_t st, const StepHandoff &ho = StepHandoff{}) {
     if (e->env_worlds && e->L != 64) return fail(MGX_ERR_ARG, "per-env worlds run one env per wavefront (lanes_per_env 64)");
     switch (e->L) {
-        case 4: return launch_step_L<R, P, 4>(e, sp, sf, si, actions, done, n_sub, count_step, st);
-        case 8: return launch_step_L<R, P, 8>(e, sp, sf, si, actions, done, n_sub, count_step, st);
-        case 16: return launch_step_L<R, P, 16>(e, sp, sf, si, actions, done, n_sub, count_step, st);
-        case 32: return launch_step_L<R, P, 32>(e, sp, sf, si, actions, done, n_sub, count_step, st);
-        case 64: return launch_step_L<R, P, 64>(e, sp, sf, si, actions, done, n_sub, count_step, st);
+        case 4: return launch_step_L<R, P, 4>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho);
+        case 8: return launch_step_L<R, P, 8>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho);
+        case 16: return launch_step_L<R, P, 16>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho);
+        case 32: return launch_step_L<R, P, 32>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho);
+        case 64: return launch_step_L<R, P, 64>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho);
     }
     return fail(MGX_ERR_ARG, "lanes_per_env must be 4, 8, 16, 32 or 64");
 }
@@ -572,6 +577,10 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
 void mgx_engine_destroy(mgx_engine *e) {
     if (!e) return;
     DeviceGuard guard__(e->device);
+    if (e->st2) { (void)hipStreamSynchronize(e->st2); (void)hipStreamDestroy(e->st2); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    for (void *p : {(void *)e->d_queue, (void *)e->d_hand, (void *)e->d_deferred}) if (p) (void)hipFree(p);
     for (void *p : {(void *)e->d_score_lib, (void *)e->d_score_ent, (void *)e->d_score_prow, (void *)e->d_score_goal_ent,
                     (void *)e->d_score_goal_xyhw, (void *)e->d_ent_type_env, (void *)e->d_ent_present_env})
         if (p) (void)hipFree(p);
@@ -622,16 +631,17 @@ int mgx_engine_reset_poses(mgx_engine *e, void *state_p, void *state_f, int32_t 
     if (!ent_pose) return fail(MGX_ERR_ARG, "ent_pose is NULL (use mgx_engine_reset for the template poses)");
     return reset_common(e, state_p, state_f, state_i, mask, ent_pose, stream);
 }
-static int step_common(mgx_engine *e, void *sp, void *sf, int32_t *si, const int32_t *actions, uint8_t *done, int n_sub, int count_step, void *stream) {
+static int step_common(mgx_engine *e, void *sp, void *sf, int32_t *si, const int32_t *actions, uint8_t *done, int n_sub, int count_step, void *stream,
+                       const StepHandoff &ho = StepHandoff{}) {
     if (!e || !sp || !sf || !si || !actions) return fail(MGX_ERR_ARG, "NULL argument");
     if (n_sub < 0) return fail(MGX_ERR_ARG, "negative substep count");
     ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     int rc = timing_begin(e, 0, st);
     if (rc) return rc;
-    rc = e->dtype == MGX_F32 ? launch_step<float, double>(e, sp, sf, si, actions, done, n_sub, count_step, st)
-       : e->dtype == MGX_F64 ? launch_step<double, double>(e, sp, sf, si, actions, done, n_sub, count_step, st)
-                             : launch_step<float, float>(e, sp, sf, si, actions, done, n_sub, count_step, st);
+    rc = e->dtype == MGX_F32 ? launch_step<float, double>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho)
+       : e->dtype == MGX_F64 ? launch_step<double, double>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho)
+                             : launch_step<float, float>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho);
     if (rc) return rc;
     return timing_end(e, 0, st);
 }
@@ -651,12 +661,13 @@ static int raster_capacity_ok(const mgx_engine *e) {
     return MGX_OK;
 }
 template <typename P>
-static int launch_raster(mgx_engine *e, const void *sp, uint8_t *out, int64_t env_stride, int view, int layout, const uint8_t *fill, hipStream_t st) {
+static int launch_raster(mgx_engine *e, const void *sp, uint8_t *out, int64_t env_stride, int view, int layout, const uint8_t *fill, hipStream_t st,
+                         const RasterHandoff &ho = RasterHandoff{}) {
     size_t lds = e->lds_raster;
     auto go = [&](auto kern) -> int {
         struct Tag { char c; };       // (a local type of this generic lambda: one table per instantiation)
         if (int rc = ensure_lds<Tag>((const void *)kern, lds, e->device)) return rc;
-        hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, fill, e->n_envs);
+        hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, fill, e->n_envs, ho);
         return MGX_OK;
     };
     auto by_layout = [&](auto waves) -> int {
@@ -688,6 +699,67 @@ int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t 
                                   : launch_raster<double>(e, state_p, out, env_stride, view, layout, fill_mask, st);
     if (rc) return rc;
     return timing_end(e, 1, st);
+}
+// fused env-step: physics and rasterisation of ONE BaseEnv.step() as a producer / consumer pair (see StepHandoff / RasterHandoff)
+int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const int32_t *actions, uint8_t *done,
+                           uint8_t *out, int64_t env_stride, int view, int layout, void *stream) {
+    if (!e || !state_p || !state_f || !state_i || !actions || !out) return fail(MGX_ERR_ARG, "NULL argument");
+    if (view != MGX_VIEW_EGO && view != MGX_VIEW_ALLO) return fail(MGX_ERR_ARG, "bad view");
+    if (layout < MGX_OBS_FRAME || layout > MGX_OBS_SLOT_LO) return fail(MGX_ERR_ARG, "bad layout");
+    int64_t need = (int64_t)LORES * LORES * (layout == MGX_OBS_FRAME ? 3 : 12);
+    if (env_stride < need || (env_stride & 3)) return fail(MGX_ERR_ARG, "env_stride too small or not a multiple of 4");
+    if (int rc = raster_capacity_ok(e)) return rc;
+    // the consumers may only wait for producers that are all resident at once: one single-wave workgroup per SIMD at most
+    // (1024 SIMDs; and the CU's LDS must hold its share of them next to at least one raster workgroup)
+    const int per_cu = (step_blocks(e) + 255) / 256;
+    const bool overlap = step_blocks(e) <= 1024 && (size_t)per_cu * ((e->lds_step + 511) & ~(size_t)511) + ((e->lds_raster + 511) & ~(size_t)511) <= (size_t)MAX_LDS_BYTES &&
+                         !getenv("MGX_NO_OVERLAP");
+    if (!overlap) {
+        int rc = step_common(e, state_p, state_f, state_i, actions, done, PHYS_STEPS, 1, stream);
+        return rc ? rc : mgx_engine_render(e, state_p, out, env_stride, view, layout, nullptr, stream);
+    }
+    ON_DEVICE(e);
+    hipStream_t st = (hipStream_t)stream;
+    if (!e->st2) {
+        HIP_OK(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        HIP_OK(hipMalloc(&e->d_queue, (size_t)e->n_envs * 8)); HIP_OK(hipMalloc(&e->d_deferred, (size_t)e->n_envs * 4)); HIP_OK(hipMalloc(&e->d_hand, 16));
+        HIP_OK(hipMemset(e->d_queue, 0, (size_t)e->n_envs * 8)); HIP_OK(hipMemset(e->d_deferred, 0, (size_t)e->n_envs * 4)); HIP_OK(hipMemset(e->d_hand, 0, 16));
+        HIP_OK(hipDeviceSynchronize());
+        e->hand_tail = e->hand_started = e->hand_epoch = 0;
+    }
+    e->hand_epoch++;
+    if (e->hand_epoch == 0) e->hand_epoch = 1;        // 0 is what the zeroed tables hold
+    StepHandoff sh{e->d_queue, e->d_hand, e->d_hand + 1, e->hand_tail, e->hand_epoch};
+    RasterHandoff rh{e->d_queue, e->d_hand + 1, e->hand_started, (unsigned)step_blocks(e), e->hand_epoch, e->d_deferred, e->d_hand + 2, 1};
+    e->hand_tail += (unsigned)e->n_envs; e->hand_started += (unsigned)step_blocks(e);
+    // the raster stream joins the caller's stream here (the observation tensor may still be read by earlier work on it) ...
+    HIP_OK(hipEventRecord(e->ev_fork, st));
+    HIP_OK(hipStreamWaitEvent(e->st2, e->ev_fork, 0));
+    int rc = step_common(e, state_p, state_f, state_i, actions, done, PHYS_STEPS, 1, stream, sh);
+    if (rc) return rc;
+    rc = timing_begin(e, 1, e->st2);
+    if (rc) return rc;
+    rc = e->dtype == MGX_F32_PURE ? launch_raster<float>(e, state_p, out, env_stride, view, layout, nullptr, e->st2, rh)
+                                  : launch_raster<double>(e, state_p, out, env_stride, view, layout, nullptr, e->st2, rh);
+    if (rc) return rc;
+    rc = timing_end(e, 1, e->st2);
+    if (rc) return rc;
+    // ... and the caller's stream waits for it: whatever comes next on `stream` sees the finished observation
+    HIP_OK(hipEventRecord(e->ev_join, e->st2));
+    HIP_OK(hipStreamWaitEvent(st, e->ev_join, 0));
+    // clean-up: the envs whose consumer gave up (producers not all running yet, or a wait that ran out) -- normally none
+    rh.mode = 2;
+    return e->dtype == MGX_F32_PURE ? launch_raster<float>(e, state_p, out, env_stride, view, layout, nullptr, st, rh)
+                                    : launch_raster<double>(e, state_p, out, env_stride, view, layout, nullptr, st, rh);
+}
+int mgx_engine_handoff_stats(mgx_engine *e, unsigned *deferred, unsigned *timeouts) {
+    if (!e) return fail(MGX_ERR_ARG, "engine is NULL");
+    unsigned h[4] = {0, 0, 0, 0};
+    if (e->d_hand) { ON_DEVICE(e); HIP_OK(hipMemcpy(h, e->d_hand, 16, hipMemcpyDeviceToHost)); }
+    if (deferred) *deferred = h[2];
+    if (timeouts) *timeouts = h[3];
+    return MGX_OK;
 }
 int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_t *out, int view, void *stream) {
     if (!e || !state_p || !out) return fail(MGX_ERR_ARG, "NULL argument");

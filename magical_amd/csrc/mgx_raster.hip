@@ -33,6 +33,23 @@ struct RasterDev {
     int ecap;                      // phase E records in use (<= ECAP; likewise)
 };
 
+// Consumer side of the step -> raster hand-off (mgx_engine_step_render; producer: StepHandoff in mgx_step.hip).
+//   mode 0  plain launch: workgroup b rasterises env b
+//   mode 1  runs concurrently with k_step: workgroup b rasterises the b-th env k_step finishes.  It waits for its queue entry
+//           only if every producer workgroup is already executing (otherwise the consumers' own residency could be what keeps the
+//           producers from starting); if not, or if the bounded wait runs out, it marks itself deferred and exits
+//   mode 2  clean-up launch after both kernels: workgroup b rasterises queue[b]'s env iff b was deferred (normally none)
+struct RasterHandoff {
+    const unsigned long long *queue;
+    const unsigned *started;
+    unsigned started_base, n_producers;    // producers of this call have all begun once *started - started_base >= n_producers
+    unsigned epoch;
+    unsigned *deferred;                    // [n_envs] = epoch where workgroup b gave up
+    unsigned *stats;                       // [0] deferred workgroups so far (diagnostic), [1] bounded waits that ran out
+    int mode;
+};
+constexpr unsigned HANDOFF_POLL_LIMIT = 1u << 20;      // x (s_sleep 16 + an L2 round trip) ~ 1 s: far beyond any step kernel
+
 MGX_HD int raster_off_q(const TmplHeader &h, int off_i) { return (off_i + h.n_words_i + 1) & ~1; }
 MGX_HD int raster_blob_words(const TmplHeader &h, int off_i) { return raster_off_q(h, off_i) + 2 * (h.n_prims * PRIM_RWORDS + 2 * h.n_pverts); }
 constexpr int N_TILES = TILES_X * TILES_Y;
@@ -224,7 +241,7 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
 
 template <typename P, int LAYOUT, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
-                                                long env_stride, int view, const uint8_t *__restrict__ fill_mask, int n_envs) {
+                                                long env_stride, int view, const uint8_t *__restrict__ fill_mask, int n_envs, RasterHandoff ho) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
     unsigned long long clk0 = wall_clock64();
@@ -238,10 +255,45 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
 #else
 #define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + (i)] = wall_clock64() - clk0;
 #endif
-    const long env = blockIdx.x;
-    {
+    long env = blockIdx.x;
+    // the shared draw list does not depend on the env: stage it before waiting for the hand-off
+    if (!t.tmpl_stride_words) for (int i = tid; i < t.n_words; i += 256) lds[i] = t.words[i];
+    if (ho.mode) {
+        // one lane waits / decides, one agent-scope acquire per workgroup, then plain loads (cdna guide, G16)
+        int32_t *slot = reinterpret_cast<int32_t *>(lds + t.lds_tmpl_words + t.off_tiles) + (N_TILES * 3 + QCAP * 4 + 5);    // = q_count[5], unused below
+        if (tid == 0) {
+            long got = -1;
+            if (ho.mode == 1) {
+                // (a short bounded wait: the two kernels are released together and the producers need a microsecond to begin)
+                unsigned begun = 0;
+                for (int n = 0; n < 64; n++) {
+                    begun = __hip_atomic_load(ho.started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ho.started_base;
+                    if (begun >= ho.n_producers) break;
+                    __builtin_amdgcn_s_sleep(32);
+                }
+                if (begun >= ho.n_producers) {
+                    for (unsigned n = 0; n < HANDOFF_POLL_LIMIT; n++) {
+                        const unsigned long long ent = __hip_atomic_load(&ho.queue[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(ent >> 32) == ho.epoch) { got = (long)(ent & 0xFFFFFFFFull); break; }
+                        __builtin_amdgcn_s_sleep(16);
+                    }
+                    if (got < 0) atomicAdd(&ho.stats[1], 1u);
+                }
+                if (got < 0) { ho.deferred[blockIdx.x] = ho.epoch; atomicAdd(&ho.stats[0], 1u); }
+                else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            } else if (ho.deferred[blockIdx.x] == ho.epoch) {
+                got = (long)(ho.queue[blockIdx.x] & 0xFFFFFFFFull);          // written by a kernel that has completed
+            }
+            *slot = (int32_t)got;
+        }
+        __syncthreads();
+        env = *slot;
+        if (env < 0) return;
+        __syncthreads();           // (the slot is reused as a counter below)
+    }
+    if (t.tmpl_stride_words) {
         const uint32_t *src = t.words + env * t.tmpl_stride_words;
-        const int n = t.tmpl_stride_words ? raster_blob_words(*reinterpret_cast<const TmplHeader *>(src), t.off_i) : t.n_words;
+        const int n = raster_blob_words(*reinterpret_cast<const TmplHeader *>(src), t.off_i);
         for (int i = tid; i < n; i += 256) lds[i] = src[i];
     }
     __syncthreads();

@@ -29,6 +29,17 @@ struct TmplDev {
     int lds_tmpl_words;        // LDS words reserved per template copy (multiple of 2)
     unsigned long long *dbg_clk;   // development probe (MGX_STEP_PROBE builds): per-workgroup phase cycles [blocks][32]
 };
+// Producer side of the step -> raster hand-off (mgx_engine_step_render): a workgroup that has written its envs' state back
+// publishes them, one 64-bit entry per env ((epoch << 32) | env), into a queue that raster workgroups of a concurrently
+// running k_raster consume in arrival order.  Placement-independent protocol: plain state stores -> s_waitcnt -> agent-scope
+// release -> s_waitcnt -> relaxed agent-scope ticket + entry store; the consumer polls its entry relaxed and acquires once.
+struct StepHandoff {
+    unsigned long long *queue;   // [n_envs]; NULL = no hand-off (plain launch)
+    unsigned *tail;              // tickets handed out so far, all calls (monotonic)
+    unsigned *started;           // step workgroups that have begun executing, all calls (monotonic)
+    unsigned base;               // value of *tail before this call
+    unsigned epoch;              // this call's tag
+};
 MGX_HD int even_words(int x) { return (x + 1) & ~1; }
 template <typename R> MGX_HD int tmpl_off_r(const TmplHeader &h, int off_i) { return even_words(off_i + h.n_words_i); }
 template <typename R, typename P> MGX_HD int tmpl_off_p(const TmplHeader &h, int off_i) {
@@ -54,12 +65,20 @@ constexpr int probe_phase_id(const char *s) {
 #ifndef MGX_L64_WAVES
 #define MGX_L64_WAVES 2
 #endif
+#ifndef MGX_LN_WAVES
+#define MGX_LN_WAVES 1      // register budget of the several-envs-per-wave instantiations, in waves per SIMD (512 / n VGPRs)
+#endif
 template <typename R, typename P, int L>
-__global__ __launch_bounds__(64, (L == 64 ? MGX_L64_WAVES : 1)) void k_step(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
+__global__ __launch_bounds__(64, (L == 64 ? MGX_L64_WAVES : MGX_LN_WAVES)) void k_step(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
                                              const int32_t *__restrict__ actions, uint8_t *__restrict__ done,
-                                             int n_envs, int n_sub, int count_step, int iterations) {
+                                             int n_envs, int n_sub, int count_step, int iterations, StepHandoff ho) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
+    if (ho.queue) {
+        // consumers only wait for producers that are already running (never for ones that still need the consumers' slots)
+        if (tid == 0) __hip_atomic_fetch_add(ho.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_setprio(3);      // the serial chain below goes first; co-resident raster waves fill its bubbles
+    }
     constexpr int EPB = 64 / L;
     const int env_local = tid / L, lane = tid % L, nl = L;
     // consecutive workgroups land on different XCDs (round robin over the 8 L2s); give each XCD a contiguous env
@@ -129,6 +148,16 @@ __global__ __launch_bounds__(64, (L == 64 ? MGX_L64_WAVES : 1)) void k_step(Tmpl
         MGX_SUBSTEP_PHASES(SYNC)
     }
     if (valid) ph_store_state(e, sp, sf, si, stride, env, lane, nl);
+    if (ho.queue) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler may drop the fence's own wait: keep this one)
+        if (valid && lane == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(ho.tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ho.queue[ticket - ho.base], ((unsigned long long)ho.epoch << 32) | (unsigned long long)env,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 #ifdef MGX_STEP_PROBE
     if (t.dbg_clk && tid == 0) for (int i = 0; i < 20; i++) t.dbg_clk[(long)blockIdx.x * 32 + i] = pacc[i];
 #endif

@@ -51,3 +51,51 @@ def gather_rollout_results(local, n_total=None):
     if n_total is not None:
         assert out.shape[0] == n_total
     return out
+
+
+class TaskFleet:
+    """Several engines (e.g. one per task: SURVEY.md section 8d config 5 = the 8 Demo tasks, 8192 envs each, 1024 per GPU) on ONE
+    GPU, each stepping on its own HIP stream, so that one engine's latency-bound `k_step` (a single wavefront per SIMD) runs
+    under another's memory-bound `k_raster`: small per-task batches no longer leave most of the chip idle.  Engines are
+    independent (no data crosses between them); `step()` issues one env-step of every engine that still has steps to go and
+    returns without joining the streams -- the host only synchronises where an engine's episode ends (its scoring)."""
+
+    def __init__(self, names, n_envs, device, seed=0, first_env=0, concurrent=True, **make_kwargs):
+        import torch
+        import magical_amd
+        self.device = torch.device(device)
+        self.names, self.concurrent = list(names), concurrent
+        self.streams = [torch.cuda.Stream(self.device) if concurrent else torch.cuda.current_stream(self.device) for _ in self.names]
+        self.envs = []
+        for name, st in zip(self.names, self.streams):
+            with torch.cuda.stream(st):
+                env = magical_amd.make(name, n_envs=n_envs, device=device, **make_kwargs)
+                env.seed(seed + first_env)          # env k of the job draws from RandomState(seed + k) whatever the sharding
+                self.envs.append(env)
+
+    def reset(self):
+        import torch
+        out = []
+        for env, st in zip(self.envs, self.streams):
+            with torch.cuda.stream(st):
+                out.append(env.reset())
+        return out
+
+    def step(self, actions, active=None):
+        """actions[k]: int32[n_envs] device tensor for engine k (None / inactive: skipped).  Returns the engines' step() results."""
+        import torch
+        out = [None] * len(self.envs)
+        for k, (env, st) in enumerate(zip(self.envs, self.streams)):
+            if actions[k] is None or (active is not None and not active[k]):
+                continue
+            with torch.cuda.stream(st):
+                out[k] = env.step(actions[k])
+        return out
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def close(self):
+        for env in self.envs:
+            env.close()

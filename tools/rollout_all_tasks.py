@@ -21,6 +21,8 @@ def main():
     ap.add_argument('--preproc', default='LoRes4E')
     ap.add_argument('--variant', default='Demo', help="'Demo', a Test* variant name, or 'all' for every registered variant of every task")
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--concurrent', action='store_true', help='all tasks of the variant at once, one engine + HIP stream per task on every GPU '
+                                                              '(magical_amd.distributed.TaskFleet), next to the sequential loop')
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -38,6 +40,51 @@ def main():
             name = f'{task}-{variant}-{args.preproc}-v0' if args.preproc else f'{task}-{variant}-v0'
             if name in magical_amd.ALL_REGISTERED_ENVS:
                 names.append((task, name))
+    if args.concurrent:
+        from magical_amd.distributed import TaskFleet
+        only = [name for _, name in names]
+        res = {}
+        for mode in ('sequential', 'concurrent'):
+            fleet = TaskFleet(only, hi - lo, f'cuda:{local_rank}', seed=args.seed, first_env=lo, concurrent=(mode == 'concurrent'))
+            Ts = [e.max_episode_steps for e in fleet.envs]
+            tapes = [torch.as_tensor(np.random.RandomState(args.seed).randint(0, 18, size=(T, args.envs)).astype(np.int32)[:, lo:hi], device=fleet.device) for T in Ts]
+            fleet.reset(); fleet.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            scores = [None] * len(only)
+            if mode == 'sequential':
+                for k, env in enumerate(fleet.envs):
+                    for s in range(Ts[k]):
+                        _, _, done, info = env.step(tapes[k][s])
+                    scores[k] = info['eval_score']
+            else:
+                for s in range(max(Ts)):
+                    out = fleet.step([tapes[k][s] if s < Ts[k] else None for k in range(len(only))])
+                    for k, o in enumerate(out):
+                        if o is not None and s == Ts[k] - 1:
+                            assert o[2].all()
+                            scores[k] = o[3]['eval_score']
+            fleet.synchronize()
+            # ONE end-of-rollout gather for all tasks: [n_tasks, n_local] -> every rank holds [n_tasks, n_total]
+            local = torch.as_tensor(np.stack(scores), device=fleet.device).T.contiguous()
+            allsc = gather_rollout_results(local, args.envs)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=fleet.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+            res[mode] = (dt, allsc.cpu().numpy())
+            fleet.close()
+        if rank == 0:
+            total = args.envs * sum(Ts)
+            assert np.array_equal(res['sequential'][1], res['concurrent'][1]), 'concurrent engines changed the results'
+            print(json.dumps({'tasks': only, 'n_envs_per_task': args.envs, 'n_gpus': world, 'env_steps': total,
+                              'sequential_env_steps_per_s': total / res['sequential'][0], 'concurrent_env_steps_per_s': total / res['concurrent'][0],
+                              'speedup': res['sequential'][0] / res['concurrent'][0], 'identical_scores': True,
+                              'mean_score_per_task': [float(v) for v in res['concurrent'][1].mean(axis=0)]}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     for task, name in names:
         env = magical_amd.make(name, n_envs=hi - lo, device=f'cuda:{local_rank}')
         T = env.max_episode_steps
