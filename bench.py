@@ -74,6 +74,71 @@ def cpu_baseline(seconds=12.0):
                       f'4-frame stack, 4x4 box filter), {cores} processes x {seconds:.0f} s, random actions'}
 
 
+CONFIG5_TASKS = ['MoveToCorner', 'MoveToRegion', 'MatchRegions', 'MakeLine', 'FindDupe', 'FixColour', 'ClusterColour', 'ClusterShape']
+
+
+def main_config5(args):
+    """BASELINE.json configs[4] / SURVEY.md section 8d config 5: the 8 Demo tasks at once, `--envs5` envs per task sharded by env index
+    over the job's GPUs (8192 / 8 = 1024 per task per GPU), every rank stepping its 8 engines concurrently on 8 HIP streams
+    (magical_amd.distributed.TaskFleet), auto-reset at each task's own episode length, and ONE all_gather of the per-env
+    scores of all tasks at the end of the rollout.  A "step" = one env-step of every task; value = env-steps/s of the job."""
+    import torch
+    import torch.distributed as dist
+    from magical_amd.distributed import TaskFleet, env_shard, gather_rollout_results, init_from_env
+    rank, world, local_rank = init_from_env(backend='nccl')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    device = f'cuda:{local_rank}'
+    lo, hi = env_shard(args.envs5, rank, world)
+    n, K, W = hi - lo, args.steps, args.warmup
+    names = [f'{t}-Demo-LoRes4E-v0' for t in CONFIG5_TASKS]
+    fleet = TaskFleet(names, n, device, seed=0, first_env=lo, dtype=args.dtype)
+    nt = len(names)
+    tapes = [torch.as_tensor(np.random.RandomState(1000 * k + rank).randint(0, 18, size=(W + K, n)).astype(np.int32), device=device) for k in range(nt)]
+    fleet.reset()
+    for s in range(W):
+        fleet.step([tp[s] for tp in tapes])
+    last = np.zeros((nt, n), dtype=np.float64)
+    n_eps = 0
+    gather_rollout_results(torch.zeros((n, nt), dtype=torch.float64, device=device), args.envs5)      # RCCL warm-up
+
+    def barrier():
+        fleet.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(W, W + K):
+        for k, o in enumerate(fleet.step([tp[s] for tp in tapes])):
+            done = o[2]
+            if done.any():
+                n_eps += int(done.sum())
+                last[k, done] = o[3]['eval_score'][done]
+    fleet.synchronize()
+    all_scores = gather_rollout_results(torch.as_tensor(last.T.copy(), device=device), args.envs5)      # [envs5, n_tasks] on every rank
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        out = {'metric': f'env-steps/sec (incl. 96x96 LoRes4E render), all 8 tasks x Demo at once, {args.envs5} envs per task', 'value': nt * args.envs5 * K / elapsed,
+               'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True,
+               'scaling': 'strong', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+               'config': {'workload': f'BASELINE.json configs[4]: {", ".join(CONFIG5_TASKS)} x Demo-LoRes4E-v0, {args.envs5} envs per task sharded '
+                                      f'{world} ways ({n} per task per GPU), 8 engines per GPU on 8 HIP streams, random actions, auto-reset, one RCCL '
+                                      'all_gather of all scores at the end',
+                          'envs_per_task_per_gpu': n, 'episodes_finished': n_eps * world, 'mean_eval_score': float(all_scores.mean().item())},
+               'roofline': None, 'note': 'a step = one env-step of each of the 8 tasks; kernels of different engines overlap, so per-kernel '
+                                         'roofline figures are those of the single-task lines (python bench.py --task ...)'}
+        print(json.dumps(out))
+    fleet.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -84,7 +149,12 @@ def main():
     ap.add_argument('--lanes', type=int, default=0)
     ap.add_argument('--dtype', default='f32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--config5', action='store_true', help='BASELINE.json configs[4]: all 8 tasks x Demo-LoRes4E, --envs5 envs per task sharded over '
+                                                           'the GPUs, one engine + HIP stream per task on every GPU, one RCCL gather at the end')
+    ap.add_argument('--envs5', type=int, default=8192, help='envs per task over the whole job (config 5)')
     args = ap.parse_args()
+    if args.config5:
+        return main_config5(args)
 
     import torch
     import torch.distributed as dist
@@ -140,6 +210,17 @@ def main():
         elapsed = float(t.item())
     step_ms = env.read_timing('step')
     rast_ms = env.read_timing('render')
+    # In the fused step the raster kernel's launch duration includes its hand-off waits for the step kernel (that overlap is the
+    # point); the same kernels launched one after the other, in a short UNTIMED phase, give the duration of the kernel's own work
+    alone_ms = None
+    if getattr(env, 'overlap', False) and len(rast_ms):
+        env.overlap = False
+        env.set_timing(1)
+        for s in range(W, min(W + 40, W + K)):
+            env.step(tape[s])
+        torch.cuda.synchronize()
+        alone_ms = {'k_step': float(env.read_timing('step').mean()), 'k_raster': float(env.read_timing('render').mean())}
+        env.overlap = True
     env.set_timing(0)
 
     if rank == 0:
@@ -197,6 +278,11 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'frac_new_frame_row': (ring_bytes / (kernels[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom == 'k_raster' else None,
+                         'launch_mode': ('fused: k_raster runs concurrently with k_step and consumes envs as they finish, so its launch duration '
+                                         'includes hand-off waits' if alone_ms else 'one kernel after the other'),
+                         'kernel_alone': None if not alone_ms else {
+                             'note': 'the same kernels launched one after the other (40 untimed steps after the timed region)',
+                             'avg_launch_ms': alone_ms, 'frac': kernels[dom][1] / (alone_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          'avg_launch_ms': kernels[dom][0], 'algorithmic_bytes_per_launch': kernels[dom][1],
                          'other_kernels': {k: {'avg_launch_ms': v[0], 'algorithmic_bytes_per_launch': v[1],
                                                'achieved_GBs': v[1] / (v[0] * 1e-3) / 1e9} for k, v in kernels.items() if k != dom}},

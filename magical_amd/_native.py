@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, 'csrc')
 LIB_PATH = os.environ.get('MGX_LIB_PATH') or os.path.join(_PKG, 'libmagical_hip.so')      # (override: development builds with other -D knobs)
 _SOURCES = ['mgx_api.hip', 'mgx_world.cpp']
-_DEPS = _SOURCES + ['mgx_step.hip', 'mgx_raster.hip', 'mgx_score.hip', 'mgx_sim.h', 'mgx_raster.h', 'mgx_tmpl.h', 'mgx_world.h']
+_DEPS = _SOURCES + ['mgx_step.hip', 'mgx_raster.hip', 'mgx_raster_body.inc', 'mgx_score.hip', 'mgx_sim.h', 'mgx_raster.h', 'mgx_tmpl.h', 'mgx_world.h']
 
 # enums (include/mgx.h)
 MGX_F32, MGX_F64, MGX_F32_PURE = 0, 1, 2

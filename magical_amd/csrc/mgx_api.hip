@@ -681,6 +681,22 @@ static int launch_raster(mgx_engine *e, const void *sp, uint8_t *out, int64_t en
     HIP_OK(hipGetLastError());
     return MGX_OK;
 }
+template <typename P>
+static int launch_raster_deferred(mgx_engine *e, const void *sp, uint8_t *out, int64_t env_stride, int view, int layout, hipStream_t st,
+                                  const RasterHandoff &ho) {
+    size_t lds = e->lds_raster;
+    auto go = [&](auto kern) -> int {
+        struct Tag { char c; };
+        if (int rc = ensure_lds<Tag>((const void *)kern, lds, e->device)) return rc;
+        hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, e->n_envs, ho);
+        return MGX_OK;
+    };
+    int rc = layout == MGX_OBS_FRAME ? go(k_raster_deferred<P, 0>) : layout == MGX_OBS_STACK4 ? go(k_raster_deferred<P, 1>)
+           : layout == MGX_OBS_STACK3_HI ? go(k_raster_deferred<P, 2>) : go(k_raster_deferred<P, 3>);
+    if (rc) return rc;
+    HIP_OK(hipGetLastError());
+    return MGX_OK;
+}
 extern "C" {
 
 int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t env_stride, int view, int layout,
@@ -750,8 +766,8 @@ int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t 
     HIP_OK(hipStreamWaitEvent(st, e->ev_join, 0));
     // clean-up: the envs whose consumer gave up (producers not all running yet, or a wait that ran out) -- normally none
     rh.mode = 2;
-    return e->dtype == MGX_F32_PURE ? launch_raster<float>(e, state_p, out, env_stride, view, layout, nullptr, st, rh)
-                                    : launch_raster<double>(e, state_p, out, env_stride, view, layout, nullptr, st, rh);
+    return e->dtype == MGX_F32_PURE ? launch_raster_deferred<float>(e, state_p, out, env_stride, view, layout, st, rh)
+                                    : launch_raster_deferred<double>(e, state_p, out, env_stride, view, layout, st, rh);
 }
 int mgx_engine_handoff_stats(mgx_engine *e, unsigned *deferred, unsigned *timeouts) {
     if (!e) return fail(MGX_ERR_ARG, "engine is NULL");

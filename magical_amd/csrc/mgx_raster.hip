@@ -281,8 +281,6 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
                 }
                 if (got < 0) { ho.deferred[blockIdx.x] = ho.epoch; atomicAdd(&ho.stats[0], 1u); }
                 else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            } else if (ho.deferred[blockIdx.x] == ho.epoch) {
-                got = (long)(ho.queue[blockIdx.x] & 0xFFFFFFFFull);          // written by a kernel that has completed
             }
             *slot = (int32_t)got;
         }
@@ -291,252 +289,28 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
         if (env < 0) return;
         __syncthreads();           // (the slot is reused as a counter below)
     }
-    if (t.tmpl_stride_words) {
-        const uint32_t *src = t.words + env * t.tmpl_stride_words;
-        const int n = raster_blob_words(*reinterpret_cast<const TmplHeader *>(src), t.off_i);
-        for (int i = tid; i < n; i += 256) lds[i] = src[i];
-    }
-    __syncthreads();
-    CLK(0)
-    const TmplHeader *h = reinterpret_cast<const TmplHeader *>(lds);
-    uint32_t *scratch = lds + t.lds_tmpl_words;
-    Raster rs(h, reinterpret_cast<const int32_t *>(lds + t.off_i), reinterpret_cast<const double *>(lds + raster_off_q(*h, t.off_i)),
-              reinterpret_cast<double *>(scratch), reinterpret_cast<int32_t *>(scratch + 2 * t.scratch_d), view);
-    // phase-local LDS: per-tile results and the queue of undecided pixels
-    uint64_t *tile_mixed = reinterpret_cast<uint64_t *>(scratch + t.off_tiles);
-    int32_t *tile_base = reinterpret_cast<int32_t *>(tile_mixed + N_TILES);
-    uint64_t *q_mask = reinterpret_cast<uint64_t *>(tile_base + N_TILES);
-    int32_t *q_pix = reinterpret_cast<int32_t *>(q_mask + QCAP);
-    int32_t *q_base = q_pix + QCAP;
-    // [0] entries pushed, [1] "some pixel did not fit" flag, [2] entries for phase E, [3] / [4] entries with / without a
-    // line loop among their prims (filled from the two ends of the queue so that a wavefront mostly runs one kind),
-    // [6..7] bit mask of the line-loop prims
-    int32_t *q_count = q_base + QCAP;
-    uint32_t *q_ovf = reinterpret_cast<uint32_t *>(q_count + 8);   // bitmap of the pixels that did not fit
-    uint64_t *e_sums = reinterpret_cast<uint64_t *>(q_ovf + OVF_WORDS);   // phase E: partial sums | uncertain samples << 40
-    uint16_t *e_list = reinterpret_cast<uint16_t *>(e_sums + ECAP);       // phase E: queue entry of each record
-    if (tid == 0) {
-        q_count[0] = 0; q_count[1] = 0; q_count[2] = 0; q_count[3] = 0; q_count[4] = 0;
-        uint64_t lm = 0;
-        for (int k = 0; k < h->n_prims; k++) if (rs.prim_kind(k) == PR_LINELOOP) lm |= 1ull << k;
-        *reinterpret_cast<uint64_t *>(q_count + 6) = lm;
-    }
-    for (int i = tid; i < OVF_WORDS; i += 256) q_ovf[i] = 0;
-    // phase S: screen-space setup (lane per body; lane per primitive + lane per vertex; lane per edge for the item list)
-    raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
-    __syncthreads();
-    raster_setup_prims(rs, tid, 256, t.ent_colour_env, (long)n_envs, env, t.goal_xyhw_env, t.palette);
-    __syncthreads();
-    raster_setup_edges(rs, tid, 256);
-    __syncthreads();
-    CLK(1)
-    const int wave = tid >> 6, lane = tid & 63;
-    // phase C: one lane per 16x4 tile; the whole item list streams through the wave's registers 64 items at a time
-    {
-        const int n_items = raster_total_items(rs);
-        const int tile = tid;                       // waves 0..2 cover the 144 tiles
-        if (wave * 64 < N_TILES) {
-            const bool active = tile < N_TILES;
-            float xc = 0.0f, yc = 0.0f;
-            if (active) tile_centre(tile, xc, yc);
-            ClassState st; st.init(t.bg_rgb);
-            for (int c0 = 0; c0 < n_items; c0 += 64) {
-                RegItems src;
-                const int idx = c0 + lane;
-                src.my = load_item(rs, idx < n_items ? idx : 0);
-                const int n = n_items - c0 < 64 ? n_items - c0 : 64;
-                classify_items_regs<true>(rs, src, n, xc, yc, st, active);
-                if (__all(st.decided || !active)) break;
-            }
-            if (active) { tile_base[tile] = st.base; tile_mixed[tile] = st.mixed; }
-        }
-    }
-    __syncthreads();
-    CLK(2)
+#include "mgx_raster_body.inc"
+#undef CLK
+}
 
-    // phase T: each wavefront walks its tiles, one lane per output pixel
-    const int tx = lane & (TILE_W - 1), ty = lane >> 4;
-    const bool fill = LAYOUT != LAY_FRAME && fill_mask != nullptr && fill_mask[env] != 0;
-    const bool need_old = layout_needs_old<LAYOUT>(fill);
-    uint8_t *frame = out + env * env_stride;
-    // wave w walks tiles w, w + 4, ... (FRAME layout; the stacked layouts walk pairs of tiles, below)
-    auto seq_tile = [&](int i) { return wave + 4 * i; };
-    constexpr int N_SEQ = N_TILES / 4;
-    static_assert(N_TILES % 4 == 0, "tiles per wave");
-    const int qcap = t.qcap, ecap = t.ecap;
-    PROBE(unsigned long long pr_gather = 0, pr_class = 0, pr_items = 0, pr_tiles = 0; const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();)
-    // a free queue entry (capacity already checked): pixels with a line loop among their prims from the front, the others
-    // from the back
-    const uint64_t line_mask = *reinterpret_cast<const uint64_t *>(q_count + 6);
-    auto queue_slot = [&](uint64_t mixed) { return (mixed & line_mask) ? atomicAdd(&q_count[3], 1) : qcap - 1 - atomicAdd(&q_count[4], 1); };
-    // classify the pixels of one tile: returns the colour; `queued` when the pixel must wait for phase Q
-    auto do_tile = [&](int tile, int X, int Y, bool &queued) -> int {
-        const uint64_t tmixed = tile_mixed[tile];
-        int c = tile_base[tile];
-        queued = false;
-        if (tmixed == 0) return c;
-        PROBE(if (t.dbg_stop == 9) return c;)     // probe: pure streaming, no per-pixel classification
-        PROBE(const unsigned long long pt0 = __builtin_amdgcn_s_memtime();)
-        // gather the items of the tile's undecided prims (front to back), one per lane, and classify every
-        // pixel's 4x4 sample block against them
-        ClassState st; st.init(c);
-        const float xc = 4.0f * X + 2.0f, yc = (float)NATIVE_RES - 4.0f * Y - 2.0f;
-        int n_total = 0;
-        for (int c0 = 0;; c0 += 64) {
-            RegItems src;
-            const int idx = masked_item_index_uniform(rs, tmixed, c0 + lane, n_total);
-            src.my = load_item(rs, idx >= 0 ? idx : 0);
-            const int n = n_total - c0 < 64 ? n_total - c0 : 64;
-            PROBE(const unsigned long long pt1 = __builtin_amdgcn_s_memtime(); pr_gather += pt1 - pt0;)
-            classify_items_regs<false>(rs, src, n, xc, yc, st, true);
-            PROBE(pr_class += __builtin_amdgcn_s_memtime() - pt1; pr_items += n;)
-            if (c0 + 64 >= n_total) break;
-        }
-        PROBE(pr_tiles++;)
-        if (st.mixed != 0) {
-            // undecided pixel: queue it for phase Q so that finished lanes do not wait for it
-            queued = true;
-            if (atomicAdd(&q_count[0], 1) < qcap) {
-                const int slot = queue_slot(st.mixed);
-                q_mask[slot] = st.mixed; q_pix[slot] = X | (Y << 8); q_base[slot] = st.base;
-            } else {
-                const int p = Y * LORES + X;
-                atomicOr(&q_ovf[p >> 5], 1u << (p & 31));
-                q_count[1] = 1;
-            }
-        }
-        return st.base;
-    };
-    if (LAYOUT == LAY_FRAME) {
-        for (int seq = 0; seq < N_SEQ; seq++) {
-            const int tile = seq_tile(seq);
-            const int tcol = tile % TILES_X, trow = tile / TILES_X;
-            const int X = tcol * TILE_W + tx, Y = trow * TILE_H + ty;
-            if (tile_mixed[tile] == 0) {
-                // 16 pixels x 3 B = 12 dwords per tile row: lanes tx < 12 each assemble one dword
-                const int c = tile_base[tile];
-                const int d = tx < 12 ? tx : 0;
-                const int p0 = (4 * d) / 3, o = (4 * d) % 3;
-                const uint32_t c0 = (uint32_t)__shfl(c, (ty << 4) + p0), c1 = (uint32_t)__shfl(c, (ty << 4) + p0 + 1);
-                uint32_t w = o == 0 ? (c0 | (c1 << 24)) : (o == 1 ? ((c0 >> 8) | (c1 << 16)) : ((c0 >> 16) | (c1 << 8)));
-                if (tx < 12) reinterpret_cast<uint32_t *>(frame + (long)(Y * LORES + tcol * TILE_W) * 3)[d] = w;
-                continue;
-            }
-            bool queued;
-            const int c = do_tile(tile, X, Y, queued);
-            if (!queued) store_frame_px(frame, X, Y, c);
-        }
-    } else {
-        // STACK4 shifts 12 B per pixel in place.  Memory is walked in PAIRS of horizontally adjacent tiles (32 x 4 pixels, lane =
-        // two adjacent pixels, whole cache lines); the old pixels of a whole group of G tiles (G / 2 pairs, G x 768 B per
-        // wavefront) are fetched ahead so that the read latency is covered by the previous group's classification.
-        constexpr int G = MGX_STACK_GROUP, GP = G / 2;
-        static_assert(G % 2 == 0 && N_SEQ % G == 0 && TILES_X % 2 == 0, "tile pairs / groups");
-        // wave w's i-th pair = tiles 2 (w + 4 i), 2 (w + 4 i) + 1; this lane's two pixels of it sit at pair_off(pair)
-        const int mr = lane >> 4, mc = lane & 15;
-        auto pair_tile = [&](int i) { return 2 * (wave + 4 * i); };
-        auto pair_off = [&](int tile0) { return (uint32_t)((((tile0 / TILES_X) * TILE_H + mr) * LORES + (tile0 % TILES_X) * TILE_W + 2 * mc) * 12); };
-        // the classification has lane = one pixel of ONE tile: lane (mr, mc) of the pair takes its two colours from lanes
-        // src, src + 1 of the left (mc < 8) or right tile
-        const int src = mr * 16 + ((2 * mc) & 15);
-        const bool right = mc >= 8;
-        OldPx2 nxt[GP];
-#pragma unroll
-        for (int u = 0; u < GP; u++) {
-            nxt[u] = OldPx2{{0, 0, 0}, {0, 0, 0}};
-            if (need_old) nxt[u] = load_old2<LAYOUT>(frame, pair_off(pair_tile(u)));
-        }
-        for (int g = 0; g < N_SEQ / 2; g += GP) {
-            OldPx2 cur[GP];
-#pragma unroll
-            for (int u = 0; u < GP; u++) {
-                cur[u] = nxt[u];
-                if (need_old && g + GP < N_SEQ / 2) nxt[u] = load_old2<LAYOUT>(frame, pair_off(pair_tile(g + GP + u)));
-            }
-            int col[G];
-#pragma unroll
-            for (int v = 0; v < G; v++) col[v] = 0;
-#pragma unroll 1
-            for (int u = 0; u < G; u++) {
-                const int tile = pair_tile(g + (u >> 1)) + (u & 1);
-                bool queued;
-                const int c = do_tile(tile, (tile % TILES_X) * TILE_W + tx, (tile / TILES_X) * TILE_H + ty, queued);
-#pragma unroll
-                for (int v = 0; v < G; v++) col[v] = u == v ? c : col[v];
-            }
-#pragma unroll
-            for (int u = 0; u < GP; u++) {
-                const int a0 = __shfl(col[2 * u], src), a1 = __shfl(col[2 * u], src + 1);
-                const int b0 = __shfl(col[2 * u + 1], src), b1 = __shfl(col[2 * u + 1], src + 1);
-                // queued pixels are shifted here too (with a placeholder for the new frame's bytes) so that phases Q / E
-                // only patch those bytes in, without reading the pixel back
-                store_pre2<LAYOUT>(frame, pair_off(pair_tile(g + u)), right ? b0 : a0, right ? b1 : a1, fill, cur[u]);
-            }
-        }
-    }
-    PROBE(if (t.dbg_clk && tid == 0) { unsigned long long *d = t.dbg_clk + blockIdx.x * 16; d[6] = pr_gather; d[7] = pr_class;
-                d[8] = __builtin_amdgcn_s_memtime() - pr_t0; d[9] = pr_tiles; d[10] = pr_items; })
-    __syncthreads();
-    CLK(3)
-    // phase Q: the queue is dense, so every lane resolves one undecided pixel (fp32 coverage masks, fp64 only for
-    // ambiguous samples and line blending).  Pixels that did not fit the queue are re-queued from the bitmap with
-    // their tile's prim set (a superset of the pixel's, same result) for another round.
-    int nq_total = 0;
-    for (;;) {
-        const int n_line = q_count[3], nq = n_line + q_count[4];
-        nq_total += nq;
-        for (int j = tid; j < nq; j += 256) {
-            const int i = j < n_line ? j : qcap - 1 - (j - n_line);
-            const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;
-            uint32_t unc;
-            const uint64_t sums = pixel_resolve_fast(rs, X, Y, q_mask[i], q_base[i], unc);
-            if (unc) {      // phase E adds the samples that need the fp64 painter
-                const int j = atomicAdd(&q_count[2], 1);
-                if (j < ecap) {
-                    e_list[j] = (uint16_t)i; e_sums[j] = sums | ((uint64_t)unc << 40);
-                } else {    // no record left this round: back to the bitmap
-                    const int p = Y * LORES + X;
-                    atomicOr(&q_ovf[p >> 5], 1u << (p & 31));
-                    q_count[1] = 1;
-                }
-                continue;
-            }
-            const int c = pixel_finish(sums);
-            if (LAYOUT == LAY_FRAME) store_frame_px(frame, X, Y, c); else store_patch<LAYOUT>(frame, X, Y, c, fill);
-        }
-        __syncthreads();
-        // phase E: the few samples whose fp32 result could not be guaranteed, with the fp64 painter
-        const bool more = q_count[1] != 0;          // some pixel found no queue slot / no phase E record: another round
-        const int ne = q_count[2] < ecap ? q_count[2] : ecap;
-        for (int j = tid; j < ne; j += 256) {
-            const int i = e_list[j];
-            const int X = q_pix[i] & 0xFF, Y = q_pix[i] >> 8;
-            const uint64_t rec = e_sums[j];
-            const int c = pixel_finish(pixel_add_exact(rs, X, Y, q_mask[i], q_base[i], rec & 0xFFFFFFFFFFull, (uint32_t)(rec >> 40)));
-            if (LAYOUT == LAY_FRAME) store_frame_px(frame, X, Y, c); else store_patch<LAYOUT>(frame, X, Y, c, fill);
-        }
-        __syncthreads();
-        if (!more) break;
-        if (tid == 0) { q_count[0] = 0; q_count[1] = 0; q_count[2] = 0; q_count[3] = 0; q_count[4] = 0; }
-        __syncthreads();
-        for (int w = tid; w < OVF_WORDS; w += 256) {
-            uint32_t bits = q_ovf[w];
-            while (bits) {
-                const int b = __ffs(bits) - 1;
-                if (atomicAdd(&q_count[0], 1) >= qcap) { q_count[1] = 1; break; }
-                const int p = w * 32 + b, X = p % LORES, Y = p / LORES;
-                const int tile = (Y / TILE_H) * TILES_X + X / TILE_W;
-                const int slot = queue_slot(tile_mixed[tile]);
-                q_mask[slot] = tile_mixed[tile]; q_pix[slot] = X | (Y << 8); q_base[slot] = tile_base[tile];
-                bits &= bits - 1;
-            }
-            q_ovf[w] = bits;
-        }
-        __syncthreads();
-    }
-    CLK(4)
-    const int nq = nq_total;
-    if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + 5] = nq;
+// the clean-up launch of mgx_engine_step_render: workgroup b rasterises queue[b]'s env iff consumer b gave up (normally none);
+// a kernel of its own, so that the launch statistics of k_raster are those of real work (one occupancy variant serves every world)
+template <typename P, int LAYOUT>
+__global__ __launch_bounds__(256, 3) void k_raster_deferred(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
+                                                   long env_stride, int view, int n_envs, RasterHandoff ho) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int tid = threadIdx.x;
+    unsigned long long clk0 = wall_clock64();
+#ifdef MGX_RASTER_PROBE
+#define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + (i)] = wall_clock64() - clk0; if ((i) > 0 && t.dbg_stop == (i)) return;
+#else
+#define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + (i)] = wall_clock64() - clk0;
+#endif
+    if (ho.deferred[blockIdx.x] != ho.epoch) return;                        // (workgroup-uniform)
+    const long env = (long)(ho.queue[blockIdx.x] & 0xFFFFFFFFull);         // written by a kernel that has completed
+    const uint8_t *fill_mask = nullptr;
+    if (!t.tmpl_stride_words) for (int i = tid; i < t.n_words; i += 256) lds[i] = t.words[i];
+#include "mgx_raster_body.inc"
 #undef CLK
 }
 

@@ -1146,3 +1146,26 @@ def test_fused_step_render_equals_the_two_calls(name, n):
     assert timeouts == 0, (deferred, timeouts)
     print(f'{name}: consumer workgroups deferred to the clean-up launch: {deferred} of {n * (2 * ep + 1)}')
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_task_fleet_equals_engines_run_one_by_one():
+    """BASELINE.json configs[4] shape on one GPU: the 8 Demo tasks as 8 engines on 8 HIP streams (distributed.TaskFleet) give
+    the scores and final observations of the same engines stepped one after the other."""
+    import torch
+    from magical_amd.distributed import TaskFleet
+    names = [f'{t}-Demo-LoRes4E-v0' for t in TASKS]
+    n, ep = 96, 9
+    outs = []
+    for concurrent in (False, True):
+        fleet = TaskFleet(names, n, 'cuda:0', seed=2, first_env=40, concurrent=concurrent, max_episode_steps=ep)
+        fleet.reset()
+        tapes = [torch.as_tensor(_tape(70 + k, ep, n), device='cuda:0') for k in range(len(names))]
+        for s in range(ep):
+            res = fleet.step([tp[s] for tp in tapes])
+        fleet.synchronize()
+        assert all(r[2].all() for r in res)
+        outs.append(([r[3]['eval_score'].copy() for r in res], [r[0].clone() for r in res]))
+        fleet.close()
+    for (sa, oa), (sb, ob) in zip(zip(*outs[0]), zip(*outs[1])):
+        assert np.array_equal(sa, sb) and torch.equal(oa, ob)
