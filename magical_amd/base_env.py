@@ -269,6 +269,8 @@ class BaseEnv(abc.ABC):
                 self._overlap = self.region_overlaps(None)
                 self.score_on_end_of_traj(None)
             self._check_capacity(None, 0)
+            if self.auto_reset:
+                self._pinned_snapshots()        # pinning host memory costs milliseconds: not at the first episode end
             self._warm = True
         obs = self._observe(fill_all=True)
         if self.copy_obs:
@@ -301,34 +303,63 @@ class BaseEnv(abc.ABC):
         if self.max_episode_steps is not None:
             done = self._steps >= self.max_episode_steps
         fill = None
+        obs = None
         if done.any():
             idx = np.nonzero(done)[0]
             self._scoring_envs = idx          # which envs the poses belong to (per-env task state of Test* variants)
             sel = None if len(idx) == self.n_envs else idx      # lockstep batches finish together: no gather then
+            # Where the next episode draws nothing on the host (the Demo variants), the reset and the rasterisation of the new
+            # episode's first frame are ENQUEUED before the host scores the old one: what the scores read (pose rows or the
+            # device's overlap sets, the overflow counters) is snapshotted on the stream first, and the host then works on the
+            # snapshots while the GPU resets and renders.  Tasks with per-episode draws keep per-env tables that the draws
+            # overwrite, so they score first, as before.
+            early = (self.auto_reset and not self.rand_dynamics and not self.variable_worlds and not self.sample_variation_is_active())
+            snap_p = snap_i = snap_o = None
+            if early:
+                # asynchronous copies into pinned host memory, an event after them, THEN the reset and the rasterisation: the host
+                # waits for the event only, and scores while the GPU is still busy
+                pin = self._pinned_snapshots()
+                snap_i = pin['i']; snap_i.copy_(self.state_i[2], non_blocking=True)
+                if self.score_needs_poses:
+                    snap_p = pin['p']; snap_p.copy_(self.state_p, non_blocking=True)
+                else:
+                    self._enqueue_region_overlaps(self._done_dev)
+                    snap_o = pin['o']; snap_o.copy_(self._overlap_dev, non_blocking=True)
+                pin['ev'].record(torch.cuda.current_stream(self.device))
+                self._reset_envs(idx, self._done_dev)
+                fill = self._done_dev
+                obs = self._observe(fill_mask=fill)
+                pin['ev'].synchronize()
             if self.score_needs_poses:
-                eval_score[idx] = self.score_on_end_of_traj(self.get_poses(sel))
+                eval_score[idx] = self.score_on_end_of_traj(self.get_poses(sel, source=snap_p))
+            elif early:
+                self._overlap = snap_o.numpy() if sel is None else snap_o.numpy()[:, :, sel]
+                eval_score[idx] = self.score_on_end_of_traj(None)
             else:
                 self._overlap = self.region_overlaps(sel, mask_dev=self._done_dev)
                 eval_score[idx] = self.score_on_end_of_traj(None)
             assert np.all((eval_score >= 0) & (eval_score <= 1)), 'eval score out of range'
-            self._check_capacity(sel, len(idx))
-            if self.auto_reset:
+            self._check_capacity(sel, len(idx), source=snap_i)
+            if self.auto_reset and not early:
                 # the device-side done flags written by the step kernel double as reset + frame-fill masks
                 self._reset_envs(idx, self._done_dev)
                 fill = self._done_dev
-        obs = self._observe(fill_mask=fill)
+        if obs is None:
+            obs = self._observe(fill_mask=fill)
         if self.copy_obs:
             obs = {k: v.clone() for k, v in obs.items()} if isinstance(obs, dict) else obs.clone()
         return obs, self._reward, done, {'eval_score': eval_score}
 
-    def _check_capacity(self, idx, n_finished):
+    def _check_capacity(self, idx, n_finished, source=None):
         """Chipmunk never drops a contact (base_env.py:243); this engine's per-env working set is sized from the world
         (every shape pair that can touch) and counts what did not fit in state_i[2].  The counter of the envs whose episode
         just ended is read here -- the stream is already drained by the pose download, so no extra synchronisation -- and a
         non-zero count is reported: a warning by default, an MgxError with strict_capacity=True."""
         import torch
         import warnings
-        row = self.state_i[2] if idx is None else self.state_i[2, torch.as_tensor(idx, device=self.device)]
+        row = self.state_i[2] if source is None else source
+        if idx is not None:
+            row = row[torch.as_tensor(idx, device=row.device)]
         n = int(row.sum())
         if n:
             self.capacity_overflows += n
@@ -487,16 +518,33 @@ class BaseEnv(abc.ABC):
             self._goal_rect[:, torch.as_tensor(idx, device=self.device)] = torch.as_tensor(
                 np.ascontiguousarray(xyhw.reshape(len(idx), -1).T), device=self.device)
 
-    def region_overlaps(self, env_idx=None, mask_dev=None):
-        """GoalRegion.get_overlapping_ents(com_overlap=True) (entities.py:821-881) on the device for the envs `env_idx`
-        (default all): numpy u8 [n_goals, n_entities, M], bit 0 = body position inside the region's box, bit 1 = every shape of
-        the block overlaps the region (goals in entity order; mgx_engine_score_overlaps).  Synchronises (one small copy)."""
+    def _pinned_snapshots(self):
+        """Pinned host buffers + the event of the episode-end snapshots (allocated on first use)."""
+        import torch
+        pin = getattr(self, '_pin', None)
+        if pin is None:
+            pin = {'i': torch.empty(self.n_envs, dtype=torch.int32).pin_memory(), 'ev': torch.cuda.Event()}
+            if self.score_needs_poses:
+                pin['p'] = torch.empty(tuple(self.state_p.shape), dtype=self.state_p.dtype).pin_memory()
+            else:
+                pin['o'] = torch.empty((len(self._goal_ent_idx), len(self._entities), self.n_envs), dtype=torch.uint8).pin_memory()
+            self._pin = pin
+        return pin
+
+    def _enqueue_region_overlaps(self, mask_dev=None):
         import torch
         ng, ne = len(self._goal_ent_idx), len(self._entities)
         if getattr(self, '_overlap_dev', None) is None:
             self._overlap_dev = torch.zeros((ng, ne, self.n_envs), dtype=torch.uint8, device=self.device)
         nat.check(self._lib.mgx_engine_score_overlaps(self._engine, self.state_p.data_ptr(), None if mask_dev is None else mask_dev.data_ptr(),
                                                       self._overlap_dev.data_ptr(), self._stream()))
+
+    def region_overlaps(self, env_idx=None, mask_dev=None):
+        """GoalRegion.get_overlapping_ents(com_overlap=True) (entities.py:821-881) on the device for the envs `env_idx`
+        (default all): numpy u8 [n_goals, n_entities, M], bit 0 = body position inside the region's box, bit 1 = every shape of
+        the block overlaps the region (goals in entity order; mgx_engine_score_overlaps).  Synchronises (one small copy)."""
+        import torch
+        self._enqueue_region_overlaps(mask_dev)
         out = self._overlap_dev if env_idx is None else self._overlap_dev[:, :, torch.as_tensor(env_idx, device=self.device)]
         return out.cpu().numpy()
 
@@ -568,10 +616,12 @@ class BaseEnv(abc.ABC):
         p = self.state_p.index_select(0, sel[0]) * sel[1]
         return p.reshape(self.n_bodies, 3, self.n_envs).permute(2, 0, 1).to(torch.float32)
 
-    def get_poses(self, env_idx=None):
-        """float64[M, n_bodies, 3] poses of the selected envs on the host (synchronises)."""
+    def get_poses(self, env_idx=None, source=None):
+        """float64[M, n_bodies, 3] poses of the selected envs on the host (synchronises).  source: a snapshot of the pose blob."""
         import torch
-        sp = self.state_p if env_idx is None else self.state_p[:, torch.as_tensor(env_idx, device=self.device)]
+        sp = self.state_p if source is None else source
+        if env_idx is not None:
+            sp = sp[:, torch.as_tensor(env_idx, device=sp.device)]
         sp = sp.to(torch.float64).cpu().numpy()
         out = np.zeros((sp.shape[1], self.n_bodies, 3), dtype=np.float64)
         for b in range(self.n_bodies):

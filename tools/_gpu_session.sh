@@ -1,25 +1,12 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out
-cd /tmp
-for cfg in "mtc:MoveToCorner-Demo-LoRes4E-v0" "cc:ClusterColour-Demo-LoRes4E-v0"; do
-  key=${cfg%%:*}; task=${cfg##*:}
-  rm -rf /tmp/prof_$key /tmp/pf_$key /tmp/pw_$key
-  timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_$key -- python $R/bench.py --no-cpu-baseline --task $task > $O/r02_bench_${key}_lores4e_under_rocprof.json 2> $O/rocprof_$key.err
-  f=$(find /tmp/prof_$key -name "*kernel_stats.csv" | head -1); cp "$f" $O/r02_bench_${key}_lores4e_kernel_stats.csv
-  MGX_NO_OVERLAP=1 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d /tmp/pf_$key -- python $R/bench.py --no-cpu-baseline --steps 60 --warmup 5 --task $task > /dev/null 2> $O/pmc_f_$key.err
-  MGX_NO_OVERLAP=1 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d /tmp/pw_$key -- python $R/bench.py --no-cpu-baseline --steps 60 --warmup 5 --task $task > /dev/null 2> $O/pmc_w_$key.err
-  python $R/tools/pmc_summary.py /tmp/pf_$key /tmp/pw_$key > $O/r02_pmc_traffic_${key}_lores4e.json 2> $O/pmc_sum_$key.err
+timeout 900 python -m pytest tests -m gpu -q -x -k "stack_and_autoreset or scores or fused or full_size or checkpoint or other_preprocessors or rollouts or debug_reward or capacity or copy_obs or reference_vectors" 2>&1 | tail -4
+for k in 1 2; do
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('20-step: %.3f M  %.4f ms/step  eps %d' % (d['value']/1e6, d['ms_per_step'], d['config']['episodes_finished']))"
 done
-rm -rf /tmp/prof_ser
-MGX_NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_ser -- python $R/bench.py --no-cpu-baseline > $O/r02_bench_mtc_lores4e_serial_under_rocprof.json 2>> $O/rocprof_mtc.err
-f=$(find /tmp/prof_ser -name "*kernel_stats.csv" | head -1); cp "$f" $O/r02_bench_mtc_lores4e_serial_kernel_stats.csv
-cd $R
-python bench.py > $O/r02_bench_mtc_lores4e.json 2> $O/r02_bench.err
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/r02_bench_mtc_lores4e_20steps.json 2>> $O/r02_bench.err
-MGX_NO_OVERLAP=1 python bench.py --no-cpu-baseline > $O/r02_bench_mtc_lores4e_serial.json 2>> $O/r02_bench.err
-python bench.py --no-cpu-baseline --task ClusterColour-Demo-LoRes4E-v0 > $O/r02_bench_cc_lores4e.json 2>> $O/r02_bench.err
-python bench.py --no-cpu-baseline --task MoveToCorner-Demo-v0 > $O/r02_bench_mtc_state_only.json 2>> $O/r02_bench.err
-python bench.py --no-cpu-baseline --config5 --envs5 1024 --steps 120 --warmup 5 > $O/r02_bench_config5_1gpu_8x1024.json 2>> $O/r02_bench.err
-tail -3 $O/r02_bench.err
+timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('400-step: %.3f M  %.4f ms/step  eps %d' % (d['value']/1e6, d['ms_per_step'], d['config']['episodes_finished']), d['roofline']['kernel_alone'])"
+timeout 300 python tools/episode_end_probe.py 2>&1 | head -3
