@@ -119,6 +119,16 @@ int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses
                                         const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
                                         const double *pos_limits, const double *rot_limits, int limits_per_env /* limits are [m][n] */,
                                         const uint64_t *mt_state_addr, const double *ent_hw /* NULL or [m][n_entities][2] */);
+/* the other per-episode draws of the tasks' on_reset() (counts, colours, shape types, region sizes: e.g. cluster.py:81-110,
+ * match_regions.py:51-117, find_dupe.py:84-112, fix_colour.py:78-113, make_line.py:100-110, base_env.py:198-203), for m envs
+ * per call, each on its own live np.random.RandomState stream (mt_state_addr[k] as above), advanced exactly as numpy would:
+ *   bounded: counts[k] (NULL: `count`) draws of rng.randint(0, max_inclusive + 1) -- what rng.choice(seq) indexes with --
+ *            into out[k][..] (row stride out_stride);
+ *   doubles: likewise rng.random_sample() (rng.uniform(lo, hi) = lo + (hi - lo) * it);
+ *   shuffle: the permutation rng.shuffle() applies to a list of n_items[k] items: shuffled[i] = original[perm[k][i]]. */
+int mgx_rng_bounded_batch(int m, const uint64_t *mt_state_addr, const int32_t *counts, int count, int max_inclusive, int32_t *out, int out_stride);
+int mgx_rng_doubles_batch(int m, const uint64_t *mt_state_addr, const int32_t *counts, int count, double *out, int out_stride);
+int mgx_rng_shuffle_batch(int m, const uint64_t *mt_state_addr, const int32_t *n_items, int32_t *perm, int perm_stride);
 /* style.py:28-37 evaluated to RGB8 for entity colour 0..3 (red green blue yellow) in `role` */
 int mgx_world_palette(int colour, int role);
 

@@ -84,6 +84,9 @@ def lib():
         'mgx_world_entity_shapes': [vp, i32, i32, ip, dp, ip, dp, i32],
         'mgx_world_prim_table': [vp, ip, ip, ip],
         'mgx_world_palette': [i32, i32],
+        'mgx_rng_bounded_batch': [i32, C.POINTER(C.c_uint64), ip, i32, i32, ip, i32],
+        'mgx_rng_doubles_batch': [i32, C.POINTER(C.c_uint64), ip, i32, dp, i32],
+        'mgx_rng_shuffle_batch': [i32, C.POINTER(C.c_uint64), ip, ip, i32],
         'mgx_world_randomise_all_poses_batch': [vp, i32, dp, ip, i32, C.POINTER(C.c_uint8), dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8),
                                                 dp, dp, i32, C.POINTER(C.c_uint64), dp],
         'mgx_world_placement_collides': [vp, i32, dp, C.POINTER(C.c_uint8), dp],
@@ -136,7 +139,7 @@ EXPORTED_SYMBOLS = [
     'mgx_last_error', 'mgx_version', 'mgx_world_create', 'mgx_world_destroy', 'mgx_world_set_phys_vars',
     'mgx_world_add_robot', 'mgx_world_add_shape', 'mgx_world_add_goal', 'mgx_world_finalize', 'mgx_world_info',
     'mgx_world_entity', 'mgx_world_body_table', 'mgx_world_n_state_entries', 'mgx_world_state_entry',
-    'mgx_world_goal_bb', 'mgx_world_entity_shapes', 'mgx_world_prim_table', 'mgx_world_palette', 'mgx_world_placement_collides', 'mgx_world_randomise_all_poses', 'mgx_world_randomise_all_poses_batch',
+    'mgx_world_goal_bb', 'mgx_world_entity_shapes', 'mgx_world_prim_table', 'mgx_world_palette', 'mgx_rng_bounded_batch', 'mgx_rng_doubles_batch', 'mgx_rng_shuffle_batch', 'mgx_world_placement_collides', 'mgx_world_randomise_all_poses', 'mgx_world_randomise_all_poses_batch',
     'mgx_engine_create', 'mgx_engine_destroy', 'mgx_engine_set_entity_colours', 'mgx_engine_set_goal_rects', 'mgx_engine_score_overlaps', 'mgx_engine_n_goals',
     'mgx_world_variant', 'mgx_engine_enable_env_worlds', 'mgx_engine_set_env_variants', 'mgx_engine_env_randomise_all_poses_batch', 'mgx_engine_env_world_info',
     'mgx_engine_state_shape', 'mgx_engine_lanes_per_env', 'mgx_engine_lds_bytes', 'mgx_engine_reset', 'mgx_engine_reset_poses',

@@ -47,6 +47,12 @@ class PhysicsVariables:
         return [float(getattr(cls, n)[0]) for n in cls.NAMES]
 
     @classmethod
+    def sample_batch(cls, brng):
+        """sample() for every env of a BatchRng: float64[m, 5], the same arithmetic on the same draws."""
+        u = brng.random_sample(len(cls.NAMES))
+        return np.stack([lo + (hi - lo) * u[:, i] for i, (lo, hi) in enumerate(getattr(cls, n)[1] for n in cls.NAMES)], axis=1)
+
+    @classmethod
     def sample(cls, rng):
         # rng.uniform(lo, hi) per variable, in order = lo + (hi - lo) * random_sample(): one call for the five doubles
         u = rng.random_sample(len(cls.NAMES))
@@ -80,7 +86,7 @@ class BaseEnv(abc.ABC):
 
     def __init__(self, *, n_envs=1, device='cuda:0', res_hw=(384, 384), fps=8, phys_steps=10, phys_iter=10,
                  max_episode_steps=None, rand_dynamics=False, ego_view=True, allo_view=True,
-                 dtype='f32', lanes_per_env=0, auto_reset=True, copy_obs=False, strict_capacity=False, overlap=True):
+                 dtype='f32', lanes_per_env=0, auto_reset=True, copy_obs=False, strict_capacity=False, overlap=True, batch_draws=True):
         import torch
         if fps != 8 or phys_steps != 10 or phys_iter != 10:
             raise NotImplementedError('the engine is built for the registered rates: fps=8, 10 substeps, 10 iterations '
@@ -95,6 +101,7 @@ class BaseEnv(abc.ABC):
             raise nat.MgxError('magical_amd runs on an MI355X (torch device "cuda:N"); there is no CPU fallback')
         if self.device.index is None:      # 'cuda' = torch's current device, pinned now (the engine lives on one GPU)
             self.device = torch.device('cuda', torch.cuda.current_device())
+        self.batch_draws = bool(batch_draws)   # per-episode draws of all envs of a reset per native call (batch_rng.py) instead of env by env
         self.overlap = bool(overlap)       # step(): physics + observation as a producer / consumer kernel pair (mgx_engine_step_render)
         self._obs_ready = False
         self.capacity_overflows = 0        # contacts / overlapping pairs the fixed-size working set dropped (see step())
@@ -381,6 +388,14 @@ class BaseEnv(abc.ABC):
         hook returns, for all envs in one native call."""
         return None
 
+    def sample_variation_batch(self, brng, env_idx):
+        """Batched form of sample_variation(): the same draws for all envs `env_idx` of a reset at once (brng: batch_rng.BatchRng
+        over their streams, in env_idx order).  Returns None or a dict of arrays over the m envs: 'colours' int64[m, n_entities]
+        (whole rows of native colour ids), 'shape_types' int32[m, n_entities] / 'enabled' bool[m, n_entities] (whole rows),
+        'goal_hw' {goal entity id: (h[m], w[m])}, 'randomise_poses' as in sample_variation().  Tasks that do not override it
+        are drawn env by env."""
+        return None
+
     def sample_variation_is_active(self):
         """Does sample_variation() draw anything for this task variant?  (The reference's on_reset branches on constructor
         flags only, so the answer is the same for every env and episode; asked on a scratch stream.)"""
@@ -400,7 +415,31 @@ class BaseEnv(abc.ABC):
         pvs, colour_rows, pose_rows, pose_spec, hw_rows, world_rows = [], [], [], None, {}, []
         # a task without per-episode draws (the Demo variants) returns None for every env and touches no stream: ask once
         draws = self.rand_dynamics or self.variable_worlds or (len(env_idx) > 0 and self.sample_variation_is_active())
-        for k in (env_idx if draws else ()):
+        # (the batched form only where it belongs to the same class as the per-env form: a subclass that overrides
+        # sample_variation() alone is drawn env by env)
+        owner = lambda name: next(c for c in type(self).__mro__ if name in c.__dict__)
+        batched = (draws and self.batch_draws and owner('sample_variation_batch') is not BaseEnv
+                   and issubclass(owner('sample_variation_batch'), owner('sample_variation')))
+        hw_batch = None
+        if batched:
+            # every kind of draw for all envs of this reset at once, in the reference's order per env: physics variables first
+            from .batch_rng import BatchRng
+            brng = BatchRng([self.rngs[k] for k in env_idx], self._lib)
+            if self.rand_dynamics:
+                pvs = PhysicsVariables.sample_batch(brng)
+            var = self.sample_variation_batch(brng, np.asarray(env_idx)) or {}
+            if 'colours' in var:
+                colour_rows = var['colours']
+            if self.variable_worlds:
+                n_ent = len(self._entities)
+                types = var.get('shape_types')
+                enabled = var.get('enabled')
+                types = np.tile(self._default_shape_types, (len(env_idx), 1)) if types is None else types
+                enabled = np.ones((len(env_idx), n_ent), dtype=bool) if enabled is None else enabled
+                world_rows = (np.ascontiguousarray(types, dtype=np.int32), np.ascontiguousarray(enabled, dtype=bool))
+            pose_spec = var.get('randomise_poses')
+            hw_batch = var.get('goal_hw')
+        for k in (env_idx if (draws and not batched) else ()):
             rng = self.rngs[k]
             if self.rand_dynamics:
                 pvs.append(PhysicsVariables.sample(rng))
@@ -426,16 +465,25 @@ class BaseEnv(abc.ABC):
                 pose_spec = var['randomise_poses']       # the same for every env of a task: one native call below
             if var is not None and 'goal_hw' in var:
                 hw_rows[int(k)] = {g.ent_id: hw for g, hw in var['goal_hw'].items()}
-        if world_rows:
+        if len(world_rows):
             # this episode's world of every env being reset, before anything is placed in it
             idx32 = np.ascontiguousarray(env_idx, dtype=np.int32)
-            types = np.ascontiguousarray(np.stack([t for t, _ in world_rows]), dtype=np.int32)
-            enabled = np.ascontiguousarray(np.stack([e for _, e in world_rows]), dtype=np.uint8)
+            if isinstance(world_rows, tuple):
+                types, enabled = world_rows[0], np.ascontiguousarray(world_rows[1], dtype=np.uint8)
+            else:
+                types = np.ascontiguousarray(np.stack([t for t, _ in world_rows]), dtype=np.int32)
+                enabled = np.ascontiguousarray(np.stack([e for _, e in world_rows]), dtype=np.uint8)
             self.entity_shape_types[env_idx], self.entity_enabled[env_idx] = types, enabled.astype(bool)
             nat.check(self._lib.mgx_engine_set_env_variants(self._engine, len(idx32), idx32.ctypes.data_as(C.POINTER(C.c_int)),
                                                             enabled.ctypes.data_as(C.POINTER(C.c_uint8)), types.ctypes.data_as(C.POINTER(C.c_int)),
                                                             self._stream()))
         ent_hw = None
+        if hw_batch:
+            # {goal entity id: (h[m], w[m])}
+            ent_hw = np.zeros((len(env_idx), len(self._entities), 2), dtype=np.float64)
+            ent_hw[:, self._goal_ent_idx] = self._goal_xyhw0[:, 2:]
+            for e, (h, w) in hw_batch.items():
+                ent_hw[:, e, 0], ent_hw[:, e, 1] = h, w
         if hw_rows:
             # resized goal regions keep their top-left corner (GoalRegion(x, y, h, w), entities.py:769-797): new centre
             ent_hw = np.zeros((len(env_idx), len(self._entities), 2), dtype=np.float64)
@@ -443,7 +491,7 @@ class BaseEnv(abc.ABC):
             for i, k in enumerate(env_idx):
                 for e, (h, w) in hw_rows.get(int(k), {}).items():
                     ent_hw[i, e] = (h, w)
-        if pose_spec is not None or hw_rows:
+        if pose_spec is not None or hw_rows or hw_batch:
             batch = np.ascontiguousarray(np.tile(self._default_poses, (len(env_idx), 1, 1)))
             if ent_hw is not None:
                 for g, e in enumerate(self._goal_ent_idx):
@@ -484,9 +532,9 @@ class BaseEnv(abc.ABC):
         else:
             nat.check(self._lib.mgx_engine_reset(self._engine, sp, sf, si, mask, self._stream()))
         self._steps[env_idx] = 0
-        if pvs:
+        if len(pvs):
             self.set_phys_vars(np.asarray(pvs, dtype=np.float64), env_idx)
-        if colour_rows:
+        if len(colour_rows):
             self.set_entity_colours(np.asarray(colour_rows), env_idx)
 
     def set_entity_colours(self, colour_ids, env_idx=None):

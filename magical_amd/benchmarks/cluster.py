@@ -70,6 +70,52 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
             var['randomise_poses'] = (all_ents, dict(rand_pos=True, rand_rot=True, rel_pos_linf_limits=pos_limit, rel_rot_limits=rot_limit))
         return var
 
+    def sample_variation_batch(self, brng, env_idx):   # the same draws, all envs at once (batch_rng.py)
+        if not (self.rand_shape_colour or self.rand_shape_type or self.rand_layout_minor or self.rand_layout_full):
+            return None
+        var, m, ents = {}, brng.m, self.__shape_ents
+        n_shapes = np.full(m, len(ents), dtype=np.int32)
+        if self.rand_shape_count:
+            n_shapes = 7 + brng.randint(10 + 1 - 7)[:, 0]
+            var['enabled'] = np.ones((m, len(self._entities)), dtype=bool)
+            for i, b in enumerate(ents):
+                var['enabled'][:, b.ent_id] = i < n_shapes
+        draws = None
+        for flag, names, key, table, default, by in (
+                (self.rand_shape_colour, en.SHAPE_COLOUR_NAMES, 'colours', en.colour_id_of_draw(), self._default_colours, self.ClusterBy.COLOUR),
+                (self.rand_shape_type, en.SHAPE_TYPE_NAMES, 'shape_types', en.type_id_of_draw(), self._default_shape_types, self.ClusterBy.TYPE)):
+            if not flag:
+                continue
+            # one block of each value, the rest drawn, then shuffled: value index of every block of the episode
+            k = len(names)
+            extra = brng.randint(k, counts=np.maximum(n_shapes - k, 0))
+            vals = np.zeros((m, len(ents)), dtype=np.int64)
+            vals[:, :k] = np.arange(k)
+            for i in range(extra.shape[1]):
+                if k + i < len(ents):
+                    vals[:, k + i] = extra[:, i]
+            perm = brng.shuffle(n_shapes)
+            r = np.arange(m)[:, None]
+            vals = vals[r, perm[:, :len(ents)]] if perm.shape[1] >= len(ents) else np.pad(vals[r, perm], ((0, 0), (0, len(ents) - perm.shape[1])))
+            rows = np.tile(default, (m, 1))
+            for i, b in enumerate(ents):
+                rows[:, b.ent_id] = np.where(i < n_shapes, table[vals[:, i]], rows[:, b.ent_id])
+            var[key] = rows
+            if self.cluster_by == by:
+                # class of a block = rank of its colour / type name among the values present (np.unique sorts them; all are present)
+                rank = np.argsort(np.argsort(np.asarray(names)))
+                draws = rank[vals]
+        if draws is not None or self.rand_shape_count:
+            if self._class_env is None:
+                self._class_env = np.tile(np.concatenate([self.__class_of_block, np.zeros(len(ents) - len(self.__class_of_block), dtype=np.int64)]), (self.n_envs, 1))
+            if draws is not None:
+                self._class_env[env_idx] = np.where(np.arange(len(ents))[None, :] < n_shapes[:, None], draws, 0)
+        if self.rand_layout_minor or self.rand_layout_full:
+            all_ents = [self._robot, *ents]
+            pos_limit, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if self.rand_layout_minor else (None, None)
+            var['randomise_poses'] = (all_ents, dict(rand_pos=True, rand_rot=True, rel_pos_linf_limits=pos_limit, rel_rot_limits=rot_limit))
+        return var
+
     def on_reset(self):   # cluster.py:67-164
         robot = self._make_robot(*self.DEFAULT_ROBOT_POSE)
         colours, shape_types, poses = self.DEFAULT_BLOCK_COLOURS, self.DEFAULT_BLOCK_SHAPES, self.DEFAULT_BLOCK_POSES

@@ -73,22 +73,83 @@ class FindDupeEnv(BaseEnv):
             var['goal_hw'] = {self.__sensor_ref: geom.randomise_hw(self.RAND_GOAL_MIN_SIZE, self.RAND_GOAL_MAX_SIZE, rng,
                                                                    current_hw=DEFAULT_TARGET_REGION_XYHW[2:],
                                                                    linf_bound=self.JITTER_TARGET_BOUND if minor else None)}
-            sensor, query = self.__sensor_ref, self.__all_blocks[0]
-            all_ents = (sensor, self._robot, *self.__outside_blocks)
-            pos_limits, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if minor else (None, None)
+            var['randomise_poses'] = self._pose_stages(minor)
+        return var
 
-            def place_query(poses, ent_hw, place):
-                # the query block goes onto the (moved) region and is then jittered so that it stays mostly inside it
-                poses[:, query.ent_id, :2] = poses[:, sensor.ent_id, :2]
-                lim = np.maximum(0.0, np.minimum(ent_hw[:, sensor.ent_id, 0], ent_hw[:, sensor.ent_id, 1]) / 2 - self.SHAPE_RAD / 2)
-                if minor:
-                    lim = np.minimum(self.JITTER_POS_BOUND, lim)
-                place([query], rand_pos=True, rand_rot=True, rel_pos_linf_limits=lim[:, None],
-                      rel_rot_limits=np.full((len(lim), 1), np.nan if rot_limit is None else rot_limit), ignore=[sensor])
-            var['randomise_poses'] = [
-                (all_ents, dict(rand_pos=True, rand_rot=[False] + [True] * (len(all_ents) - 1), rel_pos_linf_limits=pos_limits,
+    def _pose_stages(self, minor):   # find_dupe.py:157-196
+        sensor, query = self.__sensor_ref, self.__all_blocks[0]
+        all_ents = (sensor, self._robot, *self.__outside_blocks)
+        pos_limits, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if minor else (None, None)
+
+        def place_query(poses, ent_hw, place):
+            # the query block goes onto the (moved) region and is then jittered so that it stays mostly inside it
+            poses[:, query.ent_id, :2] = poses[:, sensor.ent_id, :2]
+            lim = np.maximum(0.0, np.minimum(ent_hw[:, sensor.ent_id, 0], ent_hw[:, sensor.ent_id, 1]) / 2 - self.SHAPE_RAD / 2)
+            if minor:
+                lim = np.minimum(self.JITTER_POS_BOUND, lim)
+            place([query], rand_pos=True, rand_rot=True, rel_pos_linf_limits=lim[:, None],
+                  rel_rot_limits=np.full((len(lim), 1), np.nan if rot_limit is None else rot_limit), ignore=[sensor])
+        return [(all_ents, dict(rand_pos=True, rand_rot=[False] + [True] * (len(all_ents) - 1), rel_pos_linf_limits=pos_limits,
                                 rel_rot_limits=rot_limit, ignore=[query])),
                 place_query]
+
+    def sample_variation_batch(self, brng, env_idx):   # the same draws, all envs at once (batch_rng.py)
+        if not (self.rand_colours or self.rand_shapes or self.rand_layout_minor or self.rand_layout_full):
+            return None
+        from ..batch_rng import uniform_hw
+        var, m = {}, brng.m
+        outside, query, sensor = self.__outside_blocks, self.__all_blocks[0], self.__sensor_ref
+        cid, tid = en.colour_id_of_draw(), en.type_id_of_draw()
+        n_out = np.full(m, len(outside), dtype=np.int32)
+        if self.rand_count:
+            n_out = brng.randint(5)[:, 0] + 1 + 1                   # rng.randint(1, 5 + 1) + 1
+            var['enabled'] = np.ones((m, len(self._entities)), dtype=bool)
+            for i, b in enumerate(outside):
+                var['enabled'][:, b.ent_id] = i < n_out
+        n_distractors = n_out - 1
+        # native ids of the query's and of every outside block's colour / shape: the Demo's, or this episode's draws
+        q_col = np.full(m, en.COLOUR_ID[DEFAULT_QUERY_COLOUR], dtype=np.int64)
+        q_typ = np.full(m, en.SHAPE_TYPE_ID[DEFAULT_QUERY_SHAPE], dtype=np.int32)
+        o_col = np.tile(np.array([en.COLOUR_ID[c] for c in DEFAULT_OUT_BLOCK_COLOURS], dtype=np.int64), (m, 1))
+        o_typ = np.tile(np.array([en.SHAPE_TYPE_ID[t] for t in DEFAULT_OUT_BLOCK_SHAPES], dtype=np.int32), (m, 1))
+        last = np.arange(m), n_out - 1                                # the last outside block of the episode always matches the query
+        if self.rand_colours:
+            q_col = cid[brng.randint(len(en.SHAPE_COLOUR_NAMES))[:, 0]]
+            d = brng.randint(len(en.SHAPE_COLOUR_NAMES), counts=n_distractors)
+            for i in range(min(d.shape[1], len(outside))):
+                o_col[:, i] = np.where(i < n_distractors, cid[d[:, i]], o_col[:, i])
+            o_col[last] = q_col
+            rows = np.tile(self._default_colours, (m, 1))
+            rows[:, sensor.ent_id] = q_col
+            rows[:, query.ent_id] = q_col
+            for i, b in enumerate(outside):
+                rows[:, b.ent_id] = np.where(i < n_out, o_col[:, i], rows[:, b.ent_id])
+            var['colours'] = rows
+        if self.rand_shapes:
+            q_typ = tid[brng.randint(len(en.SHAPE_TYPE_NAMES))[:, 0]]
+            d = brng.randint(len(en.SHAPE_TYPE_NAMES), counts=n_distractors)
+            for i in range(min(d.shape[1], len(outside))):
+                o_typ[:, i] = np.where(i < n_distractors, tid[d[:, i]], o_typ[:, i])
+            o_typ[last] = q_typ
+            rows = np.tile(self._default_shape_types, (m, 1))
+            rows[:, query.ent_id] = q_typ
+            for i, b in enumerate(outside):
+                rows[:, b.ent_id] = np.where(i < n_out, o_typ[:, i], rows[:, b.ent_id])
+            var['shape_types'] = rows
+        if self.rand_colours or self.rand_shapes:
+            if self._is_target_env is None:
+                self._is_target_env = np.tile(self.__is_target, (self.n_envs, 1))
+            # __all_blocks = [query block, *outside blocks]; a block is a target iff it has the query's colour and shape
+            row = np.zeros((m, len(self.__all_blocks)), dtype=bool)
+            row[:, 0] = True
+            for i in range(len(outside)):
+                row[:, 1 + i] = (i < n_out) & (o_col[:, i] == q_col) & (o_typ[:, i] == q_typ)
+            self._is_target_env[env_idx] = row
+        if self.rand_layout_minor or self.rand_layout_full:
+            minor = self.rand_layout_minor
+            var['goal_hw'] = {sensor.ent_id: uniform_hw(brng.random_sample(2), self.RAND_GOAL_MIN_SIZE, self.RAND_GOAL_MAX_SIZE,
+                                                       current_hw=DEFAULT_TARGET_REGION_XYHW[2:], linf_bound=self.JITTER_TARGET_BOUND if minor else None)}
+            var['randomise_poses'] = self._pose_stages(minor)
         return var
 
     def on_reset(self):   # find_dupe.py:72-155

@@ -62,23 +62,82 @@ class FixColourEnv(BaseEnv):
             hw_bound = self.JITTER_TARGET_BOUND if minor else None
             var['goal_hw'] = {s: geom.randomise_hw(MIN_GOAL_SIZE, MAX_GOAL_SIZE, rng, current_hw=xyhw[2:], linf_bound=hw_bound)
                               for s, xyhw in zip(self._sensors[:n_regions], DEFAULT_REGION_XYHWS)}
-            sensors, blocks, robot = self._sensors, self._blocks, self._robot
-            pos_limits, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if minor else (None, None)
+            var['randomise_poses'] = self._pose_stages(minor)
+        return var
 
-            def place_blocks(poses, ent_hw, place):
-                # every block goes onto its (moved) region, then each is jittered inside its own region
-                for block, sensor in zip(blocks, sensors):
-                    poses[:, block.ent_id, :2] = poses[:, sensor.ent_id, :2]
-                for block, sensor in zip(blocks, sensors):
-                    lim = np.maximum(0.0, np.minimum(ent_hw[:, sensor.ent_id, 0], ent_hw[:, sensor.ent_id, 1]) / 2 - self.SHAPE_RAD)
-                    if minor:
-                        lim = np.minimum(self.JITTER_POS_BOUND, lim)
-                    place([block], rand_pos=True, rand_rot=True, rel_pos_linf_limits=lim[:, None],
-                          rel_rot_limits=np.full((len(lim), 1), np.nan if rot_limit is None else rot_limit), ignore=[sensor])
-            var['randomise_poses'] = [
-                ((*sensors, robot), dict(rand_pos=True, rand_rot=[False] * len(sensors) + [True], rel_pos_linf_limits=pos_limits,
+    def _pose_stages(self, minor):   # fix_colour.py:143-187
+        sensors, blocks, robot = self._sensors, self._blocks, self._robot
+        pos_limits, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if minor else (None, None)
+
+        def place_blocks(poses, ent_hw, place):
+            # every block goes onto its (moved) region, then each is jittered inside its own region
+            for block, sensor in zip(blocks, sensors):
+                poses[:, block.ent_id, :2] = poses[:, sensor.ent_id, :2]
+            for block, sensor in zip(blocks, sensors):
+                lim = np.maximum(0.0, np.minimum(ent_hw[:, sensor.ent_id, 0], ent_hw[:, sensor.ent_id, 1]) / 2 - self.SHAPE_RAD)
+                if minor:
+                    lim = np.minimum(self.JITTER_POS_BOUND, lim)
+                place([block], rand_pos=True, rand_rot=True, rel_pos_linf_limits=lim[:, None],
+                      rel_rot_limits=np.full((len(lim), 1), np.nan if rot_limit is None else rot_limit), ignore=[sensor])
+        return [((*sensors, robot), dict(rand_pos=True, rand_rot=[False] * len(sensors) + [True], rel_pos_linf_limits=pos_limits,
                                          rel_rot_limits=rot_limit, ignore=blocks)),
                 place_blocks]
+
+    def sample_variation_batch(self, brng, env_idx):   # the same draws, all envs at once (batch_rng.py)
+        if not (self.rand_colours or self.rand_shapes or self.rand_layout_minor or self.rand_layout_full):
+            return None
+        from ..batch_rng import uniform_hw
+        var, m = {}, brng.m
+        sensors, blocks = self._sensors, self._blocks
+        cid, tid, n_names = en.colour_id_of_draw(), en.type_id_of_draw(), len(en.SHAPE_COLOUR_NAMES)
+        n_regions = np.full(m, len(sensors), dtype=np.int32)
+        if self.rand_count:
+            n_regions = MIN_REGIONS + brng.randint(MAX_REGIONS + 1 - MIN_REGIONS)[:, 0]
+            var['enabled'] = np.ones((m, len(self._entities)), dtype=bool)
+            for ents in (sensors, blocks):
+                for i, e in enumerate(ents):
+                    var['enabled'][:, e.ent_id] = i < n_regions
+        if self.rand_colours:
+            region = brng.randint(n_names, counts=n_regions)                   # draw indices, [m, <= 3]
+            block = region.copy()
+            odd = np.zeros(m, dtype=np.int64)                                   # rng.randint(n_regions): the bound differs between envs
+            for n in np.unique(n_regions):
+                rows = np.nonzero(n_regions == n)[0]
+                odd[rows] = brng.randint(int(n), rows=rows)[:, 0]
+            new = brng.randint(n_names - 1)[:, 0].astype(np.int64)
+            r = np.arange(m)
+            new = np.where(new == block[r, odd], new + 1, new)
+            block[r, odd] = new
+            if self._keep_env is None:
+                self._keep_env = np.tile(np.asarray(self._keep, dtype=bool), (self.n_envs, 1))
+            keep = np.zeros((m, len(sensors)), dtype=bool)
+            rows_c = np.tile(self._default_colours, (m, 1))
+            for i in range(len(sensors)):
+                if i < region.shape[1]:
+                    on = i < n_regions
+                    keep[:, i] = on & (block[:, i] == region[:, i])
+                    rows_c[:, sensors[i].ent_id] = np.where(on, cid[region[:, i]], rows_c[:, sensors[i].ent_id])
+                    rows_c[:, blocks[i].ent_id] = np.where(on, cid[block[:, i]], rows_c[:, blocks[i].ent_id])
+            self._keep_env[env_idx] = keep
+            var['colours'] = rows_c
+        if self.rand_shapes:
+            d = brng.randint(len(en.SHAPE_TYPE_NAMES), counts=n_regions)
+            rows_t = np.tile(self._default_shape_types, (m, 1))
+            for i, b in enumerate(blocks):
+                if i < d.shape[1]:
+                    rows_t[:, b.ent_id] = np.where(i < n_regions, tid[d[:, i]], rows_t[:, b.ent_id])
+            var['shape_types'] = rows_t
+        if self.rand_layout_minor or self.rand_layout_full:
+            minor = self.rand_layout_minor
+            hw_bound = self.JITTER_TARGET_BOUND if minor else None
+            u = brng.random_sample(counts=2 * n_regions)                        # (h, w) of the episode's regions, in order
+            var['goal_hw'] = {}
+            for i, (sensor, xyhw) in enumerate(zip(sensors, DEFAULT_REGION_XYHWS)):
+                if 2 * i + 1 < u.shape[1]:
+                    h, w = uniform_hw(u[:, 2 * i:2 * i + 2], MIN_GOAL_SIZE, MAX_GOAL_SIZE, current_hw=xyhw[2:], linf_bound=hw_bound)
+                    on = i < n_regions
+                    var['goal_hw'][sensor.ent_id] = (np.where(on, h, xyhw[2]), np.where(on, w, xyhw[3]))
+            var['randomise_poses'] = self._pose_stages(minor)
         return var
 
     def on_reset(self):   # fix_colour.py:69-141

@@ -112,6 +112,30 @@ class MakeLineEnv(BaseEnv):
             var['randomise_poses'] = (all_ents, dict(rand_pos=True, rand_rot=True, rel_pos_linf_limits=pos_limits, rel_rot_limits=rot_limit))
         return var
 
+    def sample_variation_batch(self, brng, env_idx):   # the same draws, all envs at once (batch_rng.py)
+        if not (self.rand_colours or self.rand_shapes or self.rand_layout_minor or self.rand_layout_full):
+            return None
+        var, m, blocks = {}, brng.m, self._blocks
+        n_blocks = np.full(m, len(blocks), dtype=np.int32)
+        if self.rand_count:
+            n_blocks = MIN_BLOCKS + brng.randint(MAX_BLOCKS + 1 - MIN_BLOCKS)[:, 0]
+            var['enabled'] = np.ones((m, len(self._entities)), dtype=bool)
+            for i, b in enumerate(blocks):
+                var['enabled'][:, b.ent_id] = i < n_blocks
+        for flag, key, n_choices, table, default in ((self.rand_colours, 'colours', len(en.SHAPE_COLOUR_NAMES), en.colour_id_of_draw(), self._default_colours),
+                                                     (self.rand_shapes, 'shape_types', len(en.SHAPE_TYPE_NAMES), en.type_id_of_draw(), self._default_shape_types)):
+            if flag:
+                d = brng.randint(n_choices, counts=n_blocks)
+                rows = np.tile(default, (m, 1))
+                for i, b in enumerate(blocks):
+                    rows[:, b.ent_id] = np.where(i < n_blocks, table[d[:, i]], rows[:, b.ent_id])
+                var[key] = rows
+        if self.rand_layout_minor or self.rand_layout_full:
+            all_ents = (self._robot, *blocks)
+            pos_limits, rot_limit = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if self.rand_layout_minor else (None, None)
+            var['randomise_poses'] = (all_ents, dict(rand_pos=True, rand_rot=True, rel_pos_linf_limits=pos_limits, rel_rot_limits=rot_limit))
+        return var
+
     def score_on_end_of_traj(self, poses):   # make_line.py:142-152
         bodies = [b.body for b in self._blocks]
         if not self.variable_worlds:

@@ -60,6 +60,55 @@ class MatchRegionsEnv(BaseEnv):
                                                      rel_pos_linf_limits=pos_limits, rel_rot_limits=rot_limits))
         return var
 
+    def sample_variation_batch(self, brng, env_idx):   # the same draws, all envs at once (batch_rng.py)
+        if not (self.rand_target_colour or self.rand_layout_minor or self.rand_layout_full or self.rand_shape_type):
+            return None
+        from ..batch_rng import uniform_hw
+        var, m = {}, brng.m
+        sensor, targets, groups = self.__sensor_ref, self.__target_shapes, self.__distractor_by_group
+        cid, tid = en.colour_id_of_draw(), en.type_id_of_draw()
+        if self.rand_target_colour:
+            t = brng.randint(len(en.SHAPE_COLOUR_NAMES))[:, 0]                     # draw index of the target colour
+            rows = np.tile(self._default_colours, (m, 1))
+            rows[:, [sensor.ent_id] + [s.ent_id for s in targets]] = cid[t][:, None]
+            # distractor group g takes the g-th of the remaining colours, in SHAPE_COLOURS order
+            for s, g in zip(self.__distractor_shapes, self.__distractor_group):
+                rows[:, s.ent_id] = cid[np.where(g < t, g, g + 1)]
+            var['colours'] = rows
+        if self.rand_layout_minor or self.rand_layout_full:
+            hw_bound = self.JITTER_TARGET_BOUND if self.rand_layout_minor else None
+            var['goal_hw'] = {sensor.ent_id: uniform_hw(brng.random_sample(2), self.RAND_GOAL_MIN_SIZE, self.RAND_GOAL_MAX_SIZE,
+                                                       current_hw=(0.7, 0.6), linf_bound=hw_bound)}
+        target_count = np.full(m, len(targets), dtype=np.int32)
+        distractor_counts = [np.full(m, len(g), dtype=np.int32) for g in groups]
+        if self.rand_shape_count:
+            target_count = 1 + brng.randint(2)[:, 0]
+            dc = brng.randint(3, count=len(groups))
+            distractor_counts = [dc[:, g] for g in range(len(groups))]
+            enabled = np.ones((m, len(self._entities)), dtype=bool)
+            for i, s in enumerate(targets):
+                enabled[:, s.ent_id] = i < target_count
+            for g, n in zip(groups, distractor_counts):
+                for i, s in enumerate(g):
+                    enabled[:, s.ent_id] = i < n
+            var['enabled'] = enabled
+        if self.rand_shape_type:
+            types = np.tile(self._default_shape_types, (m, 1))
+            for ents, n in [(targets, target_count)] + list(zip(groups, distractor_counts)):
+                if len(ents) == 0:
+                    continue
+                d = brng.randint(len(en.SHAPE_TYPE_NAMES), counts=n)
+                for i, s in enumerate(ents):
+                    if i < d.shape[1]:
+                        types[:, s.ent_id] = np.where(i < n, tid[d[:, i]], types[:, s.ent_id])
+            var['shape_types'] = types
+        if self.rand_layout_minor or self.rand_layout_full:
+            all_ents = (sensor, self._robot, *targets, *self.__distractor_shapes)
+            pos_limits, rot_limits = (self.JITTER_POS_BOUND, self.JITTER_ROT_BOUND) if self.rand_layout_minor else (None, None)
+            var['randomise_poses'] = (all_ents, dict(rand_pos=True, rand_rot=[False] + [True] * (len(all_ents) - 1),
+                                                     rel_pos_linf_limits=pos_limits, rel_rot_limits=rot_limits))
+        return var
+
     def on_reset(self):   # match_regions.py:44-162
         robot = self._make_robot(np.asarray((-0.5, 0.1)), -math.pi * 1.2)
         target_colour = en.ShapeColour.GREEN

@@ -54,6 +54,21 @@ class MoveToCornerEnv(BaseEnv):
                 rand_pos=True, rand_rot=True, rel_pos_linf_limits=self.JITTER_POS_BOUND, rel_rot_limits=self.JITTER_ROT_BOUND))
         return var
 
+    def sample_variation_batch(self, brng, env_idx):   # the same draws, all envs at once (batch_rng.py)
+        if not (self.rand_shape_colour or self.rand_shape_type or self.rand_poses):
+            return None
+        var, m, shape = {}, brng.m, self.__shape_ref
+        if self.rand_shape_colour:
+            var['colours'] = np.tile(self._default_colours, (m, 1))
+            var['colours'][:, shape.ent_id] = en.colour_id_of_draw()[brng.randint(len(en.SHAPE_COLOUR_NAMES))[:, 0]]
+        if self.rand_shape_type:
+            var['shape_types'] = np.tile(self._default_shape_types, (m, 1))
+            var['shape_types'][:, shape.ent_id] = en.type_id_of_draw()[brng.randint(len(en.SHAPE_TYPE_NAMES))[:, 0]]
+        if self.rand_poses:
+            var['randomise_poses'] = ((self._robot, shape), dict(
+                rand_pos=True, rand_rot=True, rel_pos_linf_limits=self.JITTER_POS_BOUND, rel_rot_limits=self.JITTER_ROT_BOUND))
+        return var
+
     def on_reset(self):   # move_to_corner.py:31-54
         robot = self._make_robot(np.asarray((0.4, -0.0)), 0.55 * math.pi)
         self.add_entities([robot])

@@ -35,6 +35,24 @@ class MoveToRegionEnv(BaseEnv):
                 rand_pos=True, rand_rot=(False, True), rel_pos_linf_limits=pos_limits, rel_rot_limits=rot_limits))
         return var
 
+    def sample_variation_batch(self, brng, env_idx):   # the same draws, all envs at once (batch_rng.py)
+        if not (self.rand_poses_minor or self.rand_poses_full or self.rand_goal_colour):
+            return None
+        from ..batch_rng import uniform_hw
+        var, m, goal = {}, brng.m, self.__goal_ref
+        if self.rand_poses_minor or self.rand_poses_full:
+            hw_bound = self.JITTER_TARGET_BOUND if self.rand_poses_minor else None
+            var['goal_hw'] = {goal.ent_id: uniform_hw(brng.random_sample(2), self.RAND_GOAL_MIN_SIZE, self.RAND_GOAL_MAX_SIZE,
+                                                     current_hw=DEFAULT_GOAL_XYHW[2:], linf_bound=hw_bound)}
+        if self.rand_goal_colour:
+            var['colours'] = np.tile(self._default_colours, (m, 1))
+            var['colours'][:, goal.ent_id] = en.colour_id_of_draw()[brng.randint(len(en.SHAPE_COLOUR_NAMES))[:, 0]]
+        if self.rand_poses_minor or self.rand_poses_full:
+            pos_limits, rot_limits = (self.JITTER_POS_BOUND, [None, self.JITTER_ROT_BOUND]) if self.rand_poses_minor else (None, None)
+            var['randomise_poses'] = ((goal, self._robot), dict(
+                rand_pos=True, rand_rot=(False, True), rel_pos_linf_limits=pos_limits, rel_rot_limits=rot_limits))
+        return var
+
     def on_reset(self):   # move_to_region.py:30-63
         goal = en.GoalRegion(*DEFAULT_GOAL_XYHW, DEFAULT_GOAL_COLOUR)
         self.add_entities([goal])

@@ -325,6 +325,44 @@ int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses
     return randomise_batch([&](int) -> const World & { return w->w; }, ne, m, poses, ents, n, ignore, arena_lrbt, rand_pos, rand_rot,
                            pos_limits, rot_limits, limits_per_env, mt_state_addr, ent_hw);
 }
+// batched RandomState draws: env k's stream at mt_state_addr[k] (numpy's mt19937_state: uint32 key[624]; int pos)
+static bool mt_state_ok(uint64_t addr, uint32_t *&key, int *&pos) {
+    key = reinterpret_cast<uint32_t *>((uintptr_t)addr);
+    pos = reinterpret_cast<int *>((uintptr_t)addr + 624 * sizeof(uint32_t));
+    return key && *pos >= 0 && *pos <= 624;
+}
+int mgx_rng_bounded_batch(int m, const uint64_t *mt_state_addr, const int32_t *counts, int count, int max_inclusive, int32_t *out, int out_stride) {
+    if (m < 0 || !mt_state_addr || !out || max_inclusive < 0 || count < 0 || out_stride < count) return fail(MGX_ERR_ARG, "bad argument");
+    for (int k = 0; k < m; k++) {
+        uint32_t *key; int *pos;
+        if (!mt_state_ok(mt_state_addr[k], key, pos)) return fail(MGX_ERR_ARG, "bad MT19937 state");
+        const int n = counts ? counts[k] : count;
+        if (n < 0 || n > out_stride) return fail(MGX_ERR_ARG, "count out of range");
+        rng_bounded(key, pos, n, (uint32_t)max_inclusive, out + (size_t)k * out_stride);
+    }
+    return MGX_OK;
+}
+int mgx_rng_doubles_batch(int m, const uint64_t *mt_state_addr, const int32_t *counts, int count, double *out, int out_stride) {
+    if (m < 0 || !mt_state_addr || !out || count < 0 || out_stride < count) return fail(MGX_ERR_ARG, "bad argument");
+    for (int k = 0; k < m; k++) {
+        uint32_t *key; int *pos;
+        if (!mt_state_ok(mt_state_addr[k], key, pos)) return fail(MGX_ERR_ARG, "bad MT19937 state");
+        const int n = counts ? counts[k] : count;
+        if (n < 0 || n > out_stride) return fail(MGX_ERR_ARG, "count out of range");
+        rng_doubles(key, pos, n, out + (size_t)k * out_stride);
+    }
+    return MGX_OK;
+}
+int mgx_rng_shuffle_batch(int m, const uint64_t *mt_state_addr, const int32_t *n_items, int32_t *perm, int perm_stride) {
+    if (m < 0 || !mt_state_addr || !n_items || !perm) return fail(MGX_ERR_ARG, "bad argument");
+    for (int k = 0; k < m; k++) {
+        uint32_t *key; int *pos;
+        if (!mt_state_ok(mt_state_addr[k], key, pos)) return fail(MGX_ERR_ARG, "bad MT19937 state");
+        if (n_items[k] < 0 || n_items[k] > perm_stride) return fail(MGX_ERR_ARG, "item count out of range");
+        rng_shuffle(key, pos, n_items[k], perm + (size_t)k * perm_stride);
+    }
+    return MGX_OK;
+}
 int mgx_world_palette(int colour, int role) {
     if (colour < 0 || colour > 3 || role < 0 || role > 2) return fail(MGX_ERR_ARG, "colour 0..3, role 0..2");
     return palette_rgb(colour, role);

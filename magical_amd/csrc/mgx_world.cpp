@@ -239,6 +239,33 @@ struct Mt19937 {
 };
 }  // namespace
 
+// ---- the other draws of the tasks' on_reset() (counts, colours, shape types, sizes), for many envs per call.  numpy's legacy
+// generator: randint(lo, hi) / choice / shuffle all come down to a masked rejection on 32-bit outputs (max = hi - lo - 1:
+// mask = next power of two minus one, redraw while (next32() & mask) > max; max == 0 draws nothing), shuffle(list of n) swaps
+// x[i], x[random_interval(i)] for i = n - 1 .. 1, random_sample() is next_double().
+void rng_bounded(uint32_t *key, int *pos, int count, uint32_t max_inclusive, int32_t *out) {
+    Mt19937 rng{key, pos};
+    uint32_t mask = max_inclusive;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    for (int i = 0; i < count; i++) {
+        uint32_t v = 0;
+        if (max_inclusive != 0) { do { v = rng.next32() & mask; } while (v > max_inclusive); }
+        out[i] = (int32_t)v;
+    }
+}
+void rng_doubles(uint32_t *key, int *pos, int count, double *out) {
+    Mt19937 rng{key, pos};
+    for (int i = 0; i < count; i++) out[i] = rng.next_double();
+}
+void rng_shuffle(uint32_t *key, int *pos, int n, int32_t *perm) {
+    for (int i = 0; i < n; i++) perm[i] = i;
+    for (int i = n - 1; i >= 1; i--) {
+        int32_t j;
+        rng_bounded(key, pos, 1, (uint32_t)i, &j);
+        const int32_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+    }
+}
+
 int World::randomise_all_poses(double *poses, const int *ents, int n, const uint8_t *ignore, const double arena[4],
                                const uint8_t *rand_pos, const uint8_t *rand_rot, const double *pos_limits, const double *rot_limits,
                                uint32_t *mt_key, int *mt_pos, const double *ent_hw) const {

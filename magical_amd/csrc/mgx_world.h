@@ -98,6 +98,12 @@ struct World {
     void serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<double> &rw, std::vector<double> &pw, bool strip_prims = false) const;
 };
 
+// np.random.RandomState primitives on a live mt19937 state (key[624], pos), advanced in place exactly as numpy would:
+// `count` draws of randint(0, max_inclusive + 1); `count` draws of random_sample(); the permutation shuffle() applies to n items
+void rng_bounded(uint32_t *key, int *pos, int count, uint32_t max_inclusive, int32_t *out);
+void rng_doubles(uint32_t *key, int *pos, int count, double *out);
+void rng_shuffle(uint32_t *key, int *pos, int n, int32_t *perm);
+
 // RGB8 (r | g << 8 | b << 16) of entity colour 0..3 in role 0 darkened / 1 base / 2 lightened twice (style.py:28-37)
 int palette_rgb(int colour, int role);
 

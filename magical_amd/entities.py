@@ -87,6 +87,18 @@ def shape_types_obj():
     return SHAPE_TYPES_OBJ
 
 
+def colour_id_of_draw():
+    """native colour id of draw index i into SHAPE_COLOUR_NAMES (batched draws)."""
+    import numpy as np
+    return np.array([COLOUR_ID[c] for c in SHAPE_COLOURS], dtype=np.int64)
+
+
+def type_id_of_draw():
+    """native shape-type id of draw index i into SHAPE_TYPE_NAMES (batched draws)."""
+    import numpy as np
+    return np.array([SHAPE_TYPE_ID[t] for t in SHAPE_TYPES], dtype=np.int32)
+
+
 def draw_choice(rng, seq, size=None):
     """rng.choice(seq[, size=n]) of the reference's per-episode draws, without numpy's argument handling: choice() is
     randint(0, len(seq)[, size]) followed by indexing, so the stream advances identically (tests/test_host_api.py);

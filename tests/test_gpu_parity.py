@@ -1169,3 +1169,33 @@ def test_task_fleet_equals_engines_run_one_by_one():
         fleet.close()
     for (sa, oa), (sb, ob) in zip(zip(*outs[0]), zip(*outs[1])):
         assert np.array_equal(sa, sb) and torch.equal(oa, ob)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('env_name', [n for n in _variant_names() if '-Demo-' not in n])
+def test_batched_draws_equal_the_per_env_loop(env_name):
+    """Every Test* variant: the per-episode draws made for all envs of a reset at once (batch_rng.BatchRng over the native
+    mgx_rng_*_batch primitives, on the envs' live numpy MT19937 states) give, bit for bit, what the per-env Python loop over
+    np.random.RandomState calls gives -- worlds, colours, force limits, goal rectangles, poses, the tasks' per-env score tables,
+    first observations -- over three consecutive resets, and leave every stream in the same state."""
+    import torch
+    name = env_name.replace('-v0', '-LoRes4E-v0')
+    n, ep = 40, 2
+    a = _make(name, n, max_episode_steps=ep); b = _make(name, n, max_episode_steps=ep, batch_draws=False)
+    a.seed(91); b.seed(91)
+    oa, ob = a.reset(), b.reset()
+    act = np.zeros(n, dtype=np.int32)
+    for episode in range(3):
+        assert torch.equal(oa, ob), (env_name, episode)
+        assert np.array_equal(a.entity_shape_types, b.entity_shape_types) and np.array_equal(a.entity_enabled, b.entity_enabled)
+        assert np.array_equal(a.entity_colours, b.entity_colours) and np.array_equal(a.phys_vars, b.phys_vars)
+        assert np.array_equal(a.goal_xyhw, b.goal_xyhw) and np.array_equal(a.entity_poses, b.entity_poses)
+        assert torch.equal(a.state_p, b.state_p) and torch.equal(a.state_f, b.state_f)
+        for attr in a.TASK_STATE_ATTRS:
+            va, vb = getattr(a, attr), getattr(b, attr)
+            assert (va is None) == (vb is None) and (va is None or np.array_equal(va, vb)), (env_name, attr)
+        for _ in range(ep):
+            oa, _, da, ia = a.step(act); ob, _, db, ib = b.step(act)
+        assert da.all() and np.array_equal(ia['eval_score'], ib['eval_score'])
+    assert all(x.randint(1 << 30) == y.randint(1 << 30) for x, y in zip(a.rngs, b.rngs))
+    a.close(); b.close()
