@@ -20,7 +20,9 @@
  * container and the reference's tests hold no numeric vectors, so this file
  * cannot be checked against the real engines here.  What IS pinned: analytic
  * known-answer tests (tests/test_oracle_*.py), Appendix-D constants and the
- * reference's images/static-*.png initial frames.
+ * reference's images/static-*.png initial frames.  (The Python side of the
+ * oracle -- palette, force-limit draws, polygon sizing, scores -- IS pinned on
+ * outputs of the reference's own code: oracle/__init__.py.)
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load the library built from this file.  Build: see oracle/Makefile

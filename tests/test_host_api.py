@@ -293,3 +293,46 @@ def test_cheap_draws_advance_the_stream_like_the_reference_calls():
             h, w = a.uniform(minima, maxima)                       # geom.py:344-360
             assert geom.randomise_hw(0.5, 0.8, b, **kw) == (h, w)
         assert a.random_sample() == b.random_sample()
+
+
+def test_batched_rng_primitives_equal_numpy():
+    """mgx_rng_bounded / doubles / shuffle_batch (batch_rng.BatchRng) draw from live np.random.RandomState streams exactly what
+    rng.randint / rng.choice / rng.random_sample / rng.shuffle draw, and leave the streams where numpy leaves them."""
+    from magical_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        pytest.skip('HIP library not built')
+    from magical_amd.batch_rng import BatchRng
+    m = 150
+    rngs = [np.random.RandomState(100 + k) for k in range(m)]
+    refs = [np.random.RandomState(100 + k) for k in range(m)]
+    brng = BatchRng(rngs)
+    for rnd in range(25):
+        rs = np.random.RandomState(rnd)
+        n = int(rs.randint(1, 40))
+        counts = rs.randint(0, 7, size=m)
+        out = brng.randint(n, counts=counts)
+        for k, r in enumerate(refs):
+            want = r.randint(0, n, size=counts[k]) if counts[k] else []
+            assert list(out[k, :counts[k]]) == list(want)
+        d = brng.random_sample(3)
+        for k, r in enumerate(refs):
+            assert np.array_equal(d[k], r.random_sample(3))
+        items = rs.randint(0, 12, size=m)
+        perm = brng.shuffle(items)
+        for k, r in enumerate(refs):
+            lst = list(range(100, 100 + items[k]))
+            r.shuffle(lst)
+            assert lst == [100 + p for p in perm[k, :items[k]]]
+        one = brng.randint(4)[:, 0]                      # rng.choice(seq of 4) indexes with this
+        names = np.asarray(['a', 'b', 'c', 'd'], dtype='object')
+        for k, r in enumerate(refs):
+            assert names[one[k]] == r.choice(names)
+        rows = np.nonzero(rs.rand(m) < 0.4)[0]           # a subset of the envs draws (per-env bounds)
+        sub = brng.randint(3, rows=rows)[:, 0]
+        for v, k in zip(sub, rows):
+            assert v == refs[k].randint(3)
+    assert all(a.randint(1 << 30) == b.randint(1 << 30) for a, b in zip(rngs, refs))
+    # PhysicsVariables.sample for a batch
+    from magical_amd.base_env import PhysicsVariables
+    got = PhysicsVariables.sample_batch(brng)
+    assert np.array_equal(got, np.array([PhysicsVariables.sample(r) for r in refs]))

@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -q -x -k "batched_draws" 2>&1 | tail -25
-timeout 300 python tools/reset_profile.py ClusterColour-TestAll-LoRes4E-v0 2>&1 | head -12
-timeout 300 python tools/reset_profile.py MatchRegions-TestCountPlus-LoRes4E-v0 2>&1 | head -4
+timeout 1500 python tools/rollout_all_tasks.py --variant all --envs 4096 > gpurun_out/r02_rollout_all_60_variants_4096x1gpu.jsonl 2> gpurun_out/rollout.err
+wc -l gpurun_out/r02_rollout_all_60_variants_4096x1gpu.jsonl; tail -2 gpurun_out/rollout.err
