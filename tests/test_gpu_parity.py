@@ -280,13 +280,13 @@ def test_render_queue_overflow_rounds(task):
     env.close()
 
 
+@pytest.mark.parametrize('task', ['MatchRegions', 'ClusterColour', 'MoveToRegion', 'FixColour'])
 @pytest.mark.parametrize('preproc', ['LoRes3EA', 'LoResStack', 'LoRes4A', 'LoResCHW4E'])
-def test_other_preprocessors_match_oracle(preproc):
+def test_other_preprocessors_match_oracle(preproc, task):
     """The remaining wrapper stacks of benchmarks/__init__.py:242-268 on device, byte for byte against the oracle's
-    restatement of the same wrappers, across an auto-reset."""
+    restatement of the same wrappers, across an auto-reset (goal regions, stars, circles and many blocks in view)."""
     from oracle.env_ref import LoRes3EARef, LoRes4ERef, LoResStackRef, RefEnv
-    n, steps, ep = 2, 7, 5
-    task = 'MatchRegions'
+    n, steps, ep = 3, 8, 5
     env = _make(f'{task}-Demo-{preproc}-v0', n, dtype='f64', max_episode_steps=ep)
 
     class LoRes4ARef(LoRes4ERef):          # FlattenFrameStack(allo=4, ego=0): the same pipeline on the other view
