@@ -128,7 +128,8 @@ class MakeLineEnv(BaseEnv):
                 d = brng.randint(n_choices, counts=n_blocks)
                 rows = np.tile(default, (m, 1))
                 for i, b in enumerate(blocks):
-                    rows[:, b.ent_id] = np.where(i < n_blocks, table[d[:, i]], rows[:, b.ent_id])
+                    if i < d.shape[1]:          # (no env of this reset drew that many blocks otherwise)
+                        rows[:, b.ent_id] = np.where(i < n_blocks, table[d[:, i]], rows[:, b.ent_id])
                 var[key] = rows
         if self.rand_layout_minor or self.rand_layout_full:
             all_ents = (self._robot, *blocks)

@@ -1172,15 +1172,16 @@ def test_task_fleet_equals_engines_run_one_by_one():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n', [2, 40])
 @pytest.mark.parametrize('env_name', [n for n in _variant_names() if '-Demo-' not in n])
-def test_batched_draws_equal_the_per_env_loop(env_name):
+def test_batched_draws_equal_the_per_env_loop(env_name, n):
     """Every Test* variant: the per-episode draws made for all envs of a reset at once (batch_rng.BatchRng over the native
     mgx_rng_*_batch primitives, on the envs' live numpy MT19937 states) give, bit for bit, what the per-env Python loop over
     np.random.RandomState calls gives -- worlds, colours, force limits, goal rectangles, poses, the tasks' per-env score tables,
     first observations -- over three consecutive resets, and leave every stream in the same state."""
     import torch
     name = env_name.replace('-v0', '-LoRes4E-v0')
-    n, ep = 40, 2
+    ep = 2                         # (n = 2: batches in which no env draws the largest count / world)
     a = _make(name, n, max_episode_steps=ep); b = _make(name, n, max_episode_steps=ep, batch_draws=False)
     a.seed(91); b.seed(91)
     oa, ob = a.reset(), b.reset()
