@@ -149,6 +149,8 @@ def main():
     ap.add_argument('--lanes', type=int, default=0)
     ap.add_argument('--dtype', default='f32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--obs-ring', type=int, default=0, help='with a -LoResCHW4E- task: frames kept as planes in a ring of this many frames '
+                    '(MGX_OBS_PLANAR; the channels-first stack is a window of the ring), priced on the 28.3 KB row of SURVEY.md 8(d)')
     ap.add_argument('--config5', action='store_true', help='BASELINE.json configs[4]: all 8 tasks x Demo-LoRes4E, --envs5 envs per task sharded over '
                                                            'the GPUs, one engine + HIP stream per task on every GPU, one RCCL gather at the end')
     ap.add_argument('--envs5', type=int, default=8192, help='envs per task over the whole job (config 5)')
@@ -165,7 +167,8 @@ def main():
     device = f'cuda:{local_rank}'
 
     import magical_amd
-    env = magical_amd.make(args.task, n_envs=args.envs, device=device, lanes_per_env=args.lanes, dtype=args.dtype)
+    env = magical_amd.make(args.task, n_envs=args.envs, device=device, lanes_per_env=args.lanes, dtype=args.dtype, obs_ring=args.obs_ring)
+    ring = bool(args.obs_ring) and '-LoResCHW4E-' in args.task
     n, K, W = args.envs, args.steps, args.warmup
     # The metric includes auto-reset + scoring at episode ends.  A timed region shorter than an episode
     # (the driver's 20 steps vs 80) would never see one, so the envs are first rolled, untimed, to K // 2 steps before their
@@ -233,6 +236,8 @@ def main():
         state_bytes = rows_p * env.state_p.element_size() + (rows_f - 4 * slots) * env.state_f.element_size() + 12 + 20 * mean_cache
         step_bytes = n * (2 * state_bytes + 4 + 1)
         rast_bytes = n * (96 * 96 * (9 + 12) + rows_p * env.state_p.element_size())
+        if ring:      # one new planar frame per env and step; the wrap copy (3 frames read + written every R-3 steps) is torch's, not the kernel's
+            rast_bytes = n * (96 * 96 * 3 + rows_p * env.state_p.element_size())
         renders = len(rast_ms) > 0        # a task name without a preprocessor is the state-only configuration
         kernels = {'k_step': (float(step_ms.mean()), step_bytes)}
         if renders:
@@ -265,7 +270,8 @@ def main():
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.dtype == 'f32' else args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{args.task}, {n} envs per GPU, random actions, auto-reset every {env.max_episode_steps} steps, '
-                                   + ('obs u8[N,96,96,12] (4 ego frames, oldest first)' if '-LoRes4E-' in args.task else
+                                   + (f'obs u8[N,12,96,96] = window of a ring u8[N,{args.obs_ring},3,96,96] of planar frames' if ring else
+                                      'obs u8[N,96,96,12] (4 ego frames, oldest first)' if '-LoRes4E-' in args.task else
                                       'rendered observation' if renders else 'obs f32[N,n_bodies,3] poses'),
                        'n_envs_per_gpu': n, 'lanes_per_env': env.lanes_per_env, 'episodes_finished': n_eps * world,
                        'mean_eval_score': float(all_scores.mean().item()),
@@ -273,7 +279,8 @@ def main():
                        'arith': 'fp32 velocities/impulses/contacts + fp64 poses; fp64 rasteriser' if args.dtype == 'f32' else args.dtype,
                        'broadphase': 'pre-filtered candidate-pair list, AABB-tested brute force, compacted in pair order through LDS counters '
                                      '(<= 27 shapes per env: measured faster than sort-and-sweep; DESIGN.md 3.1)',
-                       'roofline_bytes_row': 'SURVEY.md 8(d) parenthetical row: [96,96,12] stack re-materialised each step (9 B read + 12 B '
+                       'roofline_bytes_row': 'SURVEY.md 8(d) headline row: state + ONE new 96x96x3 frame per env-step (ring of planar frames)' if ring else
+                                             'SURVEY.md 8(d) parenthetical row: [96,96,12] stack re-materialised each step (9 B read + 12 B '
                                              'written per pixel + pose rows); frac_new_frame_row uses the 28.3 KB headline row'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,

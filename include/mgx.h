@@ -48,6 +48,11 @@ enum mgx_obs_layout {
      * the same u8[N][96][96][12] tensor, one launch per view: */
     MGX_OBS_STACK3_HI = 2,  /* channels 3..11: depth-3 stack of this view, shifted in place; channels 0..2 untouched */
     MGX_OBS_SLOT_LO = 3,    /* channels 0..2 <- this view's new frame; channels 3..11 untouched */
+    /* u8[3][96][96] per env: the new frame as three channel planes, nothing else read or written.  `out` + env * env_stride
+     * addresses the frame's slot in a caller-owned ring u8[N][R][3][96][96]: with frames kept as planes the channels-first stack
+     * of the 4 newest frames (LoResCHW4E, benchmarks/__init__.py:262-268) is a contiguous window u8[12][96][96] of the ring, so a
+     * step writes 27.6 KB per env (SURVEY.md 8(d)'s headline row) instead of re-materialising the 110 KB stack */
+    MGX_OBS_PLANAR = 4,
 };
 
 const char *mgx_last_error(void);

@@ -17,7 +17,7 @@ _DEPS = _SOURCES + ['mgx_step.hip', 'mgx_raster.hip', 'mgx_raster_body.inc', 'mg
 # enums (include/mgx.h)
 MGX_F32, MGX_F64, MGX_F32_PURE = 0, 1, 2
 VIEW_EGO, VIEW_ALLO = 0, 1
-OBS_FRAME, OBS_STACK4, OBS_STACK3_HI, OBS_SLOT_LO = 0, 1, 2, 3
+OBS_FRAME, OBS_STACK4, OBS_STACK3_HI, OBS_SLOT_LO, OBS_PLANAR = 0, 1, 2, 3, 4
 INFO = {k: i for i, k in enumerate([
     'n_bodies', 'n_shapes', 'n_joints', 'n_pairs', 'n_prims', 'state_rows_p', 'state_rows_f', 'state_rows_i',
     'robot_body', 'n_entities', 'cache_slots', 'max_contacts', 'max_episode_steps', 'n_jacc', 'physvar_row'])}

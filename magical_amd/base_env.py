@@ -24,6 +24,7 @@ clone per call (one extra 110 KB/env device copy per step).
 """
 import abc
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -86,7 +87,8 @@ class BaseEnv(abc.ABC):
 
     def __init__(self, *, n_envs=1, device='cuda:0', res_hw=(384, 384), fps=8, phys_steps=10, phys_iter=10,
                  max_episode_steps=None, rand_dynamics=False, ego_view=True, allo_view=True,
-                 dtype='f32', lanes_per_env=0, auto_reset=True, copy_obs=False, strict_capacity=False, overlap=True, batch_draws=True):
+                 dtype='f32', lanes_per_env=0, auto_reset=True, copy_obs=False, strict_capacity=False, overlap=True, batch_draws=True,
+                 obs_ring=None):
         import torch
         if fps != 8 or phys_steps != 10 or phys_iter != 10:
             raise NotImplementedError('the engine is built for the registered rates: fps=8, 10 substeps, 10 iterations '
@@ -101,6 +103,11 @@ class BaseEnv(abc.ABC):
             raise nat.MgxError('magical_amd runs on an MI355X (torch device "cuda:N"); there is no CPU fallback')
         if self.device.index is None:      # 'cuda' = torch's current device, pinned now (the engine lives on one GPU)
             self.device = torch.device('cuda', torch.cuda.current_device())
+        # LoResCHW4E only: keep the last `obs_ring` frames as channel planes u8[N, R, 3, 96, 96] and hand out windows of that ring
+        # (benchmarks/preproc.py); None reads MGX_OBS_RING, 0 = the in-place 12-channel stack
+        self.obs_ring = int(os.environ.get('MGX_OBS_RING', '0')) if obs_ring is None else int(obs_ring)
+        if self.obs_ring and self.obs_ring < 5:
+            raise ValueError('obs_ring: at least 5 frames (4 in the window + the one being written)')
         self.batch_draws = bool(batch_draws)   # per-episode draws of all envs of a reset per native call (batch_rng.py) instead of env by env
         self.overlap = bool(overlap)       # step(): physics + observation as a producer / consumer kernel pair (mgx_engine_step_render)
         self._obs_ready = False
@@ -766,8 +773,10 @@ class BaseEnv(abc.ABC):
 
     def render_frames(self, out, view='ego', layout='frame', fill_mask=None):
         """Rasterise every env into `out` (torch.uint8 on the engine device): [N,96,96,3] or [N,96,96,12]."""
-        lay = {'frame': nat.OBS_FRAME, 'stack4': nat.OBS_STACK4, 'stack3_hi': nat.OBS_STACK3_HI, 'slot_lo': nat.OBS_SLOT_LO}[layout]
-        assert out.is_contiguous() and out.device == self.device and out.shape[0] == self.n_envs
+        lay = {'frame': nat.OBS_FRAME, 'stack4': nat.OBS_STACK4, 'stack3_hi': nat.OBS_STACK3_HI, 'slot_lo': nat.OBS_SLOT_LO,
+               'planar': nat.OBS_PLANAR}[layout]
+        # one env's pixels are contiguous; envs may be strided (a slot of a ring of frames)
+        assert out[0].is_contiguous() and out.device == self.device and out.shape[0] == self.n_envs
         nat.check(self._lib.mgx_engine_render(self._engine, self.state_p.data_ptr(), out.data_ptr(), out.stride(0),
                                               nat.VIEW_EGO if view == 'ego' else nat.VIEW_ALLO, lay,
                                               None if fill_mask is None else fill_mask.data_ptr(), self._stream()))

@@ -9,6 +9,15 @@ In the reference these are gym.Wrappers around one env; here they are a mixin th
     LoResCHW4E          LoRes4E moved to channels-first (a view, no copy)     (:262-268)
     LoRes3EA            [allo_t, ego_t-2, ego_t-1, ego_t]                      (:242-245)
     LoResStack          {'allo': 4 allo frames, 'ego': 4 ego frames}           (:257-261)
+
+LoResCHW4E with `obs_ring=R` (or MGX_OBS_RING=R): the frames are kept as channel planes in a ring
+u8[N, R, 3, 96, 96] instead.  A channels-first stack of four consecutive frames is then the contiguous window
+ring.view(N, 3R, 96, 96)[:, 3(k-3) : 3(k+1)] of that ring: the rasteriser writes ONE 27.6 KB frame per env and step
+(layout MGX_OBS_PLANAR) and nothing is shifted.  When the window reaches the end of the ring its last three frames are
+copied to the front (once every R-3 steps), and an env whose episode ended gets its three older slots filled with the
+new episode's first frame.  The bytes handed out are those of the in-place stack, and unlike it, an observation stays
+valid for at least R-7 further steps of the same episode (until its oldest slot is written again; an auto-reset refills
+the three older slots of the envs it resets).
 """
 
 
@@ -28,15 +37,48 @@ def wrap_preproc(env_cls, preproc):
             self._stack = mk()
             self._stack_allo = mk() if preproc == 'LoResStack' else None
             self._ones = torch.ones(self.n_envs, dtype=torch.uint8, device=self.device)
+            self._ring = None
+            if preproc == 'LoResCHW4E' and self.obs_ring:
+                self._ring = torch.zeros((self.n_envs, self.obs_ring, 3, 96, 96), dtype=torch.uint8, device=self.device)
+                self._ring_k = 2           # slot of the newest frame (none yet)
+
+        # ---- ring of planar frames
+        def _ring_next_slot(self):
+            """Advance the window by one frame and return the slot u8[N, 3, 96, 96] the new frame goes to."""
+            k = self._ring_k + 1
+            if k == self.obs_ring:       # wrap: the three frames that stay in the window move to the front
+                src = self._ring[:, k - 3:k]
+                self._ring[:, 0:3].copy_(src.clone() if k < 6 else src)      # R = 5: source and destination share slot 2
+                k = 3
+            self._ring_k = k
+            return self._ring[:, k]
+
+        def _ring_window(self):
+            k = self._ring_k
+            return self._ring.view(self.n_envs, 3 * self.obs_ring, 96, 96)[:, 3 * (k - 3):3 * (k + 1)]
+
+        def _ring_fill(self, fill_all, fill_mask):
+            """FrameStack.reset(): the envs of the mask see their new first frame four times."""
+            import torch
+            k = self._ring_k
+            old, new = self._ring[:, k - 3:k], self._ring[:, k:k + 1]
+            if fill_all:
+                old.copy_(new.expand_as(old))
+            elif fill_mask is not None:
+                old.copy_(torch.where(fill_mask.view(-1, 1, 1, 1, 1) != 0, new, old))
 
         def get_state(self):
             d = super().get_state()
-            d['stack'] = self._stack.clone()
+            d['stack'] = self._stack.clone() if self._ring is None else self._ring_window().clone()
             d['stack_allo'] = None if self._stack_allo is None else self._stack_allo.clone()
             return d
 
         def set_state(self, d):
             super().set_state(d)
+            if self._ring is not None:
+                self._ring_k = 3
+                self._ring[:, 0:4].copy_(d['stack'].view(self.n_envs, 4, 3, 96, 96))
+                return
             self._stack.copy_(d['stack'])
             if self._stack_allo is not None:
                 self._stack_allo.copy_(d['stack_allo'])
@@ -50,12 +92,20 @@ def wrap_preproc(env_cls, preproc):
             from .. import _native as nat
             if preproc in ('LoRes3EA', 'LoResStack'):
                 return None
+            if self._ring is not None:
+                return self._ring_next_slot(), nat.VIEW_EGO, nat.OBS_PLANAR
             return self._stack, (nat.VIEW_ALLO if preproc == 'LoRes4A' else nat.VIEW_EGO), nat.OBS_STACK4
 
         def _observe(self, fill_all=False, fill_mask=None):
             if self._obs_ready:            # this step's frame is already in the stack (fused step + render)
                 self._obs_ready = False
+                if self._ring is not None:
+                    return self._ring_window()
                 return self._stack.permute(0, 3, 1, 2) if preproc == 'LoResCHW4E' else self._stack
+            if self._ring is not None:
+                self.render_frames(self._ring_next_slot(), view='ego', layout='planar')
+                self._ring_fill(fill_all, fill_mask)
+                return self._ring_window()
             if fill_all:
                 fill_mask = self._ones
             if preproc == 'LoRes3EA':

@@ -711,7 +711,7 @@ static int launch_raster(mgx_engine *e, const void *sp, uint8_t *out, int64_t en
     auto by_layout = [&](auto waves) -> int {
         constexpr int W = decltype(waves)::value;
         return layout == MGX_OBS_FRAME ? go(k_raster<P, 0, W>) : layout == MGX_OBS_STACK4 ? go(k_raster<P, 1, W>)
-             : layout == MGX_OBS_STACK3_HI ? go(k_raster<P, 2, W>) : go(k_raster<P, 3, W>);
+             : layout == MGX_OBS_STACK3_HI ? go(k_raster<P, 2, W>) : layout == MGX_OBS_SLOT_LO ? go(k_raster<P, 3, W>) : go(k_raster<P, 4, W>);
     };
     int rc = e->raster_waves >= 5 ? by_layout(std::integral_constant<int, 5>{})
            : e->raster_waves == 4 ? by_layout(std::integral_constant<int, 4>{}) : by_layout(std::integral_constant<int, 3>{});
@@ -730,7 +730,7 @@ static int launch_raster_deferred(mgx_engine *e, const void *sp, uint8_t *out, i
         return MGX_OK;
     };
     int rc = layout == MGX_OBS_FRAME ? go(k_raster_deferred<P, 0>) : layout == MGX_OBS_STACK4 ? go(k_raster_deferred<P, 1>)
-           : layout == MGX_OBS_STACK3_HI ? go(k_raster_deferred<P, 2>) : go(k_raster_deferred<P, 3>);
+           : layout == MGX_OBS_STACK3_HI ? go(k_raster_deferred<P, 2>) : layout == MGX_OBS_SLOT_LO ? go(k_raster_deferred<P, 3>) : go(k_raster_deferred<P, 4>);
     if (rc) return rc;
     HIP_OK(hipGetLastError());
     return MGX_OK;
@@ -741,8 +741,8 @@ int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t 
                       const uint8_t *fill_mask, void *stream) {
     if (!e || !state_p || !out) return fail(MGX_ERR_ARG, "NULL argument");
     if (view != MGX_VIEW_EGO && view != MGX_VIEW_ALLO) return fail(MGX_ERR_ARG, "bad view");
-    if (layout < MGX_OBS_FRAME || layout > MGX_OBS_SLOT_LO) return fail(MGX_ERR_ARG, "bad layout");
-    int64_t need = (int64_t)LORES * LORES * (layout == MGX_OBS_FRAME ? 3 : 12);
+    if (layout < MGX_OBS_FRAME || layout > MGX_OBS_PLANAR) return fail(MGX_ERR_ARG, "bad layout");
+    int64_t need = (int64_t)LORES * LORES * (layout == MGX_OBS_FRAME || layout == MGX_OBS_PLANAR ? 3 : 12);
     if (env_stride < need || (env_stride & 3)) return fail(MGX_ERR_ARG, "env_stride too small or not a multiple of 4");
     if (int rc = raster_capacity_ok(e)) return rc;
     ON_DEVICE(e);
@@ -759,8 +759,8 @@ int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t 
                            uint8_t *out, int64_t env_stride, int view, int layout, void *stream) {
     if (!e || !state_p || !state_f || !state_i || !actions || !out) return fail(MGX_ERR_ARG, "NULL argument");
     if (view != MGX_VIEW_EGO && view != MGX_VIEW_ALLO) return fail(MGX_ERR_ARG, "bad view");
-    if (layout < MGX_OBS_FRAME || layout > MGX_OBS_SLOT_LO) return fail(MGX_ERR_ARG, "bad layout");
-    int64_t need = (int64_t)LORES * LORES * (layout == MGX_OBS_FRAME ? 3 : 12);
+    if (layout < MGX_OBS_FRAME || layout > MGX_OBS_PLANAR) return fail(MGX_ERR_ARG, "bad layout");
+    int64_t need = (int64_t)LORES * LORES * (layout == MGX_OBS_FRAME || layout == MGX_OBS_PLANAR ? 3 : 12);
     if (env_stride < need || (env_stride & 3)) return fail(MGX_ERR_ARG, "env_stride too small or not a multiple of 4");
     if (int rc = raster_capacity_ok(e)) return rc;
     // the consumers may only wait for producers that are all resident at once: one single-wave workgroup per SIMD at most

@@ -70,7 +70,9 @@ constexpr int ECAP = 256;      // phase E records per round (uncertain pixels be
 //   2 STACK3HI depth 3 in bytes 3..11 (the 3 ego frames of LoRes3EA): bytes 3..8 <- bytes 6..11, bytes 9..11 <- new
 //   3 SLOT0    bytes 0..2 <- new frame, the rest untouched (the allo frame of LoRes3EA)
 // after a reset (`fill`) every frame of the stack is the new one.
-constexpr int LAY_FRAME = 0, LAY_STACK4 = 1, LAY_STACK3HI = 2, LAY_SLOT0 = 3;
+//   4 PLANAR   u8[3][96][96] channel planes of the new frame only (one slot of a caller-owned ring of frames: channels-first
+//              stacks are then contiguous windows of the ring, nothing is shifted)
+constexpr int LAY_FRAME = 0, LAY_STACK4 = 1, LAY_STACK3HI = 2, LAY_SLOT0 = 3, LAY_PLANAR = 4;
 struct OldPx { uint32_t o0, o1, o2; };
 template <int LAYOUT> __device__ __forceinline__ bool layout_needs_old(bool fill) { return LAYOUT == LAY_STACK4 ? !fill : true; }
 template <int LAYOUT> __device__ __forceinline__ OldPx load_old(const uint8_t *frame, int X, int Y) {
@@ -140,6 +142,10 @@ template <int LAYOUT> __device__ __forceinline__ void store_patch(uint8_t *frame
     const int first = LAYOUT == LAY_SLOT0 ? 0 : (fill ? (LAYOUT == LAY_STACK4 ? 0 : 3) : 9);   // after a reset every frame of the stack
     const int last = LAYOUT == LAY_SLOT0 ? 3 : 12;
     for (int k = first; k < last; k += 3) { px[k] = r; px[k + 1] = g; px[k + 2] = b; }
+}
+__device__ __forceinline__ void store_planar_px(uint8_t *frame, int X, int Y, int c) {
+    uint8_t *q = frame + (Y * LORES + X);          // a tile row = 16 consecutive bytes per plane
+    q[0] = c & 0xFF; q[LORES * LORES] = (c >> 8) & 0xFF; q[2 * LORES * LORES] = (c >> 16) & 0xFF;
 }
 __device__ __forceinline__ void store_frame_px(uint8_t *frame, int X, int Y, int c) {
     uint8_t *q = frame + (long)(Y * LORES + X) * 3;

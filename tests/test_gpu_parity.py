@@ -1149,6 +1149,60 @@ def test_fused_step_render_equals_the_two_calls(name, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name,n,ring,overlap', [('MoveToCorner-Demo-LoResCHW4E-v0', 4096, 8, True), ('MoveToCorner-Demo-LoResCHW4E-v0', 300, 5, False),
+                                                 ('ClusterColour-TestAll-LoResCHW4E-v0', 257, 6, True), ('MatchRegions-TestJitter-LoResCHW4E-v0', 67, 11, True)])
+def test_planar_frame_ring_equals_the_inplace_stack(name, n, ring, overlap):
+    """LoResCHW4E from a ring of planar frames (layout MGX_OBS_PLANAR, obs_ring=R) against the in-place 12-channel stack moved to
+    channels-first: the same bytes at every step of a rollout that wraps the ring several times and crosses episode ends
+    (all envs at once here; partial masks in the next test), and an observation stays valid for R-7 more steps of its episode."""
+    import torch
+    ep = 9
+    a = _make(name, n, max_episode_steps=ep, obs_ring=ring, overlap=overlap); b = _make(name, n, max_episode_steps=ep, overlap=overlap)
+    a.seed(5); b.seed(5)
+    oa, ob = a.reset(), b.reset()
+    assert oa.shape == ob.shape == (n, 12, 96, 96) and torch.equal(oa, ob)
+    T = 3 * ep + 2
+    tape = _tape(17, T, n)
+    kept = []
+    for s in range(T):
+        oa, _, da, ia = a.step(tape[s])
+        ob, _, db, ib = b.step(tape[s])
+        assert torch.equal(oa, ob), (name, s, int((oa != ob).sum()))
+        assert np.array_equal(da, db) and np.array_equal(ia['eval_score'], ib['eval_score'])
+        if da.any():
+            kept.clear()        # an auto-reset refills the finished envs' three older slots
+        kept.append((oa, ob.clone()))
+        if len(kept) > max(ring - 7, 0):
+            old_view, old_copy = kept.pop(0)
+            assert torch.equal(old_view, old_copy), (name, s, 'an observation of the ring changed within R-7 steps')
+    # get_state / set_state round trip
+    st = a.get_state()
+    o1 = a.step(tape[0])[0].clone()
+    a.set_state(st)
+    assert torch.equal(a.step(tape[0])[0], o1)
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_planar_frame_ring_partial_episode_ends():
+    """Envs that finish at different steps (episode clocks set apart by hand): only the finished envs' older slots are filled."""
+    import torch
+    name, n, ep = 'MoveToCorner-Demo-LoResCHW4E-v0', 130, 6
+    a = _make(name, n, max_episode_steps=ep, obs_ring=7); b = _make(name, n, max_episode_steps=ep)
+    a.seed(1); b.seed(1)
+    a.reset(); b.reset()
+    for e in (a, b):
+        e._steps[::3] += 2; e._steps[1::3] += 4
+        e.state_i[0].copy_(torch.as_tensor(e._steps, device=e.device, dtype=e.state_i.dtype))
+    tape = _tape(23, 20, n)
+    for s in range(20):
+        oa, _, da, _ = a.step(tape[s]); ob, _, db, _ = b.step(tape[s])
+        assert np.array_equal(da, db)
+        assert torch.equal(oa, ob), (s, int((oa != ob).sum()))
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_task_fleet_equals_engines_run_one_by_one():
     """BASELINE.json configs[4] shape on one GPU: the 8 Demo tasks as 8 engines on 8 HIP streams (distributed.TaskFleet) give
     the scores and final observations of the same engines stepped one after the other."""
