@@ -170,17 +170,33 @@ def main():
     env = magical_amd.make(args.task, n_envs=args.envs, device=device, lanes_per_env=args.lanes, dtype=args.dtype, obs_ring=args.obs_ring)
     ring = bool(args.obs_ring) and '-LoResCHW4E-' in args.task
     n, K, W = args.envs, args.steps, args.warmup
-    # The metric includes auto-reset + scoring at episode ends.  A timed region shorter than an episode
-    # (the driver's 20 steps vs 80) would never see one, so the envs are first rolled, untimed, to K // 2 steps before their
-    # episode ends, so that the K timed steps contain one episode end of every env (one per 80 env-steps is the long-run rate:
-    # a 20-step window carries four times its share of that cost, a 400-step window exactly its share).
+    # The metric includes auto-reset + scoring at episode ends: one per env per `ep` env-steps in the long run.  A
+    # timed region shorter than an episode (the driver's 20 steps vs 80) would see none, or -- with every env's end rolled into
+    # it -- ep / K times its share.  So a K-step window is given exactly its long-run share: the first n * K / ep envs have
+    # their episode clocks set ahead (set_episode_steps) so that their episodes end in the middle of the window -- scoring,
+    # auto-reset and frame-stack refill of that many envs are inside the timed region -- and the other envs are mid-episode (the
+    # window covers the middle K steps of their episode; the untimed preroll takes them there).  K >= ep: the window
+    # contains K / ep whole episodes of every env as it is, nothing is set ahead.
     ep = env.max_episode_steps
-    preroll = (ep - K // 2 - W) % ep if K < ep else 0
+    preroll, share = 0, 0
+    if K < ep:
+        start_phase = max(W, (ep - K) // 2)             # episode step of the untouched envs at the start of the window
+        preroll = ep + start_phase - W                  # one whole untimed episode first (clocks, allocator, pinned buffers warm)
+        share = int(round(n * K / ep))
+        ahead = ep - K // 2 - 1 - start_phase           # clock offset of the envs that finish inside the window
+        assert 0 <= ahead and ahead + start_phase < ep and start_phase + K <= ep
     # synthetic input: A = RandomState(seed).randint(0, 18, (T, N)) uploaded once; each rank its own slice
     tape = torch.as_tensor(np.random.RandomState(rank).randint(0, 18, size=(preroll + W + K, n)).astype(np.int32), device=device)
     obs = env.reset()
+    last_score = torch.zeros(n, dtype=torch.float64, device=device)      # per-env result of the rollout
     for s in range(preroll):
-        env.step(tape[s])
+        if share and s in (0, ep):                      # s == ep: every env has just started its second episode
+            # (s == 0: the same number of envs also finishes early in the untimed first episode, so that the partial-mask path's
+            # first-use costs -- torch's lazily loaded kernels, allocator blocks -- are not inside the timed window)
+            clocks = np.zeros(n, dtype=np.int64)
+            clocks[:share] = ahead if s == ep else ep // 2
+            env.set_episode_steps(clocks)
+        obs, rew, done, info = env.step(tape[s])
     tape = tape[preroll:]
     for s in range(W):
         obs, rew, done, info = env.step(tape[s])
@@ -191,18 +207,19 @@ def main():
         torch.cuda.synchronize()
 
     env.set_timing(8)       # HIP events around every 8th launch of each kernel inside the timed region
-    last_score = torch.zeros(n, dtype=torch.float64, device=device)      # per-env result of the rollout
+    last_score.zero_()
+    score_host = np.zeros(n, dtype=np.float64)          # scores are collected on the host and uploaded once, for the gather
     n_eps = 0
     gather_rollout_results(last_score, n * world)      # warm-up of the collective (RCCL sets its channels up on first use)
-    last_score[torch.arange(n, device=device)] = torch.zeros(n, dtype=torch.float64, device=device)   # ... and of the loop's index_put
+    last_score.copy_(torch.as_tensor(np.zeros(n, dtype=np.float64)))                                   # ... and of the score upload
     barrier()
     t0 = time.perf_counter()
     for s in range(W, W + K):
         obs, rew, done, info = env.step(tape[s])
         if done.any():
             n_eps += int(done.sum())
-            idx = torch.as_tensor(np.nonzero(done)[0], device=device)
-            last_score[idx] = torch.as_tensor(info['eval_score'][done], device=device)
+            score_host[done] = info['eval_score'][done]
+    last_score.copy_(torch.as_tensor(score_host))
     # end-of-rollout gather over xGMI (RCCL): per-env scores of every rank; observations never leave their GPU
     all_scores = gather_rollout_results(last_score, n * world)
     barrier()
@@ -276,6 +293,9 @@ def main():
                        'n_envs_per_gpu': n, 'lanes_per_env': env.lanes_per_env, 'episodes_finished': n_eps * world,
                        'mean_eval_score': float(all_scores.mean().item()),
                        'untimed_preroll_steps': preroll,
+                       'episode_ends_in_window': (f'{share} of {n} envs per GPU finish an episode inside the {K}-step window = its long-run share K / {ep} '
+                                                  '(their episode clocks were set ahead; scoring + auto-reset + stack refill are timed)') if share else
+                                                 f'{K // ep} whole episodes of every env',
                        'arith': 'fp32 velocities/impulses/contacts + fp64 poses; fp64 rasteriser' if args.dtype == 'f32' else args.dtype,
                        'broadphase': 'pre-filtered candidate-pair list, AABB-tested brute force, compacted in pair order through LDS counters '
                                      '(<= 27 shapes per env: measured faster than sort-and-sweep; DESIGN.md 3.1)',

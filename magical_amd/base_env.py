@@ -371,10 +371,12 @@ class BaseEnv(abc.ABC):
         non-zero count is reported: a warning by default, an MgxError with strict_capacity=True."""
         import torch
         import warnings
-        row = self.state_i[2] if source is None else source
-        if idx is not None:
-            row = row[torch.as_tensor(idx, device=row.device)]
-        n = int(row.sum())
+        if source is None:
+            row = self.state_i[2]
+            n = int((row if idx is None else row[torch.as_tensor(idx, device=row.device)]).sum())
+        else:
+            row = source.numpy()
+            n = int((row if idx is None else row[np.asarray(idx)]).sum())
         if n:
             self.capacity_overflows += n
             msg = (f'{n} contact(s) / overlapping pair(s) exceeded the per-env working set in {n_finished} finished episode(s) and were '
@@ -674,10 +676,16 @@ class BaseEnv(abc.ABC):
     def get_poses(self, env_idx=None, source=None):
         """float64[M, n_bodies, 3] poses of the selected envs on the host (synchronises).  source: a snapshot of the pose blob."""
         import torch
-        sp = self.state_p if source is None else source
-        if env_idx is not None:
-            sp = sp[:, torch.as_tensor(env_idx, device=sp.device)]
-        sp = sp.to(torch.float64).cpu().numpy()
+        if source is None:
+            sp = self.state_p if env_idx is None else self.state_p[:, torch.as_tensor(env_idx, device=self.device)]
+            sp = sp.to(torch.float64).cpu().numpy()
+        else:
+            # a host snapshot: gathered with numpy (torch's CPU indexing wakes its whole thread pool, whose workers then spin
+            # for a while -- measured as 50 ms hiccups of the steps after a partial episode end)
+            sp = source.numpy()
+            if env_idx is not None:
+                sp = sp[:, np.asarray(env_idx)]
+            sp = sp.astype(np.float64, copy=False)
         out = np.zeros((sp.shape[1], self.n_bodies, 3), dtype=np.float64)
         for b in range(self.n_bodies):
             for c in range(3):
@@ -703,6 +711,16 @@ class BaseEnv(abc.ABC):
              'task': {a: (None if getattr(self, a) is None else getattr(self, a).copy()) for a in self.TASK_STATE_ATTRS},
              'have': {'colours': self._ent_colour is not None, 'poses': self._ent_pose is not None, 'goals': self._goal_rect is not None}}
         return d
+
+    def set_episode_steps(self, steps):
+        """Set every env's episode step counter (the TimeLimit clock of benchmarks/__init__.py:979-999): host mirror and the
+        device row the step kernel increments.  Envs of one batch can then be at different points of their episodes, as they
+        are when a long-running job resumes from get_state() snapshots taken at different times."""
+        import torch
+        steps = np.asarray(steps, dtype=np.int64).reshape(self.n_envs)
+        assert (steps >= 0).all() and (self.max_episode_steps is None or (steps < self.max_episode_steps).all())
+        self._steps[:] = steps
+        self.state_i[0].copy_(torch.as_tensor(steps.astype(np.int32), device=self.device))
 
     def set_state(self, d):
         """Inverse of get_state() on an env of the same task / variant / size (any seed, any history)."""

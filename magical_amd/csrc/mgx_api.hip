@@ -1131,6 +1131,14 @@ int mgx_engine_env_world_info(const mgx_engine *e, int env, int key, int *out) {
 int mgx_engine_set_timing(mgx_engine *e, int enable) {
     if (!e) return fail(MGX_ERR_ARG, "engine is NULL");
     e->timing = enable < 0 ? 0 : enable;
+    if (e->timing) {      // the event ring is made here, not at the first sampled launch (which is inside the caller's timed region)
+        ON_DEVICE(e);
+        for (int which = 0; which < 2; which++)
+            if (e->ev[which].empty()) {
+                e->ev[which].resize(2 * TIMING_RING);
+                for (auto &ev : e->ev[which]) HIP_OK(hipEventCreate(&ev));
+            }
+    }
     e->ev_count[0] = e->ev_count[1] = 0;
     e->launch_count[0] = e->launch_count[1] = 0;
     return MGX_OK;

@@ -1191,9 +1191,9 @@ def test_planar_frame_ring_partial_episode_ends():
     a = _make(name, n, max_episode_steps=ep, obs_ring=7); b = _make(name, n, max_episode_steps=ep)
     a.seed(1); b.seed(1)
     a.reset(); b.reset()
-    for e in (a, b):
-        e._steps[::3] += 2; e._steps[1::3] += 4
-        e.state_i[0].copy_(torch.as_tensor(e._steps, device=e.device, dtype=e.state_i.dtype))
+    clocks = np.zeros(n, dtype=np.int64)
+    clocks[::3] = 2; clocks[1::3] = 4
+    a.set_episode_steps(clocks); b.set_episode_steps(clocks)
     tape = _tape(23, 20, n)
     for s in range(20):
         oa, _, da, _ = a.step(tape[s]); ob, _, db, _ = b.step(tape[s])

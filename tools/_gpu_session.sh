@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q -x -k "planar" 2>&1 | grep -v "^$" | head -60
+timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -5
+timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3

@@ -43,6 +43,8 @@ print('  queued pixels per env: mean %.0f max %.0f' % (c[:, 5].mean(), c[:, 5].m
 if c[:, 8].max() > 0:   # MGX_RASTER_PROBE build: wave 0 of each block, shader cycles
     print('  wave 0 phase T: total %.0f cyc; gather %.0f cyc, classify %.0f cyc, mixed tiles %.1f, items %.0f' % (
         c[:, 8].mean(), c[:, 6].mean(), c[:, 7].mean(), c[:, 9].mean(), c[:, 10].mean()))
+    print('  phase Q, shader cycles per wavefront (first round): waves 0..3 mean %s, max %s; phase E (wave 0 incl. barrier wait) mean %.0f max %.0f' % (
+        np.round(c[:, 11:15].mean(0)), c[:, 11:15].max(0), c[:, 15].mean(), c[:, 15].max()))
 # copy bandwidth reference
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): stack.copy_(stack + 0)
