@@ -206,7 +206,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    env.set_timing(8)       # HIP events around every 8th launch of each kernel inside the timed region
+    env.set_timing(8 if K >= 160 else 2)       # HIP events around every 8th (short windows: every 2nd) launch of each kernel inside the timed region
     last_score.zero_()
     score_host = np.zeros(n, dtype=np.float64)          # scores are collected on the host and uploaded once, for the gather
     n_eps = 0
