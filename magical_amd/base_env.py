@@ -111,6 +111,7 @@ class BaseEnv(abc.ABC):
         self.batch_draws = bool(batch_draws)   # per-episode draws of all envs of a reset per native call (batch_rng.py) instead of env by env
         self.overlap = bool(overlap)       # step(): physics + observation as a producer / consumer kernel pair (mgx_engine_step_render)
         self._obs_ready = False
+        self._fill_idx = None              # host-side index list of the device mask handed to _observe() (step() only)
         self.capacity_overflows = 0        # contacts / overlapping pairs the fixed-size working set dropped (see step())
         self.dtype_name = dtype
         self._dtype = {'f32': nat.MGX_F32, 'f64': nat.MGX_F64, 'f32_pure': nat.MGX_F32_PURE}[dtype]
@@ -342,6 +343,7 @@ class BaseEnv(abc.ABC):
                 pin['ev'].record(torch.cuda.current_stream(self.device))
                 self._reset_envs(idx, self._done_dev)
                 fill = self._done_dev
+                self._fill_idx = idx
                 obs = self._observe(fill_mask=fill)
                 pin['ev'].synchronize()
             if self.score_needs_poses:
@@ -358,8 +360,10 @@ class BaseEnv(abc.ABC):
                 # the device-side done flags written by the step kernel double as reset + frame-fill masks
                 self._reset_envs(idx, self._done_dev)
                 fill = self._done_dev
+                self._fill_idx = idx
         if obs is None:
             obs = self._observe(fill_mask=fill)
+        self._fill_idx = None
         if self.copy_obs:
             obs = {k: v.clone() for k, v in obs.items()} if isinstance(obs, dict) else obs.clone()
         return obs, self._reward, done, {'eval_score': eval_score}

@@ -62,8 +62,12 @@ def wrap_preproc(env_cls, preproc):
             import torch
             k = self._ring_k
             old, new = self._ring[:, k - 3:k], self._ring[:, k:k + 1]
-            if fill_all:
+            idx = self._fill_idx            # step(): the envs of the mask, known on the host (no ring-sized temporaries then)
+            if fill_all or (idx is not None and len(idx) == self.n_envs):
                 old.copy_(new.expand_as(old))
+            elif idx is not None:
+                it = torch.as_tensor(idx, device=self.device)
+                self._ring[it, k - 3:k] = self._ring[it, k:k + 1]
             elif fill_mask is not None:
                 old.copy_(torch.where(fill_mask.view(-1, 1, 1, 1, 1) != 0, new, old))
 

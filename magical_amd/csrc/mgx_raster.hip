@@ -270,21 +270,21 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
         if (tid == 0) {
             long got = -1;
             if (ho.mode == 1) {
-                // (a short bounded wait: the two kernels are released together and the producers need a microsecond to begin)
-                unsigned begun = 0;
-                for (int n = 0; n < 64; n++) {
-                    begun = __hip_atomic_load(ho.started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ho.started_base;
-                    if (begun >= ho.n_producers) break;
-                    __builtin_amdgcn_s_sleep(32);
-                }
-                if (begun >= ho.n_producers) {
-                    for (unsigned n = 0; n < HANDOFF_POLL_LIMIT; n++) {
-                        const unsigned long long ent = __hip_atomic_load(&ho.queue[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((unsigned)(ent >> 32) == ho.epoch) { got = (long)(ent & 0xFFFFFFFFull); break; }
-                        __builtin_amdgcn_s_sleep(16);
+                // An entry that is already there is taken at once.  Otherwise the wait is long only once every producer is
+                // resident (then entry blockIdx.x is certain to come); while some producer has not begun -- it may be waiting for
+                // the very resources this workgroup holds -- the wait is a short bounded one (the two kernels are released
+                // together and the producers need a microsecond to begin), after which the env is left to the clean-up launch.
+                bool all = false;
+                for (unsigned n = 0; n < HANDOFF_POLL_LIMIT; n++) {
+                    const unsigned long long ent = __hip_atomic_load(&ho.queue[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(ent >> 32) == ho.epoch) { got = (long)(ent & 0xFFFFFFFFull); break; }
+                    if (!all) {
+                        all = __hip_atomic_load(ho.started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ho.started_base >= ho.n_producers;
+                        if (!all && n >= 64) break;
                     }
-                    if (got < 0) atomicAdd(&ho.stats[1], 1u);
+                    if (all) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(32);
                 }
+                if (got < 0 && all) atomicAdd(&ho.stats[1], 1u);
                 if (got < 0) { ho.deferred[blockIdx.x] = ho.epoch; atomicAdd(&ho.stats[0], 1u); }
                 else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
