@@ -307,10 +307,15 @@ class BaseEnv(abc.ABC):
                                                 self.state_i.data_ptr(), actions.data_ptr(), self._done_dev.data_ptr(),
                                                 self._stream()))
         else:
-            out, view, layout = target
+            # (a preprocessor with two rasteriser passes: the first one is the consumer of the step kernel, the second follows)
+            first, rest = (target[0], target[1:]) if isinstance(target, list) else (target, ())
+            out, view, layout = first
             nat.check(self._lib.mgx_engine_step_render(self._engine, self.state_p.data_ptr(), self.state_f.data_ptr(),
                                                        self.state_i.data_ptr(), actions.data_ptr(), self._done_dev.data_ptr(),
                                                        out.data_ptr(), out.stride(0), view, layout, self._stream()))
+            for out, view, layout in rest:
+                nat.check(self._lib.mgx_engine_render(self._engine, self.state_p.data_ptr(), out.data_ptr(), out.stride(0), view, layout,
+                                                      None, self._stream()))
             self._obs_ready = True
         self._steps += 1
         done = np.zeros(self.n_envs, dtype=bool)
@@ -653,8 +658,8 @@ class BaseEnv(abc.ABC):
         return spaces.Box(-np.inf, np.inf, (self.n_bodies, 3), np.float32)
 
     def _fused_target(self):
-        """(tensor, view, layout) of the single rasteriser pass that makes this env's observation, or None (state-only
-        observation, or a preprocessor that renders two views)."""
+        """(tensor, view, layout) of the rasteriser pass that makes this env's observation -- or a list of them, in launch order, for
+        a preprocessor that renders two views -- or None (state-only observation)."""
         return None
 
     def handoff_stats(self):

@@ -94,8 +94,10 @@ def wrap_preproc(env_cls, preproc):
 
         def _fused_target(self):
             from .. import _native as nat
-            if preproc in ('LoRes3EA', 'LoResStack'):
-                return None
+            if preproc == 'LoRes3EA':         # the launches of _observe(), in its order
+                return [(self._stack, nat.VIEW_ALLO, nat.OBS_SLOT_LO), (self._stack, nat.VIEW_EGO, nat.OBS_STACK3_HI)]
+            if preproc == 'LoResStack':
+                return [(self._stack_allo, nat.VIEW_ALLO, nat.OBS_STACK4), (self._stack, nat.VIEW_EGO, nat.OBS_STACK4)]
             if self._ring is not None:
                 return self._ring_next_slot(), nat.VIEW_EGO, nat.OBS_PLANAR
             return self._stack, (nat.VIEW_ALLO if preproc == 'LoRes4A' else nat.VIEW_EGO), nat.OBS_STACK4
@@ -105,6 +107,8 @@ def wrap_preproc(env_cls, preproc):
                 self._obs_ready = False
                 if self._ring is not None:
                     return self._ring_window()
+                if preproc == 'LoResStack':
+                    return {'allo': self._stack_allo, 'ego': self._stack}
                 return self._stack.permute(0, 3, 1, 2) if preproc == 'LoResCHW4E' else self._stack
             if self._ring is not None:
                 self.render_frames(self._ring_next_slot(), view='ego', layout='planar')

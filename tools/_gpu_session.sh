@@ -1,5 +1,15 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests -m gpu -q -x -k "planar" 2>&1 | tail -2
-for i in 1 2 3 4 5; do timeout 300 python bench.py --no-cpu-baseline --task MoveToCorner-Demo-LoResCHW4E-v0 --obs-ring 35 2>/dev/null > gpurun_out/ring_$i.json; python -c "
-import json,sys; d=json.loads(open('gpurun_out/ring_$i.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['config']['episodes_finished'], d['roofline']['avg_launch_ms'])"; done
+timeout 900 python -m pytest tests -m gpu -q -x -k "fused or other_preproc or autoreset or rollouts" 2>&1 | tail -3
+python - <<'PY'
+import time, numpy as np, torch, magical_amd
+for name in ['MoveToCorner-Demo-LoRes3EA-v0', 'MoveToCorner-Demo-LoResStack-v0', 'ClusterColour-Demo-LoRes3EA-v0']:
+    for ov in (False, True):
+        e = magical_amd.make(name, n_envs=4096, device='cuda:0', overlap=ov, max_episode_steps=100000); e.reset()
+        tape = torch.as_tensor(np.random.RandomState(2).randint(0, 18, size=(240, 4096)).astype(np.int32), device='cuda:0')
+        for s in range(40): e.step(tape[s])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for s in range(40, 240): e.step(tape[s])
+        torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 200
+        print('%-34s overlap=%s  %.3f ms/step  %.2f M' % (name, ov, t * 1e3, 4096 / t / 1e6)); e.close()
+PY
