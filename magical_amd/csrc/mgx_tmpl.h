@@ -153,6 +153,10 @@ struct WorkOff {
 #ifndef MGX_AOS
 #define MGX_AOS 507     // bit 0 body poses, 1 body velocities, 2 joints, 3 contacts (joint records measured slower), 4.. below
 #endif
+#ifndef MGX_ALIAS
+#define MGX_ALIAS 1
+#endif
+    static constexpr bool ALIAS = MGX_ALIAS != 0;
     static constexpr bool AOS_BP = MGX_AOS & 1, AOS_BR = MGX_AOS & 2, AOS_J = MGX_AOS & 4, AOS_K = MGX_AOS & 8;
     // 4 world vertices (x y nx ny: -1.4 %), 5 shape boxes, 6 overlap records (pair count hash offset), 7 contact ints, 8 cache ints
     // (5..8: nothing measurable one by one, -1.5 % together)
@@ -179,23 +183,34 @@ struct WorkOff {
         o = 0;
         vx = o; vy = o + sbr; w = o + 2 * sbr; vbx = o + 3 * sbr; vby = o + 4 * sbr; wb = o + 5 * sbr; o += 6 * nb;
         const int sv = AOS_V ? 1 : nv, sbb = AOS_BB ? 1 : ns;
+        // The world-space vertices and boxes live from ph_shapes to ph_narrow, the contact records from ph_arbiters_joints to
+        // ph_cache_commit of the same substep: the two share their words (MGX_ALIAS; 2 KB per env in ClusterColour).
+        const int shared = o;
         wx = o; wy = o + sv; wnx = o + 2 * sv; wny = o + 3 * sv; o += 4 * nv;
         bbl = o; bbb = o + sbb; bbr = o + 2 * sbb; bbt = o + 3 * sbb; o += 4 * ns;
-        jr1x = o; jr1y = o + sj; jr2x = o + 2 * sj; jr2y = o + 3 * sj; jk0 = o + 4 * sj; jk1 = o + 5 * sj; jk2 = o + 6 * sj; jk3 = o + 7 * sj;
-        jb0 = o + 8 * sj; jb1 = o + 9 * sj; ja0 = o + 10 * sj; ja1 = o + 11 * sj; jrate = o + 12 * sj; jlim = o + 13 * sj; o += 15 * nj;
+        const int geom_end = o;
+        if (ALIAS) o = shared;
         knx = o; kny = o + sk; kr1x = o + 2 * sk; kr1y = o + 3 * sk; kr2x = o + 4 * sk; kr2y = o + 5 * sk; knm = o + 6 * sk; ktm = o + 7 * sk;
         kbias = o + 8 * sk; kjb = o + 9 * sk; kjn = o + 10 * sk; kjt = o + 11 * sk; kmu = o + 12 * sk; o += 13 * nk;
+        if (o < geom_end) o = geom_end;
+        jr1x = o; jr1y = o + sj; jr2x = o + 2 * sj; jr2y = o + 3 * sj; jk0 = o + 4 * sj; jk1 = o + 5 * sj; jk2 = o + 6 * sj; jk3 = o + 7 * sj;
+        jb0 = o + 8 * sj; jb1 = o + 9 * sj; ja0 = o + 10 * sj; ja1 = o + 11 * sj; jrate = o + 12 * sj; jlim = o + 13 * sj; o += 15 * nj;
         mn = o; o += nov * 2; mp = o; o += nov * 8;
         cj = o; o += nc * 4; ncj = o; o += nc * 4;
         n_r = o;
         o = 0;
         const int sov = AOS_OV ? 1 : nov, ski = AOS_KI ? 1 : nk, sc = AOS_C ? 1 : nc;
         ov = o; mcnt = o + sov; mhash = o + 2 * sov; koff = o + 3 * sov; o += 4 * nov;
-        kab = o; kfirst = o + ski; o += 2 * nk;
         chead = o; nchead = o + sc; cmatched = o + 2 * sc; o += 3 * nc;
         misc = o; o += M_N;
+        // likewise the broadphase's pair flags and compaction counters (ph_broad_*) and the contacts' body / first-touch ints
+        const int shared_i = o;
         flag = o; o += (h.n_pairs + 3) / 4;   // one byte per candidate pair
         cnt = o; o += 64;                      // per-lane counters for ordered compaction
+        const int broad_end = o;
+        if (ALIAS) o = shared_i;
+        kab = o; kfirst = o + ski; o += 2 * nk;
+        if (o < broad_end) o = broad_end;
         n_i = o;
     }
 };
