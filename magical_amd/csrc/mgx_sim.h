@@ -404,8 +404,7 @@ template <typename R, typename P> MGX_HD void ph_narrow(Env<R, P> &e, int lane, 
         int pr = T_I(pair, E_I(ov, q));
         ManifoldOut<R> m;
         collide_pair(e, pr & 0xFF, pr >> 8, m);
-        E_I(mcnt, q) = m.count;
-        E_I(mhash, q) = m.h0 | (m.h1 << 8);
+        E_I(mcnt, q) = m.count | ((m.h0 | (m.h1 << 8)) << 8);        // point count (0..2) | the two point hashes
         E_R(mn, 2 * q) = m.nx; E_R(mn, 2 * q + 1) = m.ny;
         for (int i = 0; i < 4 * m.count; i++) E_R(mp, 8 * q + i) = m.p[i];
     }
@@ -419,8 +418,8 @@ template <typename R, typename P> MGX_HD void ph_arbiters_joints(Env<R, P> &e, i
     R dt = e.cst(C_DT), slop = e.cst(C_SLOP), brate = e.cst(C_CONTACT_BIAS_RATE);
     int koff = 0, rank = 0, scanned = 0;
     for (int q = lane; q < nov; q += nl) {
-        for (; scanned < q; scanned++) { int c = E_I(mcnt, scanned); if (c > 0 && koff + c <= kcap && rank < ccap) { koff += c; rank++; } }
-        int cnt = E_I(mcnt, q);
+        for (; scanned < q; scanned++) { int c = E_I(mcnt, scanned) & 3; if (c > 0 && koff + c <= kcap && rank < ccap) { koff += c; rank++; } }
+        const int mc = E_I(mcnt, q), cnt = mc & 3;
         scanned = q + 1;                                      // this entry is accounted for right below
         if (cnt == 0) continue;
         if (koff + cnt > kcap || rank >= ccap) continue;     // dropped: counted by lane 0 below
@@ -433,7 +432,7 @@ template <typename R, typename P> MGX_HD void ph_arbiters_joints(Env<R, P> &e, i
         if (ci >= 0) { first = ((old >> 12) & 3u) != 0u; E_I(cmatched, ci) = 1; }
         int ocnt = ci >= 0 ? (int)((old >> 14) & 3u) : 0;
         int oh[2] = {(int)((old >> 16) & 0xFFu), (int)((old >> 24) & 0xFFu)};
-        int mh = E_I(mhash, q);
+        int mh = mc >> 8;
         int nh[2] = {mh & 0xFF, (mh >> 8) & 0xFF};
         R nx = E_R(mn, 2 * q), ny = E_R(mn, 2 * q + 1);
         R mu = T_R(shape_u, sa) * T_R(shape_u, sb);
@@ -463,7 +462,7 @@ template <typename R, typename P> MGX_HD void ph_arbiters_joints(Env<R, P> &e, i
     }
     if (lane == 0) {   // totals (lane 0 rescans everything once; also counts drops)
         int k = 0, r = 0, dropped = 0;
-        for (int q = 0; q < nov; q++) { int c = E_I(mcnt, q); if (c > 0) { if (k + c <= kcap && r < ccap) { k += c; r++; } else dropped++; } }
+        for (int q = 0; q < nov; q++) { int c = E_I(mcnt, q) & 3; if (c > 0) { if (k + c <= kcap && r < ccap) { k += c; r++; } else dropped++; } }
         E_I(misc, M_NK) = k; E_I(misc, M_NARB) = r;
         if (dropped) E_I(misc, M_OVERFLOW) += dropped;
     }

@@ -141,13 +141,13 @@ struct WorkOff {
     int jr1x, jr1y, jr2x, jr2y, jk0, jk1, jk2, jk3, jb0, jb1, ja0, ja1, jrate, jlim;
     // contact points
     int knx, kny, kr1x, kr1y, kr2x, kr2y, knm, ktm, kbias, kjb, kjn, kjt, kmu;
-    // manifold scratch per overlapping pair: n(2) + 2 x (p1, p2)(4)
+    // manifold scratch per overlapping pair: n(2) + 2 x (p1, p2)(4)  [mn and mp are adjacent: ncj may lie over both]
     int mn, mp;
     // persistent contact cache impulses (jn, jt per point) and the one being built
     int cj, ncj;
     int n_r;
     // int region
-    int ov, mcnt, mhash, koff, kab, kfirst, chead, nchead, cmatched, misc, flag, cnt;
+    int ov, mcnt, koff, kab, kfirst, chead, nchead, cmatched, misc, flag, cnt;
     int n_i;
     // element strides of the fields (1 = plain array)
 #ifndef MGX_AOS
@@ -164,14 +164,14 @@ struct WorkOff {
     static constexpr int BODY_P = AOS_BP ? 5 : 1, BODY_R = AOS_BR ? 6 : 1, JOINT_R = AOS_J ? 15 : 1, CONTACT_R = AOS_K ? 13 : 1;
     static constexpr int S_px = BODY_P, S_py = BODY_P, S_ang = BODY_P, S_c = BODY_P, S_s = BODY_P;
     static constexpr int S_vx = BODY_R, S_vy = BODY_R, S_w = BODY_R, S_vbx = BODY_R, S_vby = BODY_R, S_wb = BODY_R;
-    static constexpr int VERT_R = AOS_V ? 4 : 1, BOX_R = AOS_BB ? 4 : 1, OV_I = AOS_OV ? 4 : 1, KI_I = AOS_KI ? 2 : 1, C_I = AOS_C ? 3 : 1;
+    static constexpr int VERT_R = AOS_V ? 4 : 1, BOX_R = AOS_BB ? 4 : 1, OV_I = AOS_OV ? 2 : 1, KI_I = AOS_KI ? 2 : 1, C_I = AOS_C ? 3 : 1;
     static constexpr int S_wx = VERT_R, S_wy = VERT_R, S_wnx = VERT_R, S_wny = VERT_R, S_bbl = BOX_R, S_bbb = BOX_R, S_bbr = BOX_R, S_bbt = BOX_R;
     static constexpr int S_jr1x = JOINT_R, S_jr1y = JOINT_R, S_jr2x = JOINT_R, S_jr2y = JOINT_R, S_jk0 = JOINT_R, S_jk1 = JOINT_R, S_jk2 = JOINT_R,
                          S_jk3 = JOINT_R, S_jb0 = JOINT_R, S_jb1 = JOINT_R, S_ja0 = JOINT_R, S_ja1 = JOINT_R, S_jrate = JOINT_R, S_jlim = JOINT_R;
     static constexpr int S_knx = CONTACT_R, S_kny = CONTACT_R, S_kr1x = CONTACT_R, S_kr1y = CONTACT_R, S_kr2x = CONTACT_R, S_kr2y = CONTACT_R,
                          S_knm = CONTACT_R, S_ktm = CONTACT_R, S_kbias = CONTACT_R, S_kjb = CONTACT_R, S_kjn = CONTACT_R, S_kjt = CONTACT_R, S_kmu = CONTACT_R;
     static constexpr int S_mn = 1, S_mp = 1, S_cj = 1, S_ncj = 1;
-    static constexpr int S_ov = OV_I, S_mcnt = OV_I, S_mhash = OV_I, S_koff = OV_I, S_kab = KI_I, S_kfirst = KI_I, S_chead = C_I, S_nchead = C_I,
+    static constexpr int S_ov = OV_I, S_mcnt = OV_I, S_koff = 1, S_kab = KI_I, S_kfirst = KI_I, S_chead = C_I, S_nchead = C_I,
                          S_cmatched = C_I, S_misc = 1, S_flag = 1, S_cnt = 1;
     MGX_HD explicit WorkOff(const TmplHeader &h) {
         int nb = h.n_bodies, nv = h.n_verts, ns = h.n_shapes, nj = h.n_joints;
@@ -196,11 +196,15 @@ struct WorkOff {
         jr1x = o; jr1y = o + sj; jr2x = o + 2 * sj; jr2y = o + 3 * sj; jk0 = o + 4 * sj; jk1 = o + 5 * sj; jk2 = o + 6 * sj; jk3 = o + 7 * sj;
         jb0 = o + 8 * sj; jb1 = o + 9 * sj; ja0 = o + 10 * sj; ja1 = o + 11 * sj; jrate = o + 12 * sj; jlim = o + 13 * sj; o += 15 * nj;
         mn = o; o += nov * 2; mp = o; o += nov * 8;
-        cj = o; o += nc * 4; ncj = o; o += nc * 4;
+        cj = o; o += nc * 4;
+        // the cache being built is written from solve_begin on, when the manifolds (ph_narrow .. ph_arbiters_joints) are dead
+        if (ALIAS && 4 * nc <= 10 * nov) ncj = mn; else { ncj = o; o += nc * 4; }
         n_r = o;
         o = 0;
         const int sov = AOS_OV ? 1 : nov, ski = AOS_KI ? 1 : nk, sc = AOS_C ? 1 : nc;
-        ov = o; mcnt = o + sov; mhash = o + 2 * sov; koff = o + 3 * sov; o += 4 * nov;
+        // overlapping pairs: (candidate pair, manifold point count | point hashes << 8) per pair; first contact of each arbiter, by rank
+        ov = o; mcnt = o + sov; o += 2 * nov;
+        koff = o; o += nc;
         chead = o; nchead = o + sc; cmatched = o + 2 * sc; o += 3 * nc;
         misc = o; o += M_N;
         // likewise the broadphase's pair flags and compaction counters (ph_broad_*) and the contacts' body / first-touch ints
