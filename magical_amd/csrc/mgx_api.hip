@@ -459,6 +459,11 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
         // but FixColour (72 KB of LDS at eight envs per workgroup) 0.96 -> 1.19 ms and larger worlds lose more
         // (only where every block island still has a lane of its own, i.e. the same register-resident joint code runs)
         if (L == 16 && e->n_envs >= 6144 && step_lds_bytes(e, 8) <= (size_t)60 * 1024 && e->h.n_islands <= 7) L = 8;
+        // the crowded worlds (ClusterColour / ClusterShape: 305 candidate pairs, 27 shapes) whose 16-lane working sets cannot all be
+        // resident anyway (54 KB: three workgroups per CU) take 32 lanes per env: the broadphase and narrowphase, a third of their
+        // step, run twice as wide.  Measured at 4096 envs: ClusterColour k_step 0.88 -> 0.77 ms, env-step 1.80 -> 1.66 ms; the
+        // smaller worlds lose (FindDupe 1.48 -> 1.68 ms, MatchRegions 1.05 -> 1.31, MakeLine 1.16 -> 1.41, FixColour 1.12 -> 1.41)
+        if (L == 16 && e->h.n_pairs > 256 && step_lds_bytes(e, 16) > (size_t)40 * 1024) L = 32;
     } else if (L == 0) {
         L = 64;      // per-env templates: one env per wavefront, so that its template copy in LDS is shared by all lanes
     }
