@@ -220,7 +220,9 @@ int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t 
  * state it has written back, and the raster kernel -- on a stream of the engine's own, joined to `stream` before and after --
  * rasterises envs in the order they finish, so the long tail of the physics (a few envs with many contacts) runs under the
  * rasterisation of the others.  Not for steps in which envs are reset between physics and rendering (episode ends:
- * use the two calls).  Falls back to the two calls in sequence where the producers would not all be resident at once. */
+ * use the two calls).  Every world takes this path (a consumer waits at length only once all producers are resident, otherwise
+ * it takes an entry that is there or leaves its env to a clean-up launch); MGX_NO_OVERLAP=1 in the environment makes it the
+ * two calls in sequence. */
 int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const int32_t *actions, uint8_t *done,
                            uint8_t *out, int64_t env_stride, int view, int layout, void *stream);
 /* diagnostics of the hand-off (synchronises): consumer workgroups that gave up and were served by the clean-up launch */
