@@ -453,42 +453,70 @@ MGX_HD void tile_centre(int tile, float &xc, float &yc) {
 // fp32 first: a sample is decided in fp32 when |E| > CLASS_EPS_F, otherwise that one sample is re-evaluated in fp64
 // against the fp64 edge function -- the result equals the all-fp64 test.
 MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, int X, int Y, uint32_t &unc) {
+#ifdef MGX_Q_NO_POLY      // development probe: what phase Q costs without the polygon coverage arithmetic (wrong pixels)
+    return 0x0F0Fu;
+#endif
     const int nv = rs.prim_nv(k), i0 = RI(pitem, k) & 0xFFFF;
-    const uint32_t ends = rs.prim_ends(k);                                  // bit e: edge e closes a convex part
+    const uint32_t ends = rs.prim_ends(k) | (1u << (nv - 1));               // bit e: edge e closes a convex part
     const float x0 = 4.0f * X + 0.5f, y0 = (float)NATIVE_RES - 0.5f - 4.0f * Y;
     const Item *items = reinterpret_cast<const Item *>(&RI(items, 0)) + i0;
-    // `part` = samples inside every edge of the convex part being walked; the polygon is the union of its parts (a sample
-    // that is ambiguous for one part stays flagged even when another part holds it: the exact painter then decides it)
-    uint32_t cov = 0, part = 0xFFFFu;
+    // Two passes, so that the lanes of a wavefront (each on its own pixel, often on different polygons) diverge as little as
+    // possible.  Pass 1, the same few operations per edge for every lane: is the block wholly outside the edge (`dead`), does
+    // the edge cross it (`cross`), or is the block wholly inside?  Pass 2 evaluates the 16 samples only for the crossing edges
+    // of parts that are still alive -- one to three per pixel, whatever the polygon (a star has 36 edges in 12 parts).
+    uint32_t cross = 0, dead = 0;
     for (int e = 0; e < nv; e++) {
-        if (part) {
-            const float a = items[e].a, b = items[e].b;
-            float row = a * x0 + b * y0 + items[e].c;
-            // block spans x0..x0+3, y0-3..y0: worst / best corner value of this edge function
-            const float lo = row + r_min(0.0f, 3.0f * a) - r_max(0.0f, 3.0f * b);
-            const float hi = row + r_max(0.0f, 3.0f * a) - r_min(0.0f, 3.0f * b);
-            if (hi < -CLASS_EPS_F) part = 0;                               // whole block outside this edge
-            else if (lo < CLASS_EPS_F) {                                   // (else: whole block inside it)
-                uint32_t in = 0, amb = 0;
-                for (int j = 0; j < 4; j++) {
-                    float v = row;
-                    for (int i = 0; i < 4; i++) {
-                        in |= (v >= CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
-                        amb |= (r_abs(v) < CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
-                        v += a;
-                    }
-                    row -= b;
-                }
-                unc |= amb & part;                                         // samples too close to call in fp32
-                part &= in;
+        const float a = items[e].a, b = items[e].b;
+        const float row = a * x0 + b * y0 + items[e].c;
+        // block spans x0..x0+3, y0-3..y0: worst / best corner value of this edge function
+        const float lo = row + r_min(0.0f, 3.0f * a) - r_max(0.0f, 3.0f * b);
+        const float hi = row + r_max(0.0f, 3.0f * a) - r_min(0.0f, 3.0f * b);
+        if (hi < -CLASS_EPS_F) dead |= 1u << e;                             // whole block outside this edge
+        else if (lo < CLASS_EPS_F) cross |= 1u << e;                        // (else: whole block inside it)
+    }
+    // the polygon is the union of its parts: a part with a dead edge holds no sample; one with neither a dead nor a crossing
+    // edge holds them all
+    uint32_t todo = 0;
+    {
+        int e0 = 0;
+        for (uint32_t er = ends; er; er &= er - 1) {
+            const int pe = __builtin_ctz(er);
+            const uint32_t rm = (2u << pe) - (1u << e0);                    // edges e0 .. pe
+            if (!(dead & rm)) {
+                if (!(cross & rm)) return 0xFFFFu;
+                todo |= cross & rm;
             }
-        }
-        if ((ends >> e) & 1u) {
-            cov |= part;
-            if (e == nv - 1 || cov == 0xFFFFu) break;
-            part = 0xFFFFu;
+            e0 = pe + 1;
         }
     }
+    // `part` = samples inside every crossing edge of the part being walked (a sample that is ambiguous for one part stays
+    // flagged even when another part holds it: the exact painter then decides it)
+    uint32_t cov = 0, part = 0xFFFFu;
+    int cur_end = -1;
+    while (todo) {
+        const int e = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const int pe = e + __builtin_ctz(ends >> e);                        // the edge that closes e's part
+        if (pe != cur_end) {
+            if (cur_end >= 0) { cov |= part; if (cov == 0xFFFFu) return cov; }
+            part = 0xFFFFu; cur_end = pe;
+        }
+        const float a = items[e].a, b = items[e].b;
+        float row = a * x0 + b * y0 + items[e].c;
+        uint32_t in = 0, amb = 0;
+        for (int j = 0; j < 4; j++) {
+            float v = row;
+            for (int i = 0; i < 4; i++) {
+                in |= (v >= CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
+                amb |= (r_abs(v) < CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
+                v += a;
+            }
+            row -= b;
+        }
+        unc |= amb & part;                                                 // samples too close to call in fp32
+        part &= in;
+    }
+    if (cur_end >= 0) cov |= part;
     return cov;
 }
 // regular n-gon (circles): inside the in-circle / outside the circum-circle is decided by the radius; in the thin annulus
@@ -607,6 +635,9 @@ MGX_HD uint64_t pixel_resolve_fast(const Raster &rs, int X, int Y, uint64_t mixe
         uint32_t cov;
         if (kind == PR_LINELOOP) {
             uint32_t segmask;
+#ifdef MGX_Q_NO_LINE      // development probe: ... without the line loops
+            continue;
+#endif
             cov = lineloop_touch16(rs, k, X, Y, segmask) & remaining;
             MGX_RSTAT(2, 1);
             if (cov) {
