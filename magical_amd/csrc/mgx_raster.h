@@ -452,7 +452,9 @@ MGX_HD void tile_centre(int tile, float &xc, float &yc) {
 // 16-bit coverage of the 4x4 sample block whose top-left sample is (x0, y0); bit 4*j + i = sample (x0 + i, y0 - j).
 // fp32 first: a sample is decided in fp32 when |E| > CLASS_EPS_F, otherwise that one sample is re-evaluated in fp64
 // against the fp64 edge function -- the result equals the all-fp64 test.
-MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, int X, int Y, uint32_t &unc) {
+// TWO_PASS: the two-pass form below (false: the edge-by-edge form -- for the rasteriser's 96-register variant, which runs the
+// small worlds: there the extra code costs more in spills than it saves; measured, MoveToCorner's fused env-step 0.68 -> 0.70 ms)
+template <bool TWO_PASS = true> MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, int X, int Y, uint32_t &unc) {
 #ifdef MGX_Q_NO_POLY      // development probe: what phase Q costs without the polygon coverage arithmetic (wrong pixels)
     return 0x0F0Fu;
 #endif
@@ -460,6 +462,42 @@ MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, int X, int Y, uint32_t 
     const uint32_t ends = rs.prim_ends(k) | (1u << (nv - 1));               // bit e: edge e closes a convex part
     const float x0 = 4.0f * X + 0.5f, y0 = (float)NATIVE_RES - 0.5f - 4.0f * Y;
     const Item *items = reinterpret_cast<const Item *>(&RI(items, 0)) + i0;
+    if (!TWO_PASS) {
+        // the edges in turn, samples only where an edge crosses the block.  `part` = samples inside every edge of the convex part
+        // being walked; the polygon is the union of its parts (a sample that is ambiguous for one part stays flagged even when
+        // another part holds it: the exact painter then decides it)
+        uint32_t cov = 0, part = 0xFFFFu;
+        for (int e = 0; e < nv; e++) {
+            if (part) {
+                const float a = items[e].a, b = items[e].b;
+                float row = a * x0 + b * y0 + items[e].c;
+                // block spans x0..x0+3, y0-3..y0: worst / best corner value of this edge function
+                const float lo = row + r_min(0.0f, 3.0f * a) - r_max(0.0f, 3.0f * b);
+                const float hi = row + r_max(0.0f, 3.0f * a) - r_min(0.0f, 3.0f * b);
+                if (hi < -CLASS_EPS_F) part = 0;                               // whole block outside this edge
+                else if (lo < CLASS_EPS_F) {                                   // (else: whole block inside it)
+                    uint32_t in = 0, amb = 0;
+                    for (int j = 0; j < 4; j++) {
+                        float v = row;
+                        for (int i = 0; i < 4; i++) {
+                            in |= (v >= CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
+                            amb |= (r_abs(v) < CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
+                            v += a;
+                        }
+                        row -= b;
+                    }
+                    unc |= amb & part;                                         // samples too close to call in fp32
+                    part &= in;
+                }
+            }
+            if ((ends >> e) & 1u) {
+                cov |= part;
+                if (e == nv - 1 || cov == 0xFFFFu) break;
+                part = 0xFFFFu;
+            }
+        }
+        return cov;
+    }
     // Two passes, so that the lanes of a wavefront (each on its own pixel, often on different polygons) diverge as little as
     // possible.  Pass 1, the same few operations per edge for every lane: is the block wholly outside the edge (`dead`), does
     // the edge cross it (`cross`), or is the block wholly inside?  Pass 2 evaluates the 16 samples only for the crossing edges
@@ -623,7 +661,7 @@ MGX_HD void lineloop_alpha16(const Raster &rs, int k, int X, int Y, uint32_t seg
 // guaranteed to agree with the fp64 painter (within the fp32 margin of an edge, a blended channel within TAU of a
 // rounding boundary, an undecidable stipple bit, two line loops on top of each other) that sample is left out of the
 // sums and reported in `uncertain`, to be added with pixel_add_exact.  sums = r | g << 12 | b << 24 (each <= 4080).
-MGX_HD uint64_t pixel_resolve_fast(const Raster &rs, int X, int Y, uint64_t mixed, int base, uint32_t &uncertain) {
+template <bool TWO_PASS = true> MGX_HD uint64_t pixel_resolve_fast(const Raster &rs, int X, int Y, uint64_t mixed, int base, uint32_t &uncertain) {
     uint32_t remaining = 0xFFFFu, unc = 0;
     int sr = 0, sg = 0, sb = 0;
     uint64_t m = mixed;
@@ -652,7 +690,7 @@ MGX_HD uint64_t pixel_resolve_fast(const Raster &rs, int X, int Y, uint64_t mixe
                     lm &= ~(1ull << kk);
                     const int kd = rs.prim_kind(kk);
                     if (kd == PR_LINELOOP || nlow == MAXL) { lunc = 0xFFFFu; break; }
-                    lcov[nlow] = kd == PR_POLY ? poly_coverage16(rs, kk, X, Y, lunc) : ngon_coverage16(rs, kk, X, Y, lunc);
+                    lcov[nlow] = kd == PR_POLY ? poly_coverage16<TWO_PASS>(rs, kk, X, Y, lunc) : ngon_coverage16(rs, kk, X, Y, lunc);
                     lcol[nlow] = rs.prim_rgb(kk);
                     nlow++;
                 }
@@ -683,7 +721,7 @@ MGX_HD uint64_t pixel_resolve_fast(const Raster &rs, int X, int Y, uint64_t mixe
             }
         } else {
             uint32_t punc = 0;
-            cov = (kind == PR_POLY ? poly_coverage16(rs, k, X, Y, punc) : ngon_coverage16(rs, k, X, Y, punc)) & remaining;
+            cov = (kind == PR_POLY ? poly_coverage16<TWO_PASS>(rs, k, X, Y, punc) : ngon_coverage16(rs, k, X, Y, punc)) & remaining;
             MGX_RSTAT(9, 1);
             punc &= remaining;
             unc |= punc;

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-timeout 900 python tools/raster_consistency_sweep.py 2>&1 | grep -v amdgpu | tail -6
+timeout 900 python tools/raster_consistency_sweep.py 2>&1 | grep -v amdgpu | grep -c "0 mismatches"
+timeout 300 python tools/task_step_times.py 2>&1 | grep -v amdgpu
