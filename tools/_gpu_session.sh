@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-timeout 900 python tools/raster_consistency_sweep.py 2>&1 | grep -v amdgpu | grep -c "0 mismatches"
-timeout 300 python tools/task_step_times.py 2>&1 | grep -v amdgpu
+echo "== default"; timeout 300 python tools/task_step_times.py 2>&1 | grep -v amdgpu
+for q in 768 576; do echo "== QCAP=$q"; MGX_LIB_PATH=$PWD/build/libmgx_q$q.so timeout 300 python tools/task_step_times.py 2>&1 | grep -v amdgpu; done
