@@ -28,6 +28,10 @@ struct TmplDev {
     int env_stride_words;      // per-env LDS stride of the working set in 32-bit words (multiple of 2)
     int lds_tmpl_words;        // LDS words reserved per template copy (multiple of 2)
     unsigned long long *dbg_clk;   // development probe (MGX_STEP_PROBE builds): per-workgroup phase cycles [blocks][32]
+    // longest-first dispatch (worlds whose step workgroups take several dispatch rounds): workgroup blockIdx.x steps the envs of
+    // group order[blockIdx.x]; every group leaves its duration (shader clock >> 6) in dur[group] for k_step_order.  NULL = off
+    const uint32_t *order;
+    uint32_t *dur;
 };
 // Producer side of the step -> raster hand-off (mgx_engine_step_render): a workgroup that has written its envs' state back
 // publishes them, one 64-bit entry per env ((epoch << 32) | env), into a queue that raster workgroups of a concurrently
@@ -84,7 +88,9 @@ __global__ __launch_bounds__(64, (L == 64 ? MGX_L64_WAVES : MGX_LN_WAVES)) void 
     // consecutive workgroups land on different XCDs (round robin over the 8 L2s); give each XCD a contiguous env
     // range so that the [row][env] lines shared by neighbouring workgroups are fetched into one L2 only
     int wg = blockIdx.x;
-    if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
+    const unsigned long long t_begin = t.dur ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (t.order) wg = (int)t.order[wg];
+    else if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
     long env = (long)wg * EPB + env_local;
     const bool valid = env < n_envs;
     if (!valid) env = n_envs - 1;   // tail lanes shadow the last env (no stores) so barriers stay uniform
@@ -158,10 +164,35 @@ __global__ __launch_bounds__(64, (L == 64 ? MGX_L64_WAVES : MGX_LN_WAVES)) void 
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (t.dur && tid == 0) t.dur[wg] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 6);
 #ifdef MGX_STEP_PROBE
     if (t.dbg_clk && tid == 0) for (int i = 0; i < 20; i++) t.dbg_clk[(long)blockIdx.x * 32 + i] = pacc[i];
 #endif
 #undef SYNC
+}
+
+// Longest-first dispatch order of the step workgroups for the NEXT launch, from the durations the last one left: a counting
+// sort on 256 duration classes (one workgroup; the order inside a class is whatever the atomics give -- it only affects when a
+// group runs, never what it computes).  A workgroup's slowest envs are slow again a step later (the same blocks still touch), and
+// with several dispatch rounds the launch ends when the last-started long workgroup does: longest first, the tail of the launch is
+// made of short ones.
+__global__ __launch_bounds__(1024) void k_step_order(const uint32_t *__restrict__ dur, uint32_t *__restrict__ order, int n) {
+    __shared__ uint32_t s_max, hist[256];
+    const int tid = threadIdx.x;
+    if (tid == 0) s_max = 1;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    for (int i = tid; i < n; i += 1024) m = dur[i] > m ? dur[i] : m;
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const uint32_t top = s_max;
+    auto cls = [&](uint32_t d) { return 255u - (uint32_t)(((unsigned long long)d * 255ull) / top); };     // 0 = longest
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[cls(dur[i])], 1u);
+    __syncthreads();
+    if (tid == 0) { uint32_t acc = 0; for (int b = 0; b < 256; b++) { const uint32_t c = hist[b]; hist[b] = acc; acc += c; } }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&hist[cls(dur[i])], 1u)] = (uint32_t)i;
 }
 
 // BaseEnv.reset(): one thread per env writes the template state into the masked envs
