@@ -1205,6 +1205,35 @@ def test_planar_frame_ring_partial_episode_ends():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name,n', [('ClusterColour-Demo-LoRes4E-v0', 4096), ('FindDupe-TestAll-LoRes4E-v0', 2500)])
+def test_longest_first_dispatch_changes_nothing(name, n):
+    """Worlds whose step workgroups need several dispatch rounds are dispatched longest first, by the durations of the previous
+    launch (k_step_order).  The order decides when a group of envs runs, never what it computes: states, observations and
+    scores equal those of the index-order dispatch (MGX_NO_LPT=1, read at every launch) bit for bit."""
+    import os, torch
+    ep = 6
+    tape = _tape(31, 2 * ep + 2, n)
+    outs = []
+    for off in (False, True):
+        if off:
+            os.environ['MGX_NO_LPT'] = '1'
+        try:
+            e = _make(name, n, max_episode_steps=ep)
+            e.seed(9); e.reset()
+            scores = []
+            for s in range(2 * ep + 2):
+                o, _, d, info = e.step(tape[s])
+                scores.append(info['eval_score'].copy())
+            outs.append((o.clone(), e.state_p.clone(), e.state_f.clone(), e.state_i.clone(), np.stack(scores)))
+            e.close()
+        finally:
+            os.environ.pop('MGX_NO_LPT', None)
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a, b)
+    assert np.array_equal(outs[0][4], outs[1][4])
+
+
+@pytest.mark.gpu
 def test_task_fleet_equals_engines_run_one_by_one():
     """BASELINE.json configs[4] shape on one GPU: the 8 Demo tasks as 8 engines on 8 HIP streams (distributed.TaskFleet) give
     the scores and final observations of the same engines stepped one after the other."""
