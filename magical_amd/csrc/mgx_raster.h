@@ -24,8 +24,10 @@ constexpr float CLASS_EPS_F = 2e-3f;   // fp32 classification margin (px): cover
 // per-env raster scratch (LDS on device)
 struct RasterOff {
     int bx, by, ba, bc, bs;             // per body pose (doubles)
-    int svx, svy, ea, eb, ec;           // per prim vertex: screen position + normalised edge function of edge (i -> i+1)
-    int elen, earc;                     // line loops: segment length and arclength at the segment start
+    int svx, svy, einv, ea, eb, ec;     // per prim vertex: screen position, sign / length of edge (i -> i+1) and -- unless `compact` --
+                                        // the normalised edge function's coefficients; compact: the exact tests rebuild them (edge_coeffs)
+    int vstride, compact;               // doubles per vertex record (6, compact 3)
+    int elen, earc;                     // per LINE-LOOP vertex: segment length and arclength at the segment start
     int pcx, pcy, prad, papo, pphi;     // per prim (n-gon centre/radius/apothem/phase; line half width in prad)
     int n_d;
     int prgb;                           // per prim colour of THIS env (the template's, or the env's own: TestColour variants)
@@ -37,13 +39,17 @@ struct RasterOff {
 #endif
     static constexpr bool A_V = MGX_RAOS & 1, A_P = MGX_RAOS & 2, A_B = MGX_RAOS & 4;
     static constexpr int S_bx = A_B ? 5 : 1, S_by = S_bx, S_ba = S_bx, S_bc = S_bx, S_bs = S_bx;
-    static constexpr int S_svx = A_V ? 7 : 1, S_svy = S_svx, S_ea = S_svx, S_eb = S_svx, S_ec = S_svx, S_elen = S_svx, S_earc = S_svx;
+    static constexpr int S_elen = 1, S_earc = 1;      // (the vertex records have a run-time stride: RDV)
     static constexpr int S_pcx = A_P ? 5 : 1, S_pcy = S_pcx, S_prad = S_pcx, S_papo = S_pcx, S_pphi = S_pcx;
     static constexpr int S_prgb = 1, S_items = 1, S_pitem = 1;
-    MGX_HD explicit RasterOff(const TmplHeader &h) {
+    // compact: three doubles per draw-list vertex less (2.6 KB of LDS in ClusterColour: a fourth workgroup per CU) for a dozen more
+    // fp64 operations per edge in the exact tests; the host takes it where it buys a workgroup per CU (configure_launch)
+    MGX_HD explicit RasterOff(const TmplHeader &h, bool compact_ = true) {
         int o = 0;
+        compact = compact_ ? 1 : 0; vstride = compact_ ? 3 : 6;
         { const int d = A_B ? 1 : h.n_bodies; bx = o; by = o + d; ba = o + 2 * d; bc = o + 3 * d; bs = o + 4 * d; o += 5 * h.n_bodies; }
-        { const int d = A_V ? 1 : h.n_pverts; svx = o; svy = o + d; ea = o + 2 * d; eb = o + 3 * d; ec = o + 4 * d; elen = o + 5 * d; earc = o + 6 * d; o += 7 * h.n_pverts; }
+        svx = o; svy = o + 1; einv = o + 2; ea = o + 3; eb = o + 4; ec = o + 5; o += vstride * h.n_pverts;
+        elen = o; o += h.n_lverts; earc = o; o += h.n_lverts;
         { const int d = A_P ? 1 : h.n_prims; pcx = o; pcy = o + d; prad = o + 2 * d; papo = o + 3 * d; pphi = o + 4 * d; o += 5 * h.n_prims; }
         n_d = o;
         o = 0;
@@ -65,11 +71,12 @@ struct Raster {
     TmplOff to;
     RasterOff ro;
     int view;
-    MGX_HD Raster(const TmplHeader *h_, const int32_t *ti_, const double *tq_, double *d_, int32_t *i_, int view_)
-        : h(h_), ti(ti_), tq(tq_), d(d_), i(i_), to(*h_), ro(*h_), view(view_) {}
+    MGX_HD Raster(const TmplHeader *h_, const int32_t *ti_, const double *tq_, double *d_, int32_t *i_, int view_, bool compact = true)
+        : h(h_), ti(ti_), tq(tq_), d(d_), i(i_), to(*h_), ro(*h_, compact), view(view_) {}
     MGX_HD int prim_kind(int k) const { return ti[to.prim_i + k * PRIM_IWORDS]; }
     MGX_HD int prim_nv(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 1]; }
-    MGX_HD int prim_voff(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 2]; }
+    MGX_HD int prim_voff(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 2] & 0xFFFF; }
+    MGX_HD int prim_lvoff(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 2] >> 16; }     // line loops: first slot of elen / earc
     MGX_HD int prim_xf(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 3]; }
     MGX_HD int prim_rgb(int k) const { return i[ro.prgb + k]; }       // after raster_setup_prims
     MGX_HD int prim_rgb_template(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 4]; }
@@ -84,6 +91,7 @@ struct Raster {
 
 #define RD(field, k) rs.d[rs.ro.field + (k) * RasterOff::S_##field]
 #define RI(field, k) rs.i[rs.ro.field + (k) * RasterOff::S_##field]
+#define RDV(field, v) rs.d[rs.ro.field + (v) * rs.ro.vstride]      // fields of the draw-list vertex records
 
 MGX_HD double rz_floor(double x) { return floor(x); }
 
@@ -218,11 +226,30 @@ MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_
             const double bx = RD(bx, body), by = RD(by, body), bc = RD(bc, body), bs = RD(bs, body);
             wx = bx + (bc * lx - bs * ly); wy = by + (bc * ly + bs * lx);
         }
-        RD(svx, v) = cam[0] * wx + cam[1] * wy + cam[4];
-        RD(svy, v) = cam[2] * wx + cam[3] * wy + cam[5];
+        RDV(svx, v) = cam[0] * wx + cam[1] * wy + cam[4];
+        RDV(svy, v) = cam[2] * wx + cam[3] * wy + cam[5];
     }
 }
 
+// coefficients of the normalised edge function a x + b y + c of the edge that starts at (ax, ay) with direction (ex, ey), inv =
+// sign / length.  One definition for the set-up (which derives the fp32 items from it) and for the exact tests (which rebuild it
+// instead of keeping three doubles per edge in LDS), without contraction so that both get the same bits.
+MGX_HD void edge_coeffs(double ax, double ay, double ex, double ey, double inv, double &a, double &b, double &c) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    a = -ey * inv; b = ex * inv;
+    const double t0 = ey * ax, t1 = ex * ay;
+    c = (t0 - t1) * inv;
+}
+// ... of edge i of primitive k (vertices at vo ..): its end point is the next vertex, or the first vertex of its convex part
+// (`first`) when i closes the part
+MGX_HD void edge_coeffs_of(const Raster &rs, int vo, int i, int first, bool closes, double &a, double &b, double &c) {
+    if (!rs.ro.compact) { a = RDV(ea, vo + i); b = RDV(eb, vo + i); c = RDV(ec, vo + i); return; }
+    const int j = closes ? first : i + 1;
+    const double ax = RDV(svx, vo + i), ay = RDV(svy, vo + i);
+    edge_coeffs(ax, ay, RDV(svx, vo + j) - ax, RDV(svy, vo + j) - ay, RDV(einv, vo + i), a, b, c);
+}
 // ---- setup phase 3 (after a barrier): lane per prim vertex = per polygon edge / line segment (vertex i -> its successor):
 // normalised edge function E(p) = sgn * cross(e, p - a) / |e| (>= 0 inside a polygon; for a line loop |E| is the
 // distance to the segment's carrier line and (eb, -ea) is its unit direction) and the edge's classification item.
@@ -241,29 +268,31 @@ MGX_HD void raster_setup_edges(Raster &rs, int lane, int nl) {
             double area2 = 0.0;
             for (int a = p0; a <= p1; a++) {
                 int b = a == p1 ? p0 : a + 1;
-                area2 += RD(svx, vo + a) * RD(svy, vo + b) - RD(svy, vo + a) * RD(svx, vo + b);
+                area2 += RDV(svx, vo + a) * RDV(svy, vo + b) - RDV(svy, vo + a) * RDV(svx, vo + b);
             }
             sgn = area2 >= 0.0 ? 1.0 : -1.0;
         }
         const int j = i == p1 ? p0 : i + 1;
-        const double ax = RD(svx, vo + i), ay = RD(svy, vo + i), ex = RD(svx, vo + j) - ax, ey = RD(svy, vo + j) - ay;
+        const double ax = RDV(svx, vo + i), ay = RDV(svy, vo + i), ex = RDV(svx, vo + j) - ax, ey = RDV(svy, vo + j) - ay;
         const double len = sqrt(ex * ex + ey * ey);
         const double inv = sgn / len;
-        const double ea = -ey * inv, eb = ex * inv, ec = (ey * ax - ex * ay) * inv;
-        RD(ea, v) = ea; RD(eb, v) = eb; RD(ec, v) = ec; RD(elen, v) = len;
+        double ea, eb, ec;
+        edge_coeffs(ax, ay, ex, ey, inv, ea, eb, ec);
+        RDV(einv, v) = inv;
+        if (!rs.ro.compact) { RDV(ea, v) = ea; RDV(eb, v) = eb; RDV(ec, v) = ec; }
         Item *it = reinterpret_cast<Item *>(&RI(items, 8 * ((RI(pitem, k) & 0xFFFF) + i)));
         it->a = (float)ea; it->b = (float)eb; it->c = (float)ec;
         if (kind == PR_LINELOOP) {
             // arclength at the segment's start: the lengths of the loop's earlier segments, summed in order
             double arc = 0.0;
             for (int a = 0; a < i; a++) {
-                const double dx = RD(svx, vo + a + 1) - RD(svx, vo + a), dy = RD(svy, vo + a + 1) - RD(svy, vo + a);
+                const double dx = RDV(svx, vo + a + 1) - RDV(svx, vo + a), dy = RDV(svy, vo + a + 1) - RDV(svy, vo + a);
                 arc += sqrt(dx * dx + dy * dy);
             }
-            RD(earc, v) = arc;
+            const int lv = rs.prim_lvoff(k) + i;
+            RD(elen, lv) = len; RD(earc, lv) = arc;
             it->g0 = (float)ax; it->g1 = (float)ay; it->g2 = (float)len; it->g3 = (float)RD(prad, k);
         } else {
-            RD(earc, v) = 0.0;
             // edge function divided by its conservative half-extent over a 4x4 sample block (g0..g2: the block is
             // entirely inside / outside this edge when the scaled value at its centre is > 1 / < -1), and the
             // reciprocal half-extent over a whole tile (g3)
@@ -282,9 +311,13 @@ MGX_HD bool poly_contains(const Raster &rs, int k, double x, double y) {
     int nv = rs.prim_nv(k), vo = rs.prim_voff(k);
     const uint32_t ends = rs.prim_ends(k);
     bool in = true;                                 // inside the part being walked; the polygon is the union of its parts
+    int first = 0;
     for (int i = 0; i < nv; i++) {
-        if (RD(ea, vo + i) * x + RD(eb, vo + i) * y + RD(ec, vo + i) < 0.0) in = false;
-        if ((ends >> i) & 1u) { if (in) return true; in = true; }
+        const bool closes = (ends >> i) & 1u;
+        double a, b, c;
+        edge_coeffs_of(rs, vo, i, first, closes, a, b, c);
+        if (a * x + b * y + c < 0.0) in = false;
+        if (closes) { if (in) return true; in = true; first = i + 1; }
     }
     return false;
 }
@@ -305,18 +338,19 @@ MGX_HD bool ngon_contains(const Raster &rs, int k, double x, double y) {
 // max coverage alpha of a smooth line loop at a sample; OUR model of GL_LINE_SMOOTH (driver-defined):
 // alpha = clamp(halfwidth - dist, 0, 1), halfwidth = (w + 1) / 2, 16-px stipple by arclength.
 MGX_HD double lineloop_alpha(const Raster &rs, int k, double x, double y) {
-    int nv = rs.prim_nv(k), vo = rs.prim_voff(k), stipple = rs.prim_stipple(k);
+    int nv = rs.prim_nv(k), vo = rs.prim_voff(k), lvo = rs.prim_lvoff(k), stipple = rs.prim_stipple(k);
     double hw = RD(prad, k), best = 0.0;
     for (int i = 0; i < nv; i++) {
-        double a = RD(ea, vo + i), b = RD(eb, vo + i);
-        double e = a * x + b * y + RD(ec, vo + i);
+        double a, b, c;
+        edge_coeffs_of(rs, vo, i, 0, i == nv - 1, a, b, c);
+        double e = a * x + b * y + c;
         if (r_abs(e) >= hw) continue;                       // distance to the segment >= distance to its line
-        double ax = RD(svx, vo + i), ay = RD(svy, vo + i), len = RD(elen, vo + i);
+        double ax = RDV(svx, vo + i), ay = RDV(svy, vo + i), len = RD(elen, lvo + i);
         double sl = r_clamp((x - ax) * b - (y - ay) * a, 0.0, len);   // arclength of the closest point
         double qx = x - (ax + b * sl), qy = y - (ay - a * sl);
         double alpha = r_clamp01(hw - sqrt(qx * qx + qy * qy));
         if (alpha > 0.0 && stipple) {
-            int bit = ((int)rz_floor(RD(earc, vo + i) + sl)) & 15;
+            int bit = ((int)rz_floor(RD(earc, lvo + i) + sl)) & 15;
             if (!((stipple >> bit) & 1)) alpha = 0.0;
         }
         if (alpha > best) best = alpha;
@@ -326,19 +360,20 @@ MGX_HD double lineloop_alpha(const Raster &rs, int k, double x, double y) {
 
 // as lineloop_alpha, restricted to the segments in `segmask` (the others were excluded by the fp32 conservative test)
 MGX_HD double lineloop_alpha_masked(const Raster &rs, int k, double x, double y, uint32_t segmask) {
-    int vo = rs.prim_voff(k), stipple = rs.prim_stipple(k);
+    int nv = rs.prim_nv(k), vo = rs.prim_voff(k), lvo = rs.prim_lvoff(k), stipple = rs.prim_stipple(k);
     double hw = RD(prad, k), best = 0.0;
     for (; segmask; segmask &= segmask - 1) {
         const int i = __builtin_ctz(segmask);
-        double a = RD(ea, vo + i), b = RD(eb, vo + i);
-        double e = a * x + b * y + RD(ec, vo + i);
+        double a, b, c;
+        edge_coeffs_of(rs, vo, i, 0, i == nv - 1, a, b, c);
+        double e = a * x + b * y + c;
         if (r_abs(e) >= hw) continue;
-        double ax = RD(svx, vo + i), ay = RD(svy, vo + i), len = RD(elen, vo + i);
+        double ax = RDV(svx, vo + i), ay = RDV(svy, vo + i), len = RD(elen, lvo + i);
         double sl = r_clamp((x - ax) * b - (y - ay) * a, 0.0, len);
         double qx = x - (ax + b * sl), qy = y - (ay - a * sl);
         double alpha = r_clamp01(hw - sqrt(qx * qx + qy * qy));
         if (alpha > 0.0 && stipple) {
-            int bit = ((int)rz_floor(RD(earc, vo + i) + sl)) & 15;
+            int bit = ((int)rz_floor(RD(earc, lvo + i) + sl)) & 15;
             if (!((stipple >> bit) & 1)) alpha = 0.0;
         }
         if (alpha > best) best = alpha;
@@ -622,18 +657,20 @@ MGX_HD uint32_t lineloop_touch16(const Raster &rs, int k, int X, int Y, uint32_t
 constexpr float ALPHA_ERR_F = 4e-6f;
 constexpr float STIPPLE_TOL_F = 1e-3f;
 MGX_HD void lineloop_alpha16(const Raster &rs, int k, int X, int Y, uint32_t segmask, float (&alpha)[16], uint32_t &amb) {
-    const int vo = rs.prim_voff(k), stipple = rs.prim_stipple(k);
+    const int nv = rs.prim_nv(k), vo = rs.prim_voff(k), lvo = rs.prim_lvoff(k), stipple = rs.prim_stipple(k);
     const float hw = (float)RD(prad, k);
     const double x0 = 4.0 * X + 0.5, y0 = (double)NATIVE_RES - 0.5 - 4.0 * Y;
 #pragma unroll
     for (int q = 0; q < 16; q++) alpha[q] = 0.0f;
     for (; segmask; segmask &= segmask - 1) {
         const int i = __builtin_ctz(segmask);
-        const double a = RD(ea, vo + i), b = RD(eb, vo + i), ax = RD(svx, vo + i), ay = RD(svy, vo + i), len = RD(elen, vo + i);
-        const double E0 = a * x0 + b * y0 + RD(ec, vo + i), S0 = (x0 - ax) * b - (y0 - ay) * a;
+        double a, b, c;
+        edge_coeffs_of(rs, vo, i, 0, i == nv - 1, a, b, c);
+        const double ax = RDV(svx, vo + i), ay = RDV(svy, vo + i), len = RD(elen, lvo + i);
+        const double E0 = a * x0 + b * y0 + c, S0 = (x0 - ax) * b - (y0 - ay) * a;
         const float af = (float)a, bf = (float)b, e0 = (float)E0, s0 = (float)S0, s1 = (float)(S0 - len), lenf = (float)len;
         float u0 = 0.0f;
-        if (stipple) { const double arc = RD(earc, vo + i); u0 = (float)(arc - 16.0 * rz_floor(arc * 0.0625)); }
+        if (stipple) { const double arc = RD(earc, lvo + i); u0 = (float)(arc - 16.0 * rz_floor(arc * 0.0625)); }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
 #pragma unroll

@@ -29,6 +29,7 @@ struct RasterDev {
     const int32_t *ent_colour_env; // [n_entities][n_envs] per-env entity colour indices (NULL: the template's colours)
     const int32_t *palette;        // device int32[12]: RGB8 of colour c in role r at [4 * r + c] (style.py:28-37)
     const double *goal_xyhw_env;   // [n_goals * 4][n_envs] per-env goal rectangles x, y (top-left), h, w (NULL: the template's)
+    int compact;                   // draw-list vertex records without the edge-function coefficients (RasterOff; the host's choice)
     int qcap;                      // queue entries in use (<= QCAP; tests shrink it to exercise the overflow rounds)
     int ecap;                      // phase E records in use (<= ECAP; likewise)
 };
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster_native(RasterD
     const TmplHeader *h = reinterpret_cast<const TmplHeader *>(lds);
     Raster rs(h, reinterpret_cast<const int32_t *>(lds + t.off_i), reinterpret_cast<const double *>(lds + raster_off_q(*h, t.off_i)),
               reinterpret_cast<double *>(lds + t.lds_tmpl_words),
-              reinterpret_cast<int32_t *>(lds + t.lds_tmpl_words + 2 * t.scratch_d), view);
+              reinterpret_cast<int32_t *>(lds + t.lds_tmpl_words + 2 * t.scratch_d), view, t.compact != 0);
     raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
     __syncthreads();
     raster_setup_prims(rs, tid, 256, t.ent_colour_env, (long)n_envs, env, t.goal_xyhw_env, t.palette);

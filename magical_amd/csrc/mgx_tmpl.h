@@ -36,7 +36,7 @@ constexpr int CAP_PVERTS = 1024;
 
 constexpr int N_PHYS_VARS = 5;    // robot_pos, robot_rot, finger, shape_trans, shape_rot joint max forces (phys_vars.py)
 constexpr int JOINT_PARAMS = 10;   // ax ay bx by p0 p1 p2 bias_rate max_bias max_impulse
-constexpr int PRIM_IWORDS = 7;     // kind, nverts, voff, xform|body<<8|(eye_body+1)<<16|(role+1)<<24|(entity+1)<<26, rgb(packed), stipple, part ends
+constexpr int PRIM_IWORDS = 7;     // kind, nverts, voff | line-vertex offset << 16, xform|body<<8|(eye_body+1)<<16|(role+1)<<24|(entity+1)<<26, rgb(packed), stipple, part ends
 // A PR_POLY primitive is a union of convex parts drawn in one colour (a star: five triangles + a pentagon, entities.py:
 // 723-734): its vertices are the parts' vertices back to back and bit i of the `part ends` word marks vertex i as the
 // last one of its part (a plain convex polygon has the single bit nverts - 1) -- hence at most 32 vertices per primitive.
@@ -49,7 +49,8 @@ struct TmplHeader {
     int32_t max_episode_steps, n_words_i, n_words_r, n_words_p;
     // joint islands (sets of joints that share no dynamic body with any other set): the robot's 10 joints
     // start at robot_j0 in Robot.setup order; every block contributes {pivot, gear} at island_j[k], +1
-    int32_t robot_j0, n_islands, eye_body[2], pad_[2];
+    int32_t robot_j0, n_islands, eye_body[2];
+    int32_t n_lverts, pad_;       // draw-list vertices that belong to line loops (they carry segment length + arclength in the rasteriser)
 };
 
 // indices into the consts block

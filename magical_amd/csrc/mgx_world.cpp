@@ -606,6 +606,8 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
     for (auto &s : shapes) nverts += (s.kind == SH_CIRCLE) ? 1 : (int)s.verts.size();
     if (!strip_prims) for (auto &p : prims) npv += (int)p.verts.size();
     h.n_verts = nverts; h.n_pverts = npv;
+    h.n_lverts = 0;
+    if (!strip_prims) for (auto &p : prims) if (p.kind == PR_LINELOOP) h.n_lverts += (int)p.verts.size();
     h.n_state = (int)state_map.size();
     h.n_state_p = n_state_p;
     h.n_jacc = n_jacc;
@@ -694,13 +696,14 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
         int m = state_map[k], comp = m & 15, b = (m >> 4) & 0xFF, row = m >> 12;
         if (comp < 3) iw[o.body_prow + 3 * b + comp] = row;
     }
-    int pvoff = 0;
+    int pvoff = 0, lvoff = 0;
     for (int k = 0; k < h.n_prims; k++) {
         const PrimDef &P = prims[k];
         int32_t *pi = &iw[o.prim_i + k * PRIM_IWORDS];
         double *pr = &rw[o.prim_r + k * PRIM_RWORDS];
         int nv = (P.kind == PR_NGON) ? P.ngon : (int)P.verts.size();
-        pi[0] = P.kind; pi[1] = nv; pi[2] = pvoff;
+        pi[0] = P.kind; pi[1] = nv; pi[2] = pvoff | (lvoff << 16);      // (both < 2^15: CAP_PVERTS)
+        if (P.kind == PR_LINELOOP) lvoff += (int)P.verts.size();
         pi[3] = P.xform | (P.body << 8) | ((P.eye_body + 1) << 16) | ((P.role + 1) << 24) | (int32_t)((uint32_t)(P.ent + 1) << 26);
         pi[4] = P.rgb[0] | (P.rgb[1] << 8) | (P.rgb[2] << 16);
         pi[5] = P.stipple | ((P.goal + 1) << 16);      // low 16 bits: line stipple; high: 1 + goal ordinal
