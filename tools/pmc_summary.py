@@ -13,7 +13,7 @@ def per_kernel(d):
     out = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        k = None if 'k_raster_deferred' in k else 'k_raster' if 'k_raster' in k else 'k_step' if 'k_step' in k else 'fill_u8' if 'FillFunctor<unsigned char>' in k else None
+        k = None if ('k_raster_deferred' in k or 'k_step_order' in k) else 'k_raster' if 'k_raster' in k else 'k_step' if 'k_step' in k else 'fill_u8' if 'FillFunctor<unsigned char>' in k else None
         if k:
             out[k].append(float(r['Counter_Value']) * 1024.0)
     return out
