@@ -71,6 +71,7 @@ struct WorldBlobs {
     std::vector<uint32_t> raster;    // [header][ints][prim reals + prim verts, fp64]
     int step_env_stride = 0;         // LDS words of the per-env working set
     int step_off_r = 0, step_off_p = 0, step_env_off_r = 0, step_env_off_i = 0;
+    int raster_lds_words = 0;      // the draw-list blob's LDS-resident prefix (header + ints; the fp64 part is read from HBM by the set-up)
     int raster_scratch_d = 0, raster_scratch_dc = 0, raster_n_i = 0;      // doubles (stored / compact vertex records, RasterOff) / ints of the rasteriser's per-env scratch
 };
 
@@ -91,7 +92,7 @@ struct mgx_engine {
     std::unordered_map<std::string, std::weak_ptr<World>> world_by_sig;  // live variants, shared between envs
     int step_stride = 0, raster_stride = 0;                             // words per env in the two blob tables
     // footprints of the envs' current worlds: the launch geometry follows their maxima, not the capacity world's
-    std::vector<int> fp_step_words, fp_env_stride, fp_raster_words, fp_scratch_d, fp_scratch_dc, fp_raster_n_i;
+    std::vector<int> fp_step_words, fp_env_stride, fp_raster_words, fp_raster_full, fp_scratch_d, fp_scratch_dc, fp_raster_n_i;
     uint32_t *d_stage = nullptr; size_t stage_words = 0;                 // upload staging (device)
     uint32_t *h_stage = nullptr; size_t h_stage_words = 0;               // upload staging (pinned host memory)
     int32_t *d_stage_idx = nullptr; size_t stage_idx_n = 0;       // (env, offsets, sizes) rows of an upload
@@ -427,6 +428,7 @@ static void make_blobs_t(const World &w, WorldBlobs &b) {
         keep(o.prim_i, orr.prim_i, b.h.n_prims * PRIM_IWORDS); keep(o.pv_prim, orr.pv_prim, b.h.n_pverts); keep(o.body_prow, orr.body_prow, 3 * b.h.n_bodies);
         const int off_i = HDR_WORDS, off_q = raster_off_q(hr, off_i), nq = b.h.n_prims * PRIM_RWORDS + 2 * b.h.n_pverts;
         b.raster.assign(raster_blob_words(hr, off_i), 0);
+        b.raster_lds_words = off_q;
         std::memcpy(b.raster.data(), &hr, sizeof(TmplHeader));
         std::memcpy(b.raster.data() + off_i, ir.data(), ir.size() * 4);
         std::memcpy(b.raster.data() + off_q, rw.data() + o.prim_r, (size_t)nq * 8);
@@ -445,21 +447,29 @@ static size_t step_lds_bytes(const mgx_engine *e, int L) { return (size_t)(e->td
 // size the launch geometry (lanes per env, LDS, raster variant) for blobs of the given sizes
 // (scratch_d and raster_n_i may be maxima taken from different worlds: the int region starts after the LARGEST double region,
 // so the tile / queue area has to start after the largest double region plus the largest int region)
-static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, int raster_words, int scratch_d_stored, int scratch_d_compact, int raster_n_i) {
+static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, int raster_lds_words, int raster_full_words, int scratch_d_stored, int scratch_d_compact, int raster_n_i) {
     // per-tile (u64 mask + i32 base) + queue (u64 mask + 2 x i32) + counters + overflow bitmap + phase E records (u64 sums, u16 entry)
     const int extra = N_TILES * 3 + QCAP * 4 + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2;
-    // as many rasteriser workgroups per CU as LDS allows (allocations round up to 512 B), between 3 and 5.  The draw-list vertex
-    // records keep their edge-function coefficients (RasterOff) unless dropping them buys a workgroup per CU: rebuilding them costs
-    // the exact tests a dozen fp64 operations per edge (MatchRegions' env-step 1.10 -> 1.17 ms), a fourth workgroup is worth 14 % of
-    // the launch (ClusterColour 45.9 -> 40.6 KB: env-step 1.59 -> 1.52 ms; FindDupe 41.5 -> 37.6 KB: 1.50 -> 1.44 ms)
-    auto raster_fit = [&](int sd) {
-        const size_t lds = (size_t)(even(raster_words) + even(2 * sd + raster_n_i) + extra) * 4;
+    // As many rasteriser workgroups per CU as LDS allows (allocations round up to 512 B), between 3 and 5; a step is worth 13-15 % of
+    // the launch.  Two economies are taken only where they buy such a step, the cheaper one first:
+    //  - the draw list's fp64 part (local vertices, radii: read once per frame, by the set-up) stays in HBM instead of being staged
+    //    with the header and ints (4 KB in ClusterColour; FixColour 36.4 -> 31.4 KB: five per CU, env-step 1.19 -> 1.12 ms; the per-env
+    //    worlds of FixColour / MakeLine: four; where it buys nothing it costs the set-up its LDS reads: MoveToCorner -1 %);
+    //  - the draw-list vertex records drop their edge-function coefficients (RasterOff): rebuilding them costs the exact tests a dozen
+    //    fp64 operations per edge (MatchRegions' env-step 1.10 -> 1.17 ms when forced; ClusterColour 45.9 -> 40.6 KB: 1.59 -> 1.48 ms)
+    auto raster_fit = [&](bool tq_hbm, bool cmp) {
+        const size_t lds = (size_t)(even(tq_hbm ? raster_lds_words : raster_full_words) + even(2 * (cmp ? scratch_d_compact : scratch_d_stored) + raster_n_i) + extra) * 4;
         const int fit = (int)((size_t)MAX_LDS_BYTES / ((lds + 511) & ~(size_t)511));
         return fit > 5 ? 5 : fit;
     };
-    const bool compact = raster_fit(scratch_d_compact) > raster_fit(scratch_d_stored) && !getenv("MGX_RASTER_STORED");
-    const int scratch_d = compact ? scratch_d_compact : scratch_d_stored;
-    e->rdev.compact = compact ? 1 : 0;
+    bool tq_hbm = false, compact = false;
+    if (!getenv("MGX_RASTER_STORED")) {
+        int best = raster_fit(false, false);
+        const bool opts[3][2] = {{true, false}, {false, true}, {true, true}};
+        for (auto &o : opts) if (raster_fit(o[0], o[1]) > best) { best = raster_fit(o[0], o[1]); tq_hbm = o[0]; compact = o[1]; }
+    }
+    const int scratch_d = compact ? scratch_d_compact : scratch_d_stored, raster_words = tq_hbm ? raster_lds_words : raster_full_words;
+    e->rdev.compact = compact ? 1 : 0; e->rdev.tq_hbm = tq_hbm ? 1 : 0;
     const int off_tiles = even(2 * scratch_d + raster_n_i);
     e->tdev.off_i = HDR_WORDS; e->tdev.lds_tmpl_words = even(step_words); e->tdev.env_stride_words = step_env_stride;
     // lanes per env: caller's choice, else the widest group (most narrowphase parallelism) that still lets
@@ -495,7 +505,7 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     e->raster_waves = fit >= 5 ? 5 : (fit == 4 ? 4 : 3);
     if (getenv("MGX_DEBUG_LAUNCH"))
         fprintf(stderr, "mgx: k_raster LDS bytes %zu (draw list %d words, per-env scratch %d words%s, tiles / queues %d words): %d workgroups per CU\n",
-                e->lds_raster, e->rdev.lds_tmpl_words, off_tiles, compact ? " [compact vertex records]" : "", extra, e->raster_waves);
+                e->lds_raster, e->rdev.lds_tmpl_words, off_tiles, compact ? (tq_hbm ? " [compact vertex records, fp64 part in HBM]" : " [compact vertex records]") : (tq_hbm ? " [fp64 part in HBM]" : ""), extra, e->raster_waves);
     return MGX_OK;
 }
 
@@ -637,7 +647,7 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
     make_blobs(dtype, e->w, b);
     e->h = b.h;
     e->rows_p = state_rows_p(b.h); e->rows_f = state_rows_f(b.h); e->rows_i = state_rows_i(b.h);
-    int rc = configure_launch(e, (int)b.step.size(), b.step_env_stride, (int)b.raster.size(), b.raster_scratch_d, b.raster_scratch_dc, b.raster_n_i);
+    int rc = configure_launch(e, (int)b.step.size(), b.step_env_stride, b.raster_lds_words, (int)b.raster.size(), b.raster_scratch_d, b.raster_scratch_dc, b.raster_n_i);
     if (rc) { delete e; return rc; }
     int32_t pal[12];
     for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) pal[4 * r + c] = palette_rgb(c, r);
@@ -942,7 +952,7 @@ int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world)
     make_blobs(e->dtype, capacity_world->w, cb);
     make_blobs(e->dtype, e->w, db);
     if (db.step.size() > cb.step.size() || db.raster.size() > cb.raster.size() || db.step_env_stride > cb.step_env_stride ||
-        db.raster_scratch_d > cb.raster_scratch_d || db.raster_scratch_dc > cb.raster_scratch_dc || db.raster_n_i > cb.raster_n_i)
+        db.raster_lds_words > cb.raster_lds_words || db.raster_scratch_d > cb.raster_scratch_d || db.raster_scratch_dc > cb.raster_scratch_dc || db.raster_n_i > cb.raster_n_i)
         return fail(MGX_ERR_ARG, "the capacity world must be at least as large as the engine's world");
     if (cb.h.n_prims > 64) return fail(MGX_ERR_CAPACITY, "draw list longer than 64 primitives");
     const int step_stride = even((int)cb.step.size()), raster_stride = even((int)cb.raster.size());
@@ -973,14 +983,14 @@ int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world)
         (void)hipFree(d_ty); (void)hipFree(d_on);
     }
     {   // the capacity world itself must be launchable
-        int rc = configure_launch(e, (int)cb.step.size(), cb.step_env_stride, (int)cb.raster.size(), cb.raster_scratch_d, cb.raster_scratch_dc, cb.raster_n_i);
+        int rc = configure_launch(e, (int)cb.step.size(), cb.step_env_stride, cb.raster_lds_words, (int)cb.raster.size(), cb.raster_scratch_d, cb.raster_scratch_dc, cb.raster_n_i);
         if (rc) return rc;
         if (e->lds_raster > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "capacity world's draw list does not fit LDS");
     }
     e->fp_step_words.assign(e->n_envs, (int)db.step.size()); e->fp_env_stride.assign(e->n_envs, db.step_env_stride);
-    e->fp_raster_words.assign(e->n_envs, (int)db.raster.size()); e->fp_scratch_d.assign(e->n_envs, db.raster_scratch_d); e->fp_scratch_dc.assign(e->n_envs, db.raster_scratch_dc);
+    e->fp_raster_words.assign(e->n_envs, db.raster_lds_words); e->fp_raster_full.assign(e->n_envs, (int)db.raster.size()); e->fp_scratch_d.assign(e->n_envs, db.raster_scratch_d); e->fp_scratch_dc.assign(e->n_envs, db.raster_scratch_dc);
     e->fp_raster_n_i.assign(e->n_envs, db.raster_n_i);
-    int rc = configure_launch(e, (int)db.step.size(), db.step_env_stride, (int)db.raster.size(), db.raster_scratch_d, db.raster_scratch_dc, db.raster_n_i);
+    int rc = configure_launch(e, (int)db.step.size(), db.step_env_stride, db.raster_lds_words, (int)db.raster.size(), db.raster_scratch_d, db.raster_scratch_dc, db.raster_n_i);
     if (rc) return rc;
     e->rows_p = std::max(e->rows_p, state_rows_p(cb.h)); e->rows_f = std::max(e->rows_f, state_rows_f(cb.h)); e->rows_i = std::max(e->rows_i, state_rows_i(cb.h));
     return MGX_OK;
@@ -1121,11 +1131,11 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         retired[k] = std::move(e->env_world[env]);
         e->env_world[env] = uniq[which[k]].world;
         e->fp_step_words[env] = (int)B.step.size(); e->fp_env_stride[env] = B.step_env_stride;
-        e->fp_raster_words[env] = (int)B.raster.size(); e->fp_scratch_d[env] = B.raster_scratch_d; e->fp_scratch_dc[env] = B.raster_scratch_dc; e->fp_raster_n_i[env] = B.raster_n_i;
+        e->fp_raster_words[env] = B.raster_lds_words; e->fp_raster_full[env] = (int)B.raster.size(); e->fp_scratch_d[env] = B.raster_scratch_d; e->fp_scratch_dc[env] = B.raster_scratch_dc; e->fp_raster_n_i[env] = B.raster_n_i;
     }
     {
         auto mx = [](const std::vector<int> &v) { return *std::max_element(v.begin(), v.end()); };
-        int rc = configure_launch(e, mx(e->fp_step_words), mx(e->fp_env_stride), mx(e->fp_raster_words), mx(e->fp_scratch_d), mx(e->fp_scratch_dc), mx(e->fp_raster_n_i));
+        int rc = configure_launch(e, mx(e->fp_step_words), mx(e->fp_env_stride), mx(e->fp_raster_words), mx(e->fp_raster_full), mx(e->fp_scratch_d), mx(e->fp_scratch_dc), mx(e->fp_raster_n_i));
         if (rc) return rc;
     }
     for (auto &U : uniq) e->world_by_sig[U.sig] = U.world;

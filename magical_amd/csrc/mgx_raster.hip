@@ -16,7 +16,8 @@
 namespace mgx {
 
 struct RasterDev {
-    const uint32_t *words;   // [TmplHeader][int words][pad][tq doubles]; env e's own blob at words + e * tmpl_stride_words
+    const uint32_t *words;   // [TmplHeader][int words][pad][tq doubles]; env e's own blob at words + e * tmpl_stride_words.  Header and ints are
+                             // staged in LDS; the doubles (local vertices, radii) are read once per frame by the set-up, straight from HBM
     long tmpl_stride_words;  // 0: one draw list for all envs
     int n_words;             // words of the shared blob (per-env blobs: see raster_blob_words)
     int off_i;               // word offset of the int array (the doubles follow at raster_off_q)
@@ -29,6 +30,7 @@ struct RasterDev {
     const int32_t *ent_colour_env; // [n_entities][n_envs] per-env entity colour indices (NULL: the template's colours)
     const int32_t *palette;        // device int32[12]: RGB8 of colour c in role r at [4 * r + c] (style.py:28-37)
     const double *goal_xyhw_env;   // [n_goals * 4][n_envs] per-env goal rectangles x, y (top-left), h, w (NULL: the template's)
+    int tq_hbm;                    // the draw list's fp64 part is not staged in LDS: the set-up reads it from HBM (the host's choice)
     int compact;                   // draw-list vertex records without the edge-function coefficients (RasterOff; the host's choice)
     int qcap;                      // queue entries in use (<= QCAP; tests shrink it to exercise the overflow rounds)
     int ecap;                      // phase E records in use (<= ECAP; likewise)
@@ -54,6 +56,14 @@ constexpr unsigned HANDOFF_POLL_LIMIT = 1u << 20;      // x (s_sleep 16 + an L2 
 MGX_HD int raster_off_q(const TmplHeader &h, int off_i) { return (off_i + h.n_words_i + 1) & ~1; }
 MGX_HD int raster_blob_words(const TmplHeader &h, int off_i) { return raster_off_q(h, off_i) + 2 * (h.n_prims * PRIM_RWORDS + 2 * h.n_pverts); }
 constexpr int N_TILES = TILES_X * TILES_Y;
+// words of a draw-list blob that a workgroup stages in LDS, and where its fp64 part is then read
+__device__ __forceinline__ int raster_staged_words(const RasterDev &t, const uint32_t *blob) {
+    const TmplHeader &h = *reinterpret_cast<const TmplHeader *>(blob);
+    return t.tq_hbm ? raster_off_q(h, t.off_i) : raster_blob_words(h, t.off_i);
+}
+__device__ __forceinline__ const double *raster_tq(const RasterDev &t, const uint32_t *blob, const uint32_t *lds, const TmplHeader &h) {
+    return reinterpret_cast<const double *>((t.tq_hbm ? blob : lds) + raster_off_q(h, t.off_i));
+}
 constexpr int QCAP = 1024;     // LDS queue of undecided pixels per env; what does not fit waits in a bitmap for another round
 constexpr int OVF_WORDS = LORES * LORES / 32;
 constexpr int ECAP = 256;      // phase E records per round (uncertain pixels beyond that wait in the bitmap like queue overflow)
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
 #endif
     long env = blockIdx.x;
     // the shared draw list does not depend on the env: stage it before waiting for the hand-off
-    if (!t.tmpl_stride_words) for (int i = tid; i < t.n_words; i += 256) lds[i] = t.words[i];
+    if (!t.tmpl_stride_words) { const int n = raster_staged_words(t, t.words); for (int i = tid; i < n; i += 256) lds[i] = t.words[i]; }
     if (ho.mode) {
         // one lane waits / decides, one agent-scope acquire per workgroup, then plain loads (cdna guide, G16)
         int32_t *slot = reinterpret_cast<int32_t *>(lds + t.lds_tmpl_words + t.off_tiles) + (N_TILES * 3 + QCAP * 4 + 5);    // = q_count[5], unused below
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(256, 3) void k_raster_deferred(RasterDev t, const P
     if (ho.deferred[blockIdx.x] != ho.epoch) return;                        // (workgroup-uniform)
     const long env = (long)(ho.queue[blockIdx.x] & 0xFFFFFFFFull);         // written by a kernel that has completed
     const uint8_t *fill_mask = nullptr;
-    if (!t.tmpl_stride_words) for (int i = tid; i < t.n_words; i += 256) lds[i] = t.words[i];
+    if (!t.tmpl_stride_words) { const int n = raster_staged_words(t, t.words); for (int i = tid; i < n; i += 256) lds[i] = t.words[i]; }
     constexpr bool TWO_PASS_POLY = true;
 #include "mgx_raster_body.inc"
 #undef CLK
@@ -331,12 +341,12 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster_native(RasterD
     const int tid = threadIdx.x;
     {
         const uint32_t *src = t.words + env * t.tmpl_stride_words;
-        const int n = t.tmpl_stride_words ? raster_blob_words(*reinterpret_cast<const TmplHeader *>(src), t.off_i) : t.n_words;
+        const int n = raster_staged_words(t, src);
         for (int i = tid; i < n; i += 256) lds[i] = src[i];
     }
     __syncthreads();
     const TmplHeader *h = reinterpret_cast<const TmplHeader *>(lds);
-    Raster rs(h, reinterpret_cast<const int32_t *>(lds + t.off_i), reinterpret_cast<const double *>(lds + raster_off_q(*h, t.off_i)),
+    Raster rs(h, reinterpret_cast<const int32_t *>(lds + t.off_i), raster_tq(t, t.words + env * t.tmpl_stride_words, lds, *h),
               reinterpret_cast<double *>(lds + t.lds_tmpl_words),
               reinterpret_cast<int32_t *>(lds + t.lds_tmpl_words + 2 * t.scratch_d), view, t.compact != 0);
     raster_setup_bodies<P>(rs, sp, (long)n_envs, env, tid, 256);
