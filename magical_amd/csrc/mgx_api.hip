@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <iterator>
 #include <thread>
+#include <chrono>
 #include <type_traits>
 
 #include <cstdio>
@@ -1001,6 +1002,9 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     if (!e->env_worlds) return fail(MGX_ERR_STATE, "call mgx_engine_enable_env_worlds first");
     if (m == 0) return MGX_OK;
     ON_DEVICE(e);
+    const bool dbg = getenv("MGX_DEBUG_VARIANTS") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tm[8]; int ti = 0; tm[ti++] = now();
     const int ne = (int)e->w.entities.size();
     for (int k = 0; k < m; k++) if (env_idx[k] < 0 || env_idx[k] >= e->n_envs) return fail(MGX_ERR_ARG, "env index out of range");
     // unique signatures of this call; worlds that are still alive are reused
@@ -1025,6 +1029,7 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         }
         which[k] = it->second;
     }
+    tm[ti++] = now();
     // build what is missing and serialise everything, a few host threads wide
     int n_threads = (int)std::thread::hardware_concurrency();
     n_threads = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
@@ -1049,6 +1054,7 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         for (int t = 0; t < n_threads; t++) pool.emplace_back(work, t);
         for (auto &th : pool) th.join();
     }
+    tm[ti++] = now();
     for (auto &U : uniq) {
         if (U.rc) return fail(U.rc == -2 ? MGX_ERR_CAPACITY : MGX_ERR_ARG, U.err);
         if ((int)U.blobs.step.size() > e->step_stride || (int)U.blobs.raster.size() > e->raster_stride ||
@@ -1085,6 +1091,7 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         for (int t = 0; t < n_threads; t++) pool.emplace_back(pack, t);
         for (auto &th : pool) th.join();
     }
+    tm[ti++] = now();
     // per env: destination env, source offsets and sizes of its two blobs
     std::vector<int32_t> rows((size_t)5 * m);
     for (int k = 0; k < m; k++) {
@@ -1124,6 +1131,7 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(st));        // the staging buffer, `rows` and the entity rows are read by the copies above
     (void)hipFree(d_ty); (void)hipFree(d_on); (void)hipFree(d_idx);
+    tm[ti++] = now();
     std::vector<std::shared_ptr<World>> retired(m);      // the envs' previous worlds: freed below, a few threads wide
     for (int k = 0; k < m; k++) {
         const int env = env_idx[k];
@@ -1139,6 +1147,7 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         if (rc) return rc;
     }
     for (auto &U : uniq) e->world_by_sig[U.sig] = U.world;
+    tm[ti++] = now();
     {
         // a World is a few hundred small allocations: drop the retired ones (and this call's blob buffers) in parallel
         auto drop = [&](int t) {
@@ -1154,6 +1163,9 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     }
     if (e->world_by_sig.size() > (size_t)4 * e->n_envs + 64)
         for (auto it = e->world_by_sig.begin(); it != e->world_by_sig.end();) it = it->second.expired() ? e->world_by_sig.erase(it) : std::next(it);
+    tm[ti++] = now();
+    if (dbg) fprintf(stderr, "mgx: set_env_variants %d envs, %zu distinct worlds, %d threads: signatures %.1f ms, build + serialise %.1f, pack %.1f, upload + place %.1f, bookkeeping %.1f, frees %.1f\n",
+                     m, uniq.size(), n_threads, tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], tm[6] - tm[5]);
     return (int)uniq.size();
 }
 
