@@ -510,6 +510,7 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     return MGX_OK;
 }
 
+static long step_slots(mgx_engine *e);
 template <typename R, typename P, int L>
 static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const int32_t *actions, uint8_t *done, int n_sub,
                          int count_step, hipStream_t st, const StepHandoff &ho) {
@@ -521,9 +522,7 @@ static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const i
     // More step workgroups than the chip holds at once (LDS: 160 KB per CU; registers: one wavefront per SIMD, two for the
     // one-env-per-wavefront instantiation): they are dispatched longest first, by the durations of the previous launch.
     // Measured at 4096 envs: ClusterColour (2048 workgroups on 1024 slots) k_step 0.89 -> 0.6x ms.
-    if (!e->n_cus) { HIP_OK(hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, e->device)); if (e->n_cus <= 0) e->n_cus = 256; }
-    const int by_lds = (int)((size_t)MAX_LDS_BYTES / ((lds + 511) & ~(size_t)511)), by_regs = 4 * (L == 64 ? MGX_L64_WAVES : MGX_LN_WAVES);
-    const long slots = (long)e->n_cus * (by_lds < by_regs ? by_lds : by_regs);
+    const long slots = step_slots(e);
     const bool lpt = blocks > slots && blocks <= (1 << 20) && !getenv("MGX_NO_LPT");
     TmplDev t = e->tdev;
     t.order = nullptr; t.dur = nullptr;
@@ -549,6 +548,14 @@ static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const i
     return MGX_OK;
 }
 static int step_blocks(const mgx_engine *e) { const int epb = 64 / e->L; return (e->n_envs + epb - 1) / epb; }
+// step workgroups the chip holds at once (LDS: 160 KB per CU; registers: one wavefront per SIMD, two for the one-env-per-wavefront
+// instantiation)
+static long step_slots(mgx_engine *e) {
+    if (!e->n_cus) { if (hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || e->n_cus <= 0) e->n_cus = 256; }
+    const size_t lds = step_lds_bytes(e, e->L);
+    const int by_lds = (int)((size_t)MAX_LDS_BYTES / ((lds + 511) & ~(size_t)511)), by_regs = 4 * (e->L == 64 ? MGX_L64_WAVES : MGX_LN_WAVES);
+    return (long)e->n_cus * (by_lds < by_regs ? by_lds : by_regs);
+}
 template <typename R, typename P>
 static int launch_step(mgx_engine *e, void *sp, void *sf, int32_t *si, const int32_t *actions, uint8_t *done, int n_sub,
                        int count_step, hipStream_t st, const StepHandoff &ho = StepHandoff{}) {
@@ -822,7 +829,11 @@ int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t 
     // worlds) are safe -- raster workgroups are dispatched as step workgroups retire and free their LDS, find their queue entry
     // there already, and fill the machine through the step kernel's tail.  Measured at 4096 envs, two-call -> fused: MatchRegions
     // 1.46 -> 1.28 ms per env-step, MakeLine 1.49 -> 1.30, FixColour 1.26 -> 1.17, FindDupe 1.84 -> 1.73, ClusterColour 1.94 -> 1.83.
-    const bool overlap = !getenv("MGX_NO_OVERLAP");
+    // ... up to six dispatch rounds of step workgroups.  Beyond that (MoveToCorner: from ~40 000 envs on one GPU) the raster
+    // workgroups that are dispatched into every freed slot outrun the finished envs, give up by the million and leave their work to
+    // the clean-up launch: measured 7.85 vs 7.49 M env-steps/s at 32 768 envs (5.3 rounds), 7.46 vs 7.71 M at 65 536 (10.7), 5.02 vs
+    // 7.62 M at 131 072 (21) -- there the two calls in sequence are the better schedule
+    const bool overlap = !getenv("MGX_NO_OVERLAP") && (long)step_blocks(e) <= 6 * step_slots(e);
     if (!overlap) {
         int rc = step_common(e, state_p, state_f, state_i, actions, done, PHYS_STEPS, 1, stream);
         return rc ? rc : mgx_engine_render(e, state_p, out, env_stride, view, layout, nullptr, stream);
