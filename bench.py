@@ -139,6 +139,19 @@ def main_config5(args):
         dist.destroy_process_group()
 
 
+def window_plan(K, W, ep, n):
+    """(untimed preroll steps, envs whose episode ends inside the K-step window, their clock offset) -- see main().
+    K >= ep, or a warm-up that leaves no room for K steps inside one episode: (0, 0, 0), the window holds whole episodes as it is."""
+    if K >= ep or W + K > ep:
+        return 0, 0, 0
+    start_phase = max(W, (ep - K) // 2)             # episode step of the untouched envs at the start of the window
+    preroll = ep + start_phase - W                  # one whole untimed episode first (clocks, allocator, pinned buffers warm)
+    share = int(round(n * K / ep))
+    ahead = ep - K // 2 - 1 - start_phase           # clock offset of the envs that finish inside the window
+    assert 0 <= ahead and ahead + start_phase < ep and start_phase + K <= ep
+    return preroll, share, ahead
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -178,13 +191,7 @@ def main():
     # window covers the middle K steps of their episode; the untimed preroll takes them there).  K >= ep: the window
     # contains K / ep whole episodes of every env as it is, nothing is set ahead.
     ep = env.max_episode_steps
-    preroll, share = 0, 0
-    if K < ep:
-        start_phase = max(W, (ep - K) // 2)             # episode step of the untouched envs at the start of the window
-        preroll = ep + start_phase - W                  # one whole untimed episode first (clocks, allocator, pinned buffers warm)
-        share = int(round(n * K / ep))
-        ahead = ep - K // 2 - 1 - start_phase           # clock offset of the envs that finish inside the window
-        assert 0 <= ahead and ahead + start_phase < ep and start_phase + K <= ep
+    preroll, share, ahead = window_plan(K, W, ep, n)
     # synthetic input: A = RandomState(seed).randint(0, 18, (T, N)) uploaded once; each rank its own slice
     tape = torch.as_tensor(np.random.RandomState(rank).randint(0, 18, size=(preroll + W + K, n)).astype(np.int32), device=device)
     obs = env.reset()

@@ -336,3 +336,28 @@ def test_batched_rng_primitives_equal_numpy():
     from magical_amd.base_env import PhysicsVariables
     got = PhysicsVariables.sample_batch(brng)
     assert np.array_equal(got, np.array([PhysicsVariables.sample(r) for r in refs]))
+
+
+def test_bench_window_plan_gives_every_window_its_share_of_episode_ends():
+    """bench.py: a K-step timed window shorter than an episode contains the episode end of n * K / ep envs (their clocks set
+    ahead so that the end falls in the middle of the window) and no end of the others, neither in the window nor in the
+    warm-up; windows that cannot be placed inside one episode, or that span episodes, are left alone."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    for ep in (40, 80, 240):
+        for K in (1, 5, 20, 39, 79, 80, 400):
+            for W in (0, 5, 20, 60):
+                n = 4096
+                preroll, share, ahead = bench.window_plan(K, W, ep, n)
+                if K >= ep or W + K > ep:
+                    assert (preroll, share, ahead) == (0, 0, 0)
+                    continue
+                assert share == round(n * K / ep) and preroll >= ep
+                # clocks are set when every env starts its second episode (preroll step ep); the window starts preroll - ep + W steps later
+                start = preroll - ep + W
+                first, last = start, start + K - 1                       # episode clock of the untouched envs over the window
+                assert last < ep and start >= W                           # ... which never reaches the end, in warm-up or window
+                end_step = ep - 1 - ahead                                 # step (since the clocks were set) at which the others finish
+                assert first <= end_step <= last                          # inside the window
+                assert end_step >= start                                  # not during the warm-up
