@@ -142,13 +142,13 @@ def main_config5(args):
 def window_plan(K, W, ep, n):
     """(untimed preroll steps, envs whose episode ends inside the K-step window, their clock offset) -- see main().
     K >= ep, or a warm-up that leaves no room for K steps inside one episode: (0, 0, 0), the window holds whole episodes as it is."""
-    if K >= ep or W + K > ep:
+    if K >= ep or W + K >= ep:
         return 0, 0, 0
-    start_phase = max(W, (ep - K) // 2)             # episode step of the untouched envs at the start of the window
+    start_phase = max(W, (ep - K - 1) // 2)         # episode clock of the untouched envs at the start of the window
     preroll = ep + start_phase - W                  # one whole untimed episode first (clocks, allocator, pinned buffers warm)
     share = int(round(n * K / ep))
     ahead = ep - K // 2 - 1 - start_phase           # clock offset of the envs that finish inside the window
-    assert 0 <= ahead and ahead + start_phase < ep and start_phase + K <= ep
+    assert 0 <= ahead and ahead + start_phase < ep and start_phase + K < ep
     return preroll, share, ahead
 
 

@@ -350,14 +350,14 @@ def test_bench_window_plan_gives_every_window_its_share_of_episode_ends():
             for W in (0, 5, 20, 60):
                 n = 4096
                 preroll, share, ahead = bench.window_plan(K, W, ep, n)
-                if K >= ep or W + K > ep:
+                if K >= ep or W + K >= ep:
                     assert (preroll, share, ahead) == (0, 0, 0)
                     continue
                 assert share == round(n * K / ep) and preroll >= ep
                 # clocks are set when every env starts its second episode (preroll step ep); the window starts preroll - ep + W steps later
                 start = preroll - ep + W
-                first, last = start, start + K - 1                       # episode clock of the untouched envs over the window
-                assert last < ep and start >= W                           # ... which never reaches the end, in warm-up or window
+                first, last = start, start + K - 1                       # steps of the window, counted from the setting of the clocks
+                assert start + K < ep and start >= W                      # the untouched envs' clock (0 then) stays below ep to the window's end
                 end_step = ep - 1 - ahead                                 # step (since the clocks were set) at which the others finish
                 assert first <= end_step <= last                          # inside the window
                 assert end_step >= start                                  # not during the warm-up
