@@ -10,7 +10,8 @@ step() returns (obs, reward, done, info) like the reference (base_env.py:255-292
            magical_amd/benchmarks/__init__.py)
   reward : torch.float32[N], always 0 (base_env.py:266-267)
   done   : numpy bool[N]
-  info   : {'eval_score': numpy float64[N]}  (0.0 until done, base_env.py:285-288)
+  info   : {'eval_score': numpy float64[N]}  (0.0 until done, base_env.py:285-288); with terminal_observation=True, in steps in
+           which episodes end, also 'terminal_observation' (the finished envs' last observation) and 'terminal_env_idx'
 With auto_reset=True (default, SB3 VecEnv semantics) finished envs are reset inside step()
 and their returned obs is the first observation of the next episode (the terminal observation
 is overwritten; a caller that needs it steps with auto_reset=False and resets itself).
@@ -88,7 +89,7 @@ class BaseEnv(abc.ABC):
     def __init__(self, *, n_envs=1, device='cuda:0', res_hw=(384, 384), fps=8, phys_steps=10, phys_iter=10,
                  max_episode_steps=None, rand_dynamics=False, ego_view=True, allo_view=True,
                  dtype='f32', lanes_per_env=0, auto_reset=True, copy_obs=False, strict_capacity=False, overlap=True, batch_draws=True,
-                 obs_ring=None):
+                 obs_ring=None, terminal_observation=False):
         import torch
         if fps != 8 or phys_steps != 10 or phys_iter != 10:
             raise NotImplementedError('the engine is built for the registered rates: fps=8, 10 substeps, 10 iterations '
@@ -108,6 +109,14 @@ class BaseEnv(abc.ABC):
         self.obs_ring = int(os.environ.get('MGX_OBS_RING', '0')) if obs_ring is None else int(obs_ring)
         if self.obs_ring and self.obs_ring < 5:
             raise ValueError('obs_ring: at least 5 frames (4 in the window + the one being written)')
+        # auto-reset replaces a finished env's observation by the first one of its next episode; with terminal_observation=True
+        # step() also hands out the observation the episode ENDED with (what the reference's step() returns together with done,
+        # base_env.py:255-292; every MAGICAL episode ends by its time limit, so value bootstrapping wants it):
+        # info['terminal_observation'] (rows in the order of info['terminal_env_idx']), at the cost of one more rasteriser pass
+        # in the steps in which episodes end
+        self.terminal_observation = bool(terminal_observation)
+        if self.terminal_observation and self.obs_ring:
+            raise NotImplementedError('terminal_observation with obs_ring: not built')
         self.batch_draws = bool(batch_draws)   # per-episode draws of all envs of a reset per native call (batch_rng.py) instead of env by env
         self.overlap = bool(overlap)       # step(): physics + observation as a producer / consumer kernel pair (mgx_engine_step_render)
         self._obs_ready = False
@@ -335,6 +344,10 @@ class BaseEnv(abc.ABC):
             # overwrite, so they score first, as before.
             early = (self.auto_reset and not self.rand_dynamics and not self.variable_worlds and not self.sample_variation_is_active())
             snap_p = snap_i = snap_o = None
+            term = term_token = None
+            want_term = self.terminal_observation and self.auto_reset
+            if want_term and not early:
+                term, term_token = self._terminal_begin(idx)
             if early:
                 # asynchronous copies into pinned host memory, an event after them, THEN the reset and the rasterisation: the host
                 # waits for the event only, and scores while the GPU is still busy
@@ -346,6 +359,8 @@ class BaseEnv(abc.ABC):
                     self._enqueue_region_overlaps(self._done_dev)
                     snap_o = pin['o']; snap_o.copy_(self._overlap_dev, non_blocking=True)
                 pin['ev'].record(torch.cuda.current_stream(self.device))
+                if want_term:
+                    term, term_token = self._terminal_begin(idx)
                 self._reset_envs(idx, self._done_dev)
                 fill = self._done_dev
                 self._fill_idx = idx
@@ -369,9 +384,13 @@ class BaseEnv(abc.ABC):
         if obs is None:
             obs = self._observe(fill_mask=fill)
         self._fill_idx = None
+        info = {'eval_score': eval_score}
+        if done.any() and self.terminal_observation and self.auto_reset:
+            self._terminal_end(term_token, self._done_dev)
+            info['terminal_observation'], info['terminal_env_idx'] = term, idx
         if self.copy_obs:
             obs = {k: v.clone() for k, v in obs.items()} if isinstance(obs, dict) else obs.clone()
-        return obs, self._reward, done, {'eval_score': eval_score}
+        return obs, self._reward, done, info
 
     def _check_capacity(self, idx, n_finished, source=None):
         """Chipmunk never drops a contact (base_env.py:243); this engine's per-env working set is sized from the world
@@ -656,6 +675,17 @@ class BaseEnv(abc.ABC):
         """Space of ONE env's observation.  Without a preprocessor that is this engine's state-only observation; the
         reference's Dict{'allo','ego': Box(0,255,(384,384,3),u8)} (base_env.py:97-107) is what `render()` returns."""
         return spaces.Box(-np.inf, np.inf, (self.n_bodies, 3), np.float32)
+
+    def _terminal_begin(self, idx):
+        """After the physics of a step in which the envs `idx` finish, before they are reset: (their terminal observations,
+        a token for _terminal_end).  Default (observations made afresh on every call): just this step's observation."""
+        import torch
+        it = torch.as_tensor(idx, device=self.device)
+        obs = self._observe()
+        return ({k: v[it].clone() for k, v in obs.items()} if isinstance(obs, dict) else obs[it].clone()), None
+
+    def _terminal_end(self, token, done_dev):
+        """After the observation of the step has been made: undo what _terminal_begin did to the envs that did not finish."""
 
     def _fused_target(self):
         """(tensor, view, layout) of the rasteriser pass that makes this env's observation -- or a list of them, in launch order, for

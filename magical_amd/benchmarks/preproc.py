@@ -92,6 +92,27 @@ def wrap_preproc(env_cls, preproc):
             box = spaces.Box(0, 255, (12, 96, 96) if preproc == 'LoResCHW4E' else (96, 96, 12), 'uint8')
             return spaces.Dict([('allo', box), ('ego', box)]) if preproc == 'LoResStack' else box
 
+        # ---- terminal observations (BaseEnv(terminal_observation=True)): the stacks take the post-step frame of EVERY env -- for the
+        # finished envs that is the observation their episode ends with -- and the envs that did not finish get their stacks back after
+        # the reset's fill pass has shifted them a second time
+        def _stacks(self):
+            return [self._stack] if self._stack_allo is None else [self._stack_allo, self._stack]
+
+        def _terminal_begin(self, idx):
+            import torch
+            it = torch.as_tensor(idx, device=self.device)
+            obs = self._observe()
+            term = {k: v[it].clone() for k, v in obs.items()} if isinstance(obs, dict) else obs[it].clone()
+            saved = None if len(idx) == self.n_envs else [t.clone() for t in self._stacks()]
+            return term, saved
+
+        def _terminal_end(self, saved, done_dev):
+            import torch
+            if saved is not None:
+                keep = done_dev.view(-1, 1, 1, 1) != 0
+                for t, sv in zip(self._stacks(), saved):
+                    t.copy_(torch.where(keep, t, sv))
+
         def _fused_target(self):
             from .. import _native as nat
             if preproc == 'LoRes3EA':         # the launches of _observe(), in its order

@@ -1234,6 +1234,46 @@ def test_longest_first_dispatch_changes_nothing(name, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', ['MoveToCorner-Demo-LoRes4E-v0', 'FixColour-TestJitter-LoResCHW4E-v0', 'MatchRegions-Demo-LoResStack-v0',
+                                  'FindDupe-TestAll-LoRes3EA-v0', 'MakeLine-Demo-v0'])
+def test_terminal_observation_is_what_the_episode_ended_with(name):
+    """terminal_observation=True: in a step in which episodes end, info['terminal_observation'] holds the finished envs' last
+    observation -- what an env that is NOT auto-reset returns in that step (the reference's step() at done, base_env.py:255-292) --
+    while the observations handed out (first frames of the new episodes, undisturbed stacks of the other envs), states and scores
+    are those of the same env without the option.  Episode clocks set apart: one full and two partial episode ends."""
+    import torch
+    n, ep = 90, 7
+    eq = lambda x, y: all(torch.equal(x[k], y[k]) for k in x) if isinstance(x, dict) else torch.equal(x, y)
+    take = lambda x, i: {k: v[i] for k, v in x.items()} if isinstance(x, dict) else x[i]
+    a = _make(name, n, max_episode_steps=ep, terminal_observation=True); b = _make(name, n, max_episode_steps=ep)
+    c = _make(name, n, max_episode_steps=ep, auto_reset=False)
+    clocks = np.zeros(n, dtype=np.int64); clocks[::3] = 2; clocks[1::3] = 4
+    for e in (a, b, c):
+        e.seed(4); e.reset(); e.set_episode_steps(clocks)
+    tape = _tape(13, 2 * ep, n)
+    first_end = np.full(n, -1)
+    for s in range(2 * ep):
+        oa, _, da, ia = a.step(tape[s]); ob, _, db, ib = b.step(tape[s])
+        assert np.array_equal(da, db) and np.array_equal(ia['eval_score'], ib['eval_score'])
+        assert eq(oa, ob), (name, s)
+        assert ('terminal_observation' in ia) == bool(da.any())
+        live = first_end < 0                              # c is never reset: comparable up to each env's first episode end
+        if live.any():
+            oc, _, dc, _ = c.step(tape[s])
+        if da.any():
+            idx = ia['terminal_env_idx']
+            assert np.array_equal(idx, np.nonzero(da)[0])
+            fresh = live[idx]
+            if fresh.any():
+                it = torch.as_tensor(idx[fresh], device='cuda:0'); rows = torch.as_tensor(np.nonzero(fresh)[0], device='cuda:0')
+                assert eq(take(ia['terminal_observation'], rows), take(oc, it)), (name, s)
+            first_end[idx[fresh]] = s
+    assert (first_end >= 0).all()
+    assert torch.equal(a.state_p, b.state_p) and torch.equal(a.state_f, b.state_f)
+    a.close(); b.close(); c.close()
+
+
+@pytest.mark.gpu
 def test_task_fleet_equals_engines_run_one_by_one():
     """BASELINE.json configs[4] shape on one GPU: the 8 Demo tasks as 8 engines on 8 HIP streams (distributed.TaskFleet) give
     the scores and final observations of the same engines stepped one after the other."""
