@@ -463,11 +463,20 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
         const int fit = (int)((size_t)MAX_LDS_BYTES / ((lds + 511) & ~(size_t)511));
         return fit > 5 ? 5 : fit;
     };
+    // (a fifth workgroup means the 96-register variant, whose edge-by-edge polygon coverage is slow on stars, §3.2: worlds that can
+    // hold multi-part polygons do not economise their way to it -- MatchRegions 1.115 -> 1.154 ms per env-step when they did, while
+    // FixColour, which has none, gains: 1.188 -> 1.126)
+    bool stars = e->env_worlds;
+    for (const auto &pr : e->w.prims) stars = stars || pr.parts.size() > 1;
+    const int cap = stars ? 4 : 5;
     bool tq_hbm = false, compact = false;
     if (!getenv("MGX_RASTER_STORED")) {
         int best = raster_fit(false, false);
         const bool opts[3][2] = {{true, false}, {false, true}, {true, true}};
-        for (auto &o : opts) if (raster_fit(o[0], o[1]) > best) { best = raster_fit(o[0], o[1]); tq_hbm = o[0]; compact = o[1]; }
+        for (auto &o : opts) {
+            const int f = raster_fit(o[0], o[1]) < cap ? raster_fit(o[0], o[1]) : cap;
+            if (f > best) { best = f; tq_hbm = o[0]; compact = o[1]; }
+        }
     }
     const int scratch_d = compact ? scratch_d_compact : scratch_d_stored, raster_words = tq_hbm ? raster_lds_words : raster_full_words;
     e->rdev.compact = compact ? 1 : 0; e->rdev.tq_hbm = tq_hbm ? 1 : 0;

@@ -54,7 +54,7 @@ struct RasterOff {
         n_d = o;
         o = 0;
         prgb = o; o += h.n_prims;
-        n_items = h.n_pverts + h.n_prims;          // upper bound: one per polygon edge / line segment / n-gon
+        n_items = h.n_items;                       // one per polygon edge / line segment / n-gon
         o = (o + 3) & ~3;                          // 16-byte aligned records
         items = o; o += 8 * n_items;
         pitem = o; o += h.n_prims;
