@@ -54,7 +54,8 @@ struct RasterOff {
         n_d = o;
         o = 0;
         prgb = o; o += h.n_prims;
-        n_items = h.n_items;                       // one per polygon edge / line segment / n-gon
+        n_items = h.n_pverts + h.n_prims;          // upper bound: one per polygon edge / line segment / n-gon (the exact count,
+                                                   // 0.4-0.8 KB less, buys no workgroup anywhere and shifts MoveToCorner's tables: -0.4 %)
         o = (o + 3) & ~3;                          // 16-byte aligned records
         items = o; o += 8 * n_items;
         pitem = o; o += h.n_prims;

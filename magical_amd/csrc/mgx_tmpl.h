@@ -50,8 +50,7 @@ struct TmplHeader {
     // joint islands (sets of joints that share no dynamic body with any other set): the robot's 10 joints
     // start at robot_j0 in Robot.setup order; every block contributes {pivot, gear} at island_j[k], +1
     int32_t robot_j0, n_islands, eye_body[2];
-    int32_t n_lverts, n_items;    // draw-list vertices that belong to line loops (they carry segment length + arclength in the rasteriser);
-                                  // classification items of the draw list: one per polygon edge / line segment / n-gon
+    int32_t n_lverts, pad_;       // draw-list vertices that belong to line loops (they carry segment length + arclength in the rasteriser)
 };
 
 // indices into the consts block

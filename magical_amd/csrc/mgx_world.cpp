@@ -608,8 +608,6 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
     h.n_verts = nverts; h.n_pverts = npv;
     h.n_lverts = 0;
     if (!strip_prims) for (auto &p : prims) if (p.kind == PR_LINELOOP) h.n_lverts += (int)p.verts.size();
-    h.n_items = 0;
-    if (!strip_prims) for (auto &p : prims) h.n_items += p.kind == PR_NGON ? 1 : (int)p.verts.size();
     h.n_state = (int)state_map.size();
     h.n_state_p = n_state_p;
     h.n_jacc = n_jacc;
