@@ -488,13 +488,6 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     if (L == 0 && !e->env_worlds) {
         L = 16;
         while (L < 64 && step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES / 2) L *= 2;
-        // bigger batches of the smallest worlds (robot + one block / one region: few overlapping pairs, so the extra lanes of
-        // a 16-group mostly idle through the serial parts of the solve) run eight lanes per env: fewer, fuller wavefronts.
-        // Measured, MoveToCorner k_step at 16 -> 8 lanes: 6144 envs 0.44 -> 0.36 ms, 8192 0.51 -> 0.49, 16384 0.80 -> 0.73,
-        // 65536 2.60 -> 2.32 (4096 envs: 0.34 -> 0.36, one wavefront per SIMD either way); MoveToRegion 16384: 0.65 -> 0.56;
-        // but FixColour (72 KB of LDS at eight envs per workgroup) 0.96 -> 1.19 ms and larger worlds lose more
-        // (only where every block island still has a lane of its own, i.e. the same register-resident joint code runs)
-        if (L == 16 && e->n_envs >= 6144 && step_lds_bytes(e, 8) <= (size_t)60 * 1024 && e->h.n_islands <= 7) L = 8;
         // the crowded worlds (ClusterColour / ClusterShape: 305 candidate pairs, 27 shapes) whose 16-lane working sets cannot all be
         // resident anyway (54 KB: three workgroups per CU) take 32 lanes per env: the broadphase and narrowphase, a third of their
         // step, run twice as wide.  Measured at 4096 envs: ClusterColour k_step 0.88 -> 0.77 ms, env-step 1.80 -> 1.66 ms; the
@@ -503,11 +496,13 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     } else if (L == 0) {
         L = 64;      // per-env templates: one env per wavefront, so that its template copy in LDS is shared by all lanes
     }
-    if (L != 4 && L != 8 && L != 16 && L != 32 && L != 64) return fail(MGX_ERR_ARG, "lanes_per_env must be 0, 4, 8, 16, 32 or 64");
+    // (a group is one or more whole DPP rows: the solver keeps robot joint j on lane j of every row, mgx_sim.h)
+    if (L != 16 && L != 32 && L != 64) return fail(MGX_ERR_ARG, "lanes_per_env must be 0, 16, 32 or 64");
+    if (e->h.n_islands > 15) return fail(MGX_ERR_CAPACITY, "more than 15 blocks: every block's joints need a lane of the group's first row");
     if (step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "world working set does not fit LDS at this lanes_per_env");
     if (getenv("MGX_DEBUG_LAUNCH"))
-        fprintf(stderr, "mgx: lanes_per_env %d, k_step LDS bytes at 8 / 16 / 32 / 64 lanes: %zu / %zu / %zu / %zu\n", L,
-                step_lds_bytes(e, 8), step_lds_bytes(e, 16), step_lds_bytes(e, 32), step_lds_bytes(e, 64));
+        fprintf(stderr, "mgx: lanes_per_env %d, k_step LDS bytes at 16 / 32 / 64 lanes: %zu / %zu / %zu\n", L,
+                step_lds_bytes(e, 16), step_lds_bytes(e, 32), step_lds_bytes(e, 64));
     e->L = L; e->lds_step = step_lds_bytes(e, L);
     e->rdev.off_i = HDR_WORDS; e->rdev.lds_tmpl_words = even(raster_words); e->rdev.scratch_d = scratch_d; e->rdev.off_tiles = off_tiles;
     e->lds_raster = (size_t)(e->rdev.lds_tmpl_words + off_tiles + extra) * 4;
@@ -570,13 +565,11 @@ static int launch_step(mgx_engine *e, void *sp, void *sf, int32_t *si, const int
                        int count_step, hipStream_t st, const StepHandoff &ho = StepHandoff{}) {
     if (e->env_worlds && e->L != 64) return fail(MGX_ERR_ARG, "per-env worlds run one env per wavefront (lanes_per_env 64)");
     switch (e->L) {
-        case 4: return launch_step_L<R, P, 4>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho);
-        case 8: return launch_step_L<R, P, 8>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho);
         case 16: return launch_step_L<R, P, 16>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho);
         case 32: return launch_step_L<R, P, 32>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho);
         case 64: return launch_step_L<R, P, 64>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho);
     }
-    return fail(MGX_ERR_ARG, "lanes_per_env must be 4, 8, 16, 32 or 64");
+    return fail(MGX_ERR_ARG, "lanes_per_env must be 16, 32 or 64");
 }
 
 // k_score's constant tables: the block shapes of every shape type in fp64 (from variants of the engine's world in which every

@@ -34,6 +34,15 @@ template <typename R> MGX_HD R r_min(R a, R b) { return a < b ? a : b; }
 template <typename R> MGX_HD R r_max(R a, R b) { return a > b ? a : b; }
 template <typename R> MGX_HD R r_clamp(R f, R lo, R hi) { return r_min(r_max(f, lo), hi); }
 template <typename R> MGX_HD R r_clamp01(R f) { return r_max(R(0), r_min(f, R(1))); }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_NO_FAST_MINMAX)
+// One instruction each on the device (v_min_f32 / v_max_f32 / v_med3_f32) instead of compare + wait states + select: the same
+// values for every finite input (lo <= hi wherever r_clamp is called); a wavefront's time is its instruction count.
+// (fminf / fmaxf would add a canonicalising v_max x, x per operand that comes from memory; the median with an infinity does not)
+template <> MGX_HD float r_min<float>(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -__builtin_inff()); }
+template <> MGX_HD float r_max<float>(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+template <> MGX_HD float r_clamp<float>(float f, float lo, float hi) { return __builtin_amdgcn_fmed3f(f, lo, hi); }
+template <> MGX_HD float r_clamp01<float>(float f) { return __builtin_amdgcn_fmed3f(f, 0.0f, 1.0f); }
+#endif
 template <typename R> MGX_HD R r_inf();
 template <> MGX_HD float r_inf<float>() { return __builtin_inff(); }
 template <> MGX_HD double r_inf<double>() { return __builtin_inf(); }
@@ -67,6 +76,21 @@ template <typename R> MGX_HD void anchor_rot(R c, R s, R ax, R ay, R &rx, R &ry)
     rx = r_add_nc(r_mul_nc(c, ax), -r_mul_nc(s, ay));
     ry = r_add_nc(r_mul_nc(c, ay), r_mul_nc(s, ax));
 }
+
+// cpvclamp(v, lim): v scaled back to length lim when longer.  The fp32 device build is branch-free with v_rsq_f32 (1 ulp)
+// instead of a correctly rounded sqrt and division (37 instructions, and the solver runs it in every iteration for the
+// robot's pivot and every sliding block's); a scale of exactly 1 leaves an unclamped vector as it is.
+template <typename R> MGX_HD void clamp_len(R &x, R &y, R lim) {
+    R l2 = x * x + y * y;
+    if (l2 > lim * lim) { R sc = lim / (r_sqrt(l2) + r_tiny<R>()); x *= sc; y *= sc; }
+}
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_NO_FAST_MINMAX)
+template <> MGX_HD void clamp_len<float>(float &x, float &y, float lim) {
+    float l2 = x * x + y * y;
+    float sc = l2 > lim * lim ? lim * __builtin_amdgcn_rsqf(l2) : 1.0f;
+    x *= sc; y *= sc;
+}
+#endif
 
 // ---------------------------------------------------------------- env view
 // R: velocity / impulse / contact arithmetic type.  P: pose type (positions, angles, their
@@ -410,9 +434,132 @@ template <typename R, typename P> MGX_HD void ph_narrow(Env<R, P> &e, int lane, 
     }
 }
 
+// ---------------------------------------------------------------- solver context (registers) + joint preSteps
+// Joints only couple bodies inside an ISLAND: the robot's ten joints (Robot.setup, entities.py:238-354: pivot + gear to the
+// kinematic control body, two eye springs, {pin, limit, motor} per finger), and each block's {pivot, gear} to the static body
+// (entities.py:703-711).  Inside the joint half of a Gauss-Seidel iteration islands can therefore run on different lanes and
+// still apply, to every body, exactly the sequence of impulses Chipmunk's serial order applies.
+//
+// Everything the solver iterates on lives in registers, per lane of the env's group (rowlane = lane & 15; a group of 32 or
+// 64 lanes is two or four rows that all carry the robot):
+//  * "pg" columns: the lane's own {pivot, gear} pair to a body that impulses do not move -- rowlane 0: the robot's pair to
+//    the control body; lanes 1 .. n_islands of the first row: one block's pair each.  Same instructions for all of them.
+//  * the robot island, identical in every lane of the env: the velocities of robot / eyes / fingers, the eight joints 2..9 with
+//    just the constants their impulse formulas need (33 values; the generic per-joint record of the first design was 12 x 10),
+//    and their accumulated impulses, which stay in registers for the whole env-step.
+// A joint's preStep runs on its OWNER lane (rowlane j for robot joint j, so both fingers' pins are one instruction stream)
+// and the few values it produces are broadcast to the row once per substep (DPP row_newbcast); the 10 iterations then run
+// without any cross-lane or LDS traffic unless the env has contacts.
+constexpr int RI_JOINTS = 10;      // pivot gear spring spring {pin limit motor} x 2
+constexpr int ROW = 16;            // a DPP row
+
+template <typename R> struct SolveCtx {
+    // pg pair (own lane)
+    R pk0, pk1, pk2, pk3, pb0, pb1, pa0, pa1, plim;   // pivot: K^-1, bias, accumulated impulse, max impulse
+    R gim, gb, ga, gratio, glim;                       // gear: effective mass, bias, accumulated impulse, ratio, max impulse
+    R avx, avy, aw;                                    // velocity of the pair's first body (control body; 0 for the static body)
+    R mvx, mvy, mw, mminv, miinv;                      // the pair's second body: this lane's robot / block
+    int mbody, mj;                                     // its index / the pivot's joint index (-1: this lane has no pair)
+    // owner lane's preStep results for robot joint `rowlane`, broadcast in solve_begin
+    R o[6];
+    // robot island (uniform over the env's lanes)
+    R rvx, rvy, rw, ew[2], fvx[2], fvy[2], fw[2];
+    R r_minv, r_iinv, e_iinv[2], f_minv[2], f_iinv[2];
+    R s_im[2], s_coef[2];                              // eye springs: 1 / (i_a + i_b), damping coefficient
+    R pin[2][6], pin_lim[2];                           // finger pins: r1x r1y nx ny n_mass bias | max impulse
+    R lim_im[2], lim_b[2], lim_lo[2], lim_hi[2], lim_max[2];     // finger limits: effective mass, clamp range of the accumulated impulse
+    R mot_im[2], mot_rate[2], mot_lim[2];              // finger motors
+    R acc[8];                                          // springs' target_wrn (2) | per finger: pin, limit, motor impulses
+    int has_contacts;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    const SolveCtx *row;                               // host emulation: the 16 contexts of this lane's row
+#endif
+};
+
+// value of `field` in lane J of this lane's row
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int J> MGX_HD float row_bcast(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + J, 0xf, 0xf, false));
+}
+template <int J> MGX_HD double row_bcast(double x) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x150 + J, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x150 + J, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+#define RB(J, field) row_bcast<J>(c.field)
+#else
+#define RB(J, field) (c.row[J].field)
+#endif
+
+// the pair's pivot + gear preSteps (cpPivotJointPreStep / cpGearJointPreStep) on the lanes that own one; the preSteps of the
+// robot's joints 2..9 on their owner lanes.  Anchor separations and angle differences are formed in pose precision.
+template <typename R, typename P> MGX_HD void joints_prestep(Env<R, P> &e, SolveCtx<R> &c, int lane, int nl) {
+    (void)nl;
+    const int rowlane = lane & (ROW - 1);
+    if (c.mj >= 0) {
+        const int j = c.mj, a = T_I(joint_a, j), b = c.mbody;
+        const R *p = &T_R(joint_p, j * JOINT_PARAMS);
+        const P *pp = &T_P(p_joint, j * 7);
+        P q1x, q1y, q2x, q2y;
+        anchor_rot<P>(E_P(c, a), E_P(s, a), pp[0], pp[1], q1x, q1y);
+        anchor_rot<P>(E_P(c, b), E_P(s, b), pp[2], pp[3], q2x, q2y);
+        const R r1x = R(q1x), r1y = R(q1y), r2x = R(q2x), r2y = R(q2y);
+        const P ddx = r_add_nc<P>(E_P(px, b), q2x) - r_add_nc<P>(E_P(px, a), q1x);
+        const P ddy = r_add_nc<P>(E_P(py, b), q2y) - r_add_nc<P>(E_P(py, a), q1y);
+        const R ma = T_R(body_minv, a), ia = T_R(body_iinv, a), mb = c.mminv, ib = c.miinv;
+        const R msum = ma + mb;
+        const R k11 = msum + r1y * r1y * ia + r2y * r2y * ib;
+        const R k12 = -r1x * r1y * ia - r2x * r2y * ib;
+        const R k22 = msum + r1x * r1x * ia + r2x * r2x * ib;
+        const R det_inv = R(1) / (k11 * k22 - k12 * k12);
+        c.pk0 = k22 * det_inv; c.pk1 = -k12 * det_inv; c.pk2 = -k12 * det_inv; c.pk3 = k11 * det_inv;
+        R bx = -R(ddx) * p[7], by = -R(ddy) * p[7];
+        clamp_len(bx, by, p[8]);
+        c.pb0 = bx; c.pb1 = by;
+        const R *pg = &T_R(joint_p, (j + 1) * JOINT_PARAMS);
+        const P *ppg = &T_P(p_joint, (j + 1) * 7);
+        c.gb = r_clamp(-R(E_P(ang, b) * ppg[5] - E_P(ang, a) - ppg[4]) * pg[7], -pg[8], pg[8]);
+        c.avx = E_R(vx, a); c.avy = E_R(vy, a); c.aw = E_R(w, a);
+    }
+    const int j0 = e.h->robot_j0;
+    if (rowlane == 2 || rowlane == 3) {                       // cpDampedRotarySpring preStep: the torque it applies
+        const int jj = j0 + rowlane, a = T_I(joint_a, jj), b = T_I(joint_b, jj);
+        c.o[0] = R((E_P(ang, a) - E_P(ang, b)) - T_P(p_joint, jj * 7 + 4)) * T_R(joint_p, jj * JOINT_PARAMS + 5);
+    } else if (rowlane == 4 || rowlane == 7) {                // cpPinJointPreStep
+        const int jj = j0 + rowlane, a = T_I(joint_a, jj), b = T_I(joint_b, jj);
+        const R *p = &T_R(joint_p, jj * JOINT_PARAMS);
+        const P *pp = &T_P(p_joint, jj * 7);
+        P q1x, q1y, q2x, q2y;
+        anchor_rot<P>(E_P(c, a), E_P(s, a), pp[0], pp[1], q1x, q1y);
+        anchor_rot<P>(E_P(c, b), E_P(s, b), pp[2], pp[3], q2x, q2y);
+        const R r1x = R(q1x), r1y = R(q1y), r2x = R(q2x), r2y = R(q2y);
+        const P ddx = r_add_nc<P>(E_P(px, b), q2x) - r_add_nc<P>(E_P(px, a), q1x);
+        const P ddy = r_add_nc<P>(E_P(py, b), q2y) - r_add_nc<P>(E_P(py, a), q1y);
+        const P dist = r_sqrt<P>(ddx * ddx + ddy * ddy);
+        const P inv = dist != P(0) ? P(1) / dist : P(0);
+        const R nx = R(ddx * inv), ny = R(ddy * inv);
+        const R rcn1 = r1x * ny - r1y * nx, rcn2 = r2x * ny - r2y * nx;
+        const R ma = T_R(body_minv, a), ia = T_R(body_iinv, a), mb = T_R(body_minv, b), ib = T_R(body_iinv, b);
+        c.o[0] = r1x; c.o[1] = r1y; c.o[2] = nx; c.o[3] = ny;
+        c.o[4] = R(1) / (ma + ia * rcn1 * rcn1 + mb + ib * rcn2 * rcn2);
+        c.o[5] = r_clamp(-R(dist - pp[4]) * p[7], -p[8], p[8]);
+    } else if (rowlane == 5 || rowlane == 8) {                // cpRotaryLimitJointPreStep
+        const int jj = j0 + rowlane, a = T_I(joint_a, jj), b = T_I(joint_b, jj);
+        const R *p = &T_R(joint_p, jj * JOINT_PARAMS);
+        const P *pp = &T_P(p_joint, jj * 7);
+        const P dist = E_P(ang, b) - E_P(ang, a);
+        P pdist = P(0);
+        if (dist > pp[5]) pdist = pp[5] - dist; else if (dist < pp[4]) pdist = pp[4] - dist;
+        c.o[0] = r_clamp(-R(pdist) * p[7], -p[8], p[8]);
+    } else if (rowlane == 6 || rowlane == 9) {                // cpSimpleMotor: the rate Robot.update set (ph_control)
+        c.o[0] = E_R(jrate, j0 + rowlane);
+    }
+}
+
 // ---------------------------------------------------------------- phase: arbiters (cpArbiterUpdate + cpArbiterPreStep)
 // and joint preStep for every joint kind that does not touch velocities.
-template <typename R, typename P> MGX_HD void ph_arbiters_joints(Env<R, P> &e, int lane, int nl) {
+template <typename R, typename P> MGX_HD void ph_arbiters_joints(Env<R, P> &e, SolveCtx<R> &c, int lane, int nl) {
     int nov = E_I(misc, M_NOV), ncache = E_I(misc, M_NCACHE);
     int kcap = e.h->max_contacts, ccap = e.h->cache_slots;
     R dt = e.cst(C_DT), slop = e.cst(C_SLOP), brate = e.cst(C_CONTACT_BIAS_RATE);
@@ -466,162 +613,15 @@ template <typename R, typename P> MGX_HD void ph_arbiters_joints(Env<R, P> &e, i
         E_I(misc, M_NK) = k; E_I(misc, M_NARB) = r;
         if (dropped) E_I(misc, M_OVERFLOW) += dropped;
     }
-    // joint preStep (all kinds except the damped rotary spring, which applies its torque right away).
-    // Anchor separations and angle differences are formed in pose precision, then narrowed.
+    // joint preSteps: straight into the registers of the lanes that own the joints (SolveCtx, below).
     (void)dt;
-    for (int j = lane; j < e.h->n_joints; j += nl) {
-        int kind = T_I(joint_kind, j), a = T_I(joint_a, j), b = T_I(joint_b, j);
-        const R *p = &T_R(joint_p, j * JOINT_PARAMS);
-        const P *pp = &T_P(p_joint, j * 7);
-        if (kind == J_PIVOT || kind == J_PIN) {
-            P q1x, q1y, q2x, q2y;
-            anchor_rot<P>(E_P(c, a), E_P(s, a), pp[0], pp[1], q1x, q1y);
-            anchor_rot<P>(E_P(c, b), E_P(s, b), pp[2], pp[3], q2x, q2y);
-            R r1x = R(q1x), r1y = R(q1y), r2x = R(q2x), r2y = R(q2y);
-            E_R(jr1x, j) = r1x; E_R(jr1y, j) = r1y; E_R(jr2x, j) = r2x; E_R(jr2y, j) = r2y;
-            P ddx = r_add_nc<P>(E_P(px, b), q2x) - r_add_nc<P>(E_P(px, a), q1x);
-            P ddy = r_add_nc<P>(E_P(py, b), q2y) - r_add_nc<P>(E_P(py, a), q1y);
-            R ma = T_R(body_minv, a), ia = T_R(body_iinv, a), mb = T_R(body_minv, b), ib = T_R(body_iinv, b);
-            if (kind == J_PIVOT) {
-                R dx = R(ddx), dy = R(ddy);
-                R msum = ma + mb;
-                R k11 = msum + r1y * r1y * ia + r2y * r2y * ib;
-                R k12 = -r1x * r1y * ia - r2x * r2y * ib;
-                R k22 = msum + r1x * r1x * ia + r2x * r2x * ib;
-                R det_inv = R(1) / (k11 * k22 - k12 * k12);
-                E_R(jk0, j) = k22 * det_inv; E_R(jk1, j) = -k12 * det_inv; E_R(jk2, j) = -k12 * det_inv; E_R(jk3, j) = k11 * det_inv;
-                R bx = -dx * p[7], by = -dy * p[7], mb_ = p[8];
-                R bl2 = bx * bx + by * by;
-                if (bl2 > mb_ * mb_) { R sc = mb_ / (r_sqrt(bl2) + r_tiny<R>()); bx *= sc; by *= sc; }
-                E_R(jb0, j) = bx; E_R(jb1, j) = by;
-            } else {
-                P dist = r_sqrt<P>(ddx * ddx + ddy * ddy);
-                P inv = dist != P(0) ? P(1) / dist : P(0);
-                R nx = R(ddx * inv), ny = R(ddy * inv);
-                R rcn1 = r1x * ny - r1y * nx, rcn2 = r2x * ny - r2y * nx;
-                E_R(jk0, j) = nx; E_R(jk1, j) = ny;
-                E_R(jk2, j) = R(1) / (ma + ia * rcn1 * rcn1 + mb + ib * rcn2 * rcn2);
-                E_R(jb0, j) = r_clamp(-R(dist - pp[4]) * p[7], -p[8], p[8]);
-            }
-        } else if (kind == J_GEAR) {
-            E_R(jb0, j) = r_clamp(-R(E_P(ang, b) * pp[5] - E_P(ang, a) - pp[4]) * p[7], -p[8], p[8]);
-        } else if (kind == J_LIMIT) {
-            P dist = E_P(ang, b) - E_P(ang, a), pdist = P(0);
-            if (dist > pp[5]) pdist = pp[5] - dist; else if (dist < pp[4]) pdist = pp[4] - dist;
-            R bias = r_clamp(-R(pdist) * p[7], -p[8], p[8]);
-            E_R(jb0, j) = bias;
-            if (bias == R(0)) E_R(ja0, j) = R(0);
-        }
-    }
+    joints_prestep(e, c, lane, nl);
 }
 
 // ---------------------------------------------------------------- velocity helpers for the solver
 template <typename R> struct Vel { R vx, vy, w; };
 #define LOADV(b) Vel<R>{E_R(vx, b), E_R(vy, b), E_R(w, b)}
 #define STOREV(b, v) do { E_R(vx, b) = (v).vx; E_R(vy, b) = (v).vy; E_R(w, b) = (v).w; } while (0)
-
-template <typename R, typename P> MGX_HD void joint_apply_cached(Env<R, P> &e, int j) {
-    int kind = T_I(joint_kind, j), a = T_I(joint_a, j), b = T_I(joint_b, j);
-    const R *p = &T_R(joint_p, j * JOINT_PARAMS);
-    R ma = T_R(body_minv, a), ia = T_R(body_iinv, a), mb = T_R(body_minv, b), ib = T_R(body_iinv, b);
-    if (kind == J_PIVOT || kind == J_PIN) {
-        R jx, jy;
-        if (kind == J_PIVOT) { jx = E_R(ja0, j); jy = E_R(ja1, j); }
-        else { jx = E_R(jk0, j) * E_R(ja0, j); jy = E_R(jk1, j) * E_R(ja0, j); }
-        R r1x = E_R(jr1x, j), r1y = E_R(jr1y, j), r2x = E_R(jr2x, j), r2y = E_R(jr2y, j);
-        E_R(vx, a) -= jx * ma; E_R(vy, a) -= jy * ma; E_R(w, a) -= ia * (r1x * jy - r1y * jx);
-        E_R(vx, b) += jx * mb; E_R(vy, b) += jy * mb; E_R(w, b) += ib * (r2x * jy - r2y * jx);
-    } else if (kind == J_GEAR) {
-        R jj = E_R(ja0, j);
-        E_R(w, a) -= jj * ia * (R(1) / p[5]); E_R(w, b) += jj * ib;
-    } else if (kind == J_LIMIT || kind == J_MOTOR) {
-        R jj = E_R(ja0, j);
-        E_R(w, a) -= jj * ia; E_R(w, b) += jj * ib;
-    }
-}
-
-template <typename R, typename P> MGX_HD void joint_apply_impulse(Env<R, P> &e, int j) {
-    int kind = T_I(joint_kind, j), a = T_I(joint_a, j), b = T_I(joint_b, j);
-    const R *p = &T_R(joint_p, j * JOINT_PARAMS);
-    R ia = T_R(body_iinv, a), ib = T_R(body_iinv, b);
-    switch (kind) {
-    case J_PIVOT: {
-        R ma = T_R(body_minv, a), mb = T_R(body_minv, b);
-        R r1x = E_R(jr1x, j), r1y = E_R(jr1y, j), r2x = E_R(jr2x, j), r2y = E_R(jr2y, j);
-        Vel<R> va = LOADV(a), vb = LOADV(b);
-        R vrx = (vb.vx - r2y * vb.w) - (va.vx - r1y * va.w), vry = (vb.vy + r2x * vb.w) - (va.vy + r1x * va.w);
-        R dx = E_R(jb0, j) - vrx, dy = E_R(jb1, j) - vry;
-        R jx = dx * E_R(jk0, j) + dy * E_R(jk1, j), jy = dx * E_R(jk2, j) + dy * E_R(jk3, j);
-        R ox = E_R(ja0, j), oy = E_R(ja1, j);
-        R nxv = ox + jx, nyv = oy + jy, lim = E_R(jlim, j);
-        R l2 = nxv * nxv + nyv * nyv;
-        if (l2 > lim * lim) { R sc = lim / (r_sqrt(l2) + r_tiny<R>()); nxv *= sc; nyv *= sc; }
-        E_R(ja0, j) = nxv; E_R(ja1, j) = nyv;
-        jx = nxv - ox; jy = nyv - oy;
-        va.vx -= jx * ma; va.vy -= jy * ma; va.w -= ia * (r1x * jy - r1y * jx);
-        vb.vx += jx * mb; vb.vy += jy * mb; vb.w += ib * (r2x * jy - r2y * jx);
-        STOREV(a, va); STOREV(b, vb);
-    } break;
-    case J_GEAR: {
-        R ratio = p[5], ratio_inv = R(1) / ratio;
-        R wa = E_R(w, a), wb = E_R(w, b);
-        R wr = wb * ratio - wa;
-        R jmax = E_R(jlim, j);
-        R jj = (E_R(jb0, j) - wr) * p[0];
-        R jold = E_R(ja0, j);
-        R jn = r_clamp(jold + jj, -jmax, jmax);
-        E_R(ja0, j) = jn; jj = jn - jold;
-        E_R(w, a) = wa - jj * ia * ratio_inv; E_R(w, b) = wb + jj * ib;
-    } break;
-    case J_SPRING: {
-        R wa = E_R(w, a), wb = E_R(w, b);
-        R wrn = wa - wb;
-        R w_damp = (E_R(jrate, j) - wrn) * p[6];
-        E_R(jrate, j) = wrn + w_damp;                       // target_wrn
-        R j_damp = w_damp * p[0];
-        E_R(w, a) = wa + j_damp * ia; E_R(w, b) = wb - j_damp * ib;
-    } break;
-    case J_PIN: {
-        R ma = T_R(body_minv, a), mb = T_R(body_minv, b);
-        R r1x = E_R(jr1x, j), r1y = E_R(jr1y, j), r2x = E_R(jr2x, j), r2y = E_R(jr2y, j);
-        R nx = E_R(jk0, j), ny = E_R(jk1, j);
-        Vel<R> va = LOADV(a), vb = LOADV(b);
-        R vrx = (vb.vx - r2y * vb.w) - (va.vx - r1y * va.w), vry = (vb.vy + r2x * vb.w) - (va.vy + r1x * va.w);
-        R vrn = vrx * nx + vry * ny;
-        R jmax = E_R(jlim, j);
-        R jn = (E_R(jb0, j) - vrn) * E_R(jk2, j);
-        R jold = E_R(ja0, j);
-        R jnew = r_clamp(jold + jn, -jmax, jmax);
-        E_R(ja0, j) = jnew; jn = jnew - jold;
-        R jx = nx * jn, jy = ny * jn;
-        va.vx -= jx * ma; va.vy -= jy * ma; va.w -= ia * (r1x * jy - r1y * jx);
-        vb.vx += jx * mb; vb.vy += jy * mb; vb.w += ib * (r2x * jy - r2y * jx);
-        STOREV(a, va); STOREV(b, vb);
-    } break;
-    case J_LIMIT: {
-        R bias = E_R(jb0, j);
-        if (bias == R(0)) return;
-        R wa = E_R(w, a), wb = E_R(w, b);
-        R wr = wb - wa;
-        R jmax = E_R(jlim, j);
-        R jj = -(bias + wr) * p[0];
-        R jold = E_R(ja0, j);
-        R jn = bias < R(0) ? r_clamp(jold + jj, R(0), jmax) : r_clamp(jold + jj, -jmax, R(0));
-        E_R(ja0, j) = jn; jj = jn - jold;
-        E_R(w, a) = wa - jj * ia; E_R(w, b) = wb + jj * ib;
-    } break;
-    case J_MOTOR: {
-        R wa = E_R(w, a), wb = E_R(w, b);
-        R wr = wb - wa + E_R(jrate, j);
-        R jmax = E_R(jlim, j);
-        R jj = -wr * p[0];
-        R jold = E_R(ja0, j);
-        R jn = r_clamp(jold + jj, -jmax, jmax);
-        E_R(ja0, j) = jn; jj = jn - jold;
-        E_R(w, a) = wa - jj * ia; E_R(w, b) = wb + jj * ib;
-    } break;
-    }
-}
 
 // cpArbiterApplyImpulse for one contact point, split so that the constants of contact k + 1 can be fetched from LDS
 // while contact k is being computed (they never alias the velocities contact k writes): ContactK = everything that does
@@ -682,167 +682,79 @@ template <typename R, typename P> MGX_HD void contact_apply_impulse(Env<R, P> &e
 }
 
 // ---------------------------------------------------------------- solve
-// Chipmunk's order per substep: (arbiter preStep, joint preStep incl. the spring torque) -> cached arbiter
-// impulses -> cached joint impulses -> 10 x { all arbiters in pair order ; all joints in insertion order }.
-// Joints only couple bodies inside an ISLAND (the robot's 10 joints; each block's {pivot, gear} to the static
-// body), so inside the joint half of an iteration islands can run on different lanes and still apply, to every
-// body, exactly the sequence of impulses the serial order applies: the result is bit-identical.  The robot
-// island is solved entirely in registers (6 bodies x 3 velocities + 10 unrolled joint rows); contacts stay
-// sequential on lane 0 against the LDS copy of the velocities, with a store / barrier / load hand-over around
-// them only when the env has contacts at all.
+// Chipmunk's order per substep: (arbiter preStep, joint preStep incl. the spring torque) -> cached arbiter impulses ->
+// cached joint impulses -> 10 x { all arbiters in pair order ; all joints in insertion order }.  Contacts (which couple
+// islands) stay sequential on lane 0 against the LDS copy of the velocities, with a store / load hand-over around them only
+// when the env has contacts at all.
 
-constexpr int RI_JOINTS = 10, RI_BODIES = 6;   // Robot.setup (entities.py:238-354): pivot gear spring spring {pin limit motor} x2
-// kinds and body slots (0 control, 1 robot, 2 eye L, 3 eye R, 4 finger L, 5 finger R) of the robot's joints
-#define RI_KIND(j) ((j) == 0 ? J_PIVOT : (j) == 1 ? J_GEAR : (j) <= 3 ? J_SPRING : ((j) - 4) % 3 == 0 ? J_PIN : ((j) - 4) % 3 == 1 ? J_LIMIT : J_MOTOR)
-#define RI_SA(j) ((j) <= 1 ? 0 : 1)
-#define RI_SB(j) ((j) <= 1 ? 1 : (j) == 2 ? 2 : (j) == 3 ? 3 : (j) <= 6 ? 4 : 5)
-
-template <typename R> struct SolveCtx {
-    // robot island (only meaningful on lane 0 of the env's group)
-    R vx[RI_BODIES], vy[RI_BODIES], w[RI_BODIES], minv[RI_BODIES], iinv[RI_BODIES];
-    R f[RI_JOINTS][12], lim[RI_JOINTS];
-    // one block island per lane (lanes 1..): pivot k (2x2), accumulators, limits, gear effective mass
-    R bvx, bvy, bw, bminv, biinv, bk[4], bacc[3], blim[2], bgear, bbias[3];
-    int bbody, bj;            // body / first joint of the register-resident block (-1: none)
-    int has_contacts;
-};
-
-// ZA / ZB: the joint's anchor on body a / b is the body origin (r = 0, so the r x j terms vanish); KA: body a is the
-// kinematic control body (inverse mass and inertia 0: impulses leave it unchanged).  What is skipped is x - 0 * y and
-// x + 0 * y on finite values, i.e. x: Robot.setup's pivot / gear to the control body and the finger pins (entities.py:
-// 255-263,334-341) have exactly these shapes.
-template <typename R, bool ZA = false, bool ZB = false, bool KA = false>
-MGX_HD void reg_apply_joint(int kind, R *f, R lim, R ma, R ia, R mb, R ib,
-                            R &avx, R &avy, R &aw, R &bvx, R &bvy, R &bw) {
-    switch (kind) {
-    case J_PIVOT: {   // f: r1x r1y r2x r2y k0 k1 k2 k3 bias0 bias1 acc0 acc1
-        R vbx_ = ZB ? bvx : bvx - f[3] * bw, vby_ = ZB ? bvy : bvy + f[2] * bw;
-        R vax_ = ZA ? avx : avx - f[1] * aw, vay_ = ZA ? avy : avy + f[0] * aw;
-        R vrx = vbx_ - vax_, vry = vby_ - vay_;
-        R dx = f[8] - vrx, dy = f[9] - vry;
-        R jx = dx * f[4] + dy * f[5], jy = dx * f[6] + dy * f[7];
-        R ox = f[10], oy = f[11];
-        R nxv = ox + jx, nyv = oy + jy;
-        R l2 = nxv * nxv + nyv * nyv;
-        if (l2 > lim * lim) { R sc = lim / (r_sqrt(l2) + r_tiny<R>()); nxv *= sc; nyv *= sc; }
-        f[10] = nxv; f[11] = nyv;
-        jx = nxv - ox; jy = nyv - oy;
-        if (!KA) { avx -= jx * ma; avy -= jy * ma; if (!ZA) aw -= ia * (f[0] * jy - f[1] * jx); }
-        bvx += jx * mb; bvy += jy * mb; if (!ZB) bw += ib * (f[2] * jy - f[3] * jx);
-    } break;
-    case J_GEAR: {    // f: imass bias acc ratio 1/ratio
-        R ratio = f[3], ratio_inv = f[4];
-        R wr = bw * ratio - aw;
-        R jj = (f[1] - wr) * f[0];
-        R jold = f[2];
-        R jn = r_clamp(jold + jj, -lim, lim);
-        f[2] = jn; jj = jn - jold;
-        if (!KA) aw = aw - jj * ia * ratio_inv;
-        bw = bw + jj * ib;
-    } break;
-    case J_SPRING: {  // f: imass w_coef target_wrn
-        R wrn = aw - bw;
-        R w_damp = (f[2] - wrn) * f[1];
-        f[2] = wrn + w_damp;
-        R j_damp = w_damp * f[0];
-        aw = aw + j_damp * ia; bw = bw - j_damp * ib;
-    } break;
-    case J_PIN: {     // f: r1x r1y r2x r2y nx ny nmass bias acc
-        R vrx = (ZB ? bvx : bvx - f[3] * bw) - (avx - f[1] * aw), vry = (ZB ? bvy : bvy + f[2] * bw) - (avy + f[0] * aw);
-        R vrn = vrx * f[4] + vry * f[5];
-        R jn = (f[7] - vrn) * f[6];
-        R jold = f[8];
-        R jnew = r_clamp(jold + jn, -lim, lim);
-        f[8] = jnew; jn = jnew - jold;
-        R jx = f[4] * jn, jy = f[5] * jn;
-        avx -= jx * ma; avy -= jy * ma; aw -= ia * (f[0] * jy - f[1] * jx);
-        bvx += jx * mb; bvy += jy * mb; if (!ZB) bw += ib * (f[2] * jy - f[3] * jx);
-    } break;
-    case J_LIMIT: {   // f: imass bias acc
-        R bias = f[1];
-        if (bias == R(0)) return;
-        R wr = bw - aw;
-        R jj = -(bias + wr) * f[0];
-        R jold = f[2];
-        R jn = bias < R(0) ? r_clamp(jold + jj, R(0), lim) : r_clamp(jold + jj, -lim, R(0));
-        f[2] = jn; jj = jn - jold;
-        aw = aw - jj * ia; bw = bw + jj * ib;
-    } break;
-    default: {        // J_MOTOR, f: imass rate acc
-        R wr = bw - aw + f[1];
-        R jj = -wr * f[0];
-        R jold = f[2];
-        R jn = r_clamp(jold + jj, -lim, lim);
-        f[2] = jn; jj = jn - jold;
-        aw = aw - jj * ia; bw = bw + jj * ib;
-    } break;
-    }
-}
-template <typename R> MGX_HD void reg_apply_cached(int kind, const R *f, R ma, R ia, R mb, R ib,
-                                                   R &avx, R &avy, R &aw, R &bvx, R &bvy, R &bw) {
-    if (kind == J_PIVOT || kind == J_PIN) {
-        R jx, jy;
-        if (kind == J_PIVOT) { jx = f[10]; jy = f[11]; } else { jx = f[4] * f[8]; jy = f[5] * f[8]; }
-        avx -= jx * ma; avy -= jy * ma; aw -= ia * (f[0] * jy - f[1] * jx);
-        bvx += jx * mb; bvy += jy * mb; bw += ib * (f[2] * jy - f[3] * jx);
-    } else if (kind == J_GEAR) {
-        R jj = f[2];
-        aw -= jj * ia * (R(1) / f[3]); bw += jj * ib;
-    } else if (kind == J_LIMIT || kind == J_MOTOR) {
-        R jj = f[2];
-        aw -= jj * ia; bw += jj * ib;
-    }
-}
-
-template <typename R, typename P> MGX_HD int ri_body(const Env<R, P> &e, int slot) {
+template <typename R, typename P> MGX_HD int ri_body(const Env<R, P> &e, int slot) {   // 1 robot, 2 / 3 eyes, 4 / 5 fingers
     const TmplHeader &h = *e.h;
     return slot == 0 ? h.control_body : slot == 1 ? h.robot_body : slot == 2 ? h.eye_body[0] : slot == 3 ? h.eye_body[1]
          : slot == 4 ? h.finger_body[0] : h.finger_body[1];
 }
+// the robot island's velocities, LDS <-> the (uniform) registers of every lane
 template <typename R, typename P> MGX_HD void ri_load_vel(const Env<R, P> &e, SolveCtx<R> &c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int s = 0; s < RI_BODIES; s++) { int b = ri_body(e, s); c.vx[s] = E_R(vx, b); c.vy[s] = E_R(vy, b); c.w[s] = E_R(w, b); }
+    const TmplHeader &h = *e.h;
+    c.rvx = E_R(vx, h.robot_body); c.rvy = E_R(vy, h.robot_body); c.rw = E_R(w, h.robot_body);
+    c.ew[0] = E_R(w, h.eye_body[0]); c.ew[1] = E_R(w, h.eye_body[1]);
+    MGX_UNROLL for (int f = 0; f < 2; f++) { const int b = h.finger_body[f]; c.fvx[f] = E_R(vx, b); c.fvy[f] = E_R(vy, b); c.fw[f] = E_R(w, b); }
 }
 template <typename R, typename P> MGX_HD void ri_store_vel(Env<R, P> &e, const SolveCtx<R> &c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int s = 1; s < RI_BODIES; s++) { int b = ri_body(e, s); E_R(vx, b) = c.vx[s]; E_R(vy, b) = c.vy[s]; E_R(w, b) = c.w[s]; }
+    const TmplHeader &h = *e.h;
+    E_R(vx, h.robot_body) = c.rvx; E_R(vy, h.robot_body) = c.rvy; E_R(w, h.robot_body) = c.rw;
+    E_R(w, h.eye_body[0]) = c.ew[0]; E_R(w, h.eye_body[1]) = c.ew[1];
+    MGX_UNROLL for (int f = 0; f < 2; f++) { const int b = h.finger_body[f]; E_R(vx, b) = c.fvx[f]; E_R(vy, b) = c.fvy[f]; E_R(w, b) = c.fw[f]; }
 }
-// which block (island) does this lane keep in registers?  lane 1 + k <-> island k when every island gets a lane
-template <typename R, typename P> MGX_HD int lane_island(const Env<R, P> &e, int lane, int nl) {
-    return (e.h->n_islands <= nl - 1 && lane >= 1 && lane - 1 < e.h->n_islands) ? lane - 1 : -1;
-}
-template <typename R, typename P> MGX_HD void bi_load_vel(const Env<R, P> &e, SolveCtx<R> &c) {
-    if (c.bbody >= 0) { c.bvx = E_R(vx, c.bbody); c.bvy = E_R(vy, c.bbody); c.bw = E_R(w, c.bbody); }
-}
-template <typename R, typename P> MGX_HD void bi_store_vel(Env<R, P> &e, const SolveCtx<R> &c) {
-    if (c.bbody >= 0) { E_R(vx, c.bbody) = c.bvx; E_R(vy, c.bbody) = c.bvy; E_R(w, c.bbody) = c.bw; }
-}
-template <typename R> MGX_HD void bi_iterate(SolveCtx<R> &c) {
-    if (c.bbody < 0) return;
-    // PivotJoint(static, block): a = static (m_inv = i_inv = 0, v = 0), r1 = r2 = 0
-    {
-        R dx = c.bbias[0] - c.bvx, dy = c.bbias[1] - c.bvy;
-        R jx = dx * c.bk[0] + dy * c.bk[1], jy = dx * c.bk[2] + dy * c.bk[3];
-        R ox = c.bacc[0], oy = c.bacc[1];
-        R nxv = ox + jx, nyv = oy + jy, lim = c.blim[0];
-        R l2 = nxv * nxv + nyv * nyv;
-        if (l2 > lim * lim) { R sc = lim / (r_sqrt(l2) + r_tiny<R>()); nxv *= sc; nyv *= sc; }
-        c.bacc[0] = nxv; c.bacc[1] = nyv;
-        jx = nxv - ox; jy = nyv - oy;
-        c.bvx += jx * c.bminv; c.bvy += jy * c.bminv; c.bw += c.biinv * (R(0) * jy - R(0) * jx);
+// does this lane keep a block's pair?  (lane 1 + k <-> island k; rowlane 0 keeps the robot's)
+template <typename R> MGX_HD bool is_block_lane(const SolveCtx<R> &c, int lane) { return c.mj >= 0 && (lane & (ROW - 1)) != 0; }
+
+// Once per env-step, after ph_load_state: who owns what, the constants that do not change during the env-step, and the
+// accumulated impulses (they stay in registers until solve_ctx_flush).
+template <typename R, typename P> MGX_HD void solve_ctx_init(Env<R, P> &e, SolveCtx<R> &c, int lane, int nl) {
+    (void)nl;
+    const TmplHeader &h = *e.h;
+    const int rowlane = lane & (ROW - 1), j0 = h.robot_j0;
+    c.mj = -1; c.mbody = -1;
+    if (rowlane == 0) { c.mj = j0; c.mbody = h.robot_body; }
+    else if (lane < ROW && lane - 1 < h.n_islands) { c.mj = T_I(island_j, lane - 1); c.mbody = T_I(joint_b, c.mj); }
+    c.pk0 = c.pk1 = c.pk2 = c.pk3 = c.pb0 = c.pb1 = c.pa0 = c.pa1 = c.plim = R(0);
+    c.gim = c.gb = c.ga = c.gratio = c.glim = R(0);
+    c.avx = c.avy = c.aw = c.mvx = c.mvy = c.mw = c.mminv = c.miinv = R(0);
+    if (c.mj >= 0) {
+        const int j = c.mj;
+        c.pa0 = E_R(ja0, j); c.pa1 = E_R(ja1, j); c.ga = E_R(ja0, j + 1);
+        c.plim = E_R(jlim, j); c.glim = E_R(jlim, j + 1);
+        c.gim = T_R(joint_p, (j + 1) * JOINT_PARAMS); c.gratio = T_R(joint_p, (j + 1) * JOINT_PARAMS + 5);
+        c.mminv = T_R(body_minv, c.mbody); c.miinv = T_R(body_iinv, c.mbody);
     }
-    // GearJoint(static, block, 0, 1)
-    {
-        R wr = c.bw * R(1) - R(0);
-        R jj = (c.bbias[2] - wr) * c.bgear;
-        R jold = c.bacc[2];
-        R jn = r_clamp(jold + jj, -c.blim[1], c.blim[1]);
-        c.bacc[2] = jn; jj = jn - jold;
-        c.bw = c.bw + jj * c.biinv;
+    c.r_minv = T_R(body_minv, h.robot_body); c.r_iinv = T_R(body_iinv, h.robot_body);
+    MGX_UNROLL for (int k = 0; k < 2; k++) {
+        c.e_iinv[k] = T_R(body_iinv, h.eye_body[k]);
+        c.f_minv[k] = T_R(body_minv, h.finger_body[k]); c.f_iinv[k] = T_R(body_iinv, h.finger_body[k]);
+        c.s_im[k] = T_R(joint_p, (j0 + 2 + k) * JOINT_PARAMS); c.s_coef[k] = T_R(joint_p, (j0 + 2 + k) * JOINT_PARAMS + 6);
+        const int jp = j0 + 4 + 3 * k;            // this finger's pin, limit, motor
+        c.pin_lim[k] = E_R(jlim, jp); c.lim_max[k] = E_R(jlim, jp + 1); c.mot_lim[k] = E_R(jlim, jp + 2);
+        c.lim_im[k] = T_R(joint_p, (jp + 1) * JOINT_PARAMS); c.mot_im[k] = T_R(joint_p, (jp + 2) * JOINT_PARAMS);
+        c.acc[k] = R(0);
+        c.acc[2 + 3 * k] = E_R(ja0, jp); c.acc[3 + 3 * k] = E_R(ja0, jp + 1); c.acc[4 + 3 * k] = E_R(ja0, jp + 2);
+        c.lim_lo[k] = c.lim_hi[k] = c.mot_rate[k] = R(0);
+        MGX_UNROLL for (int i = 0; i < 6; i++) c.pin[k][i] = R(0);
+    }
+    MGX_UNROLL for (int i = 0; i < 6; i++) c.o[i] = R(0);
+    c.rvx = c.rvy = c.rw = R(0);
+    MGX_UNROLL for (int k = 0; k < 2; k++) c.ew[k] = c.fvx[k] = c.fvy[k] = c.fw[k] = R(0);
+    c.has_contacts = 0;
+}
+// ... and back into the working set, before ph_store_state
+template <typename R, typename P> MGX_HD void solve_ctx_flush(Env<R, P> &e, const SolveCtx<R> &c, int lane, int nl) {
+    (void)nl;
+    if (c.mj >= 0 && lane < ROW) { E_R(ja0, c.mj) = c.pa0; E_R(ja1, c.mj) = c.pa1; E_R(ja0, c.mj + 1) = c.ga; }
+    if (lane == 0) {
+        const int j0 = e.h->robot_j0;
+        MGX_UNROLL for (int k = 0; k < 2; k++) {
+            const int jp = j0 + 4 + 3 * k;
+            E_R(ja0, jp) = c.acc[2 + 3 * k]; E_R(ja0, jp + 1) = c.acc[3 + 3 * k]; E_R(ja0, jp + 2) = c.acc[4 + 3 * k];
+        }
     }
 }
 
@@ -860,12 +772,12 @@ template <typename R, typename P> MGX_HD void contacts_warm_start(Env<R, P> &e) 
     }
 }
 
-// solve step A (after the preStep phase): lane 0 ages the contact cache, loads the robot island into registers and
-// applies the spring torques (cpDampedRotarySpring preStep, in joint order); block lanes load their island
+// solve step A (after the preStep phase): lane 0 ages the contact cache; every lane picks up the owners' preStep results
+// and the island's velocities, and the springs apply their torque (cpDampedRotarySpring preStep, in joint order)
 template <typename R, typename P> MGX_HD void solve_begin(Env<R, P> &e, SolveCtx<R> &c, int lane, int nl) {
+    (void)nl;
     const TmplHeader &h = *e.h;
     c.has_contacts = E_I(misc, M_NK) > 0;
-    c.bbody = -1; c.bj = -1;
     if (lane == 0) {
         int narb = E_I(misc, M_NARB), ncache = E_I(misc, M_NCACHE);
         // untouched cached arbiters age; they survive collision_persistence = 3 steps (cpSpaceArbiterSetFilter)
@@ -882,90 +794,72 @@ template <typename R, typename P> MGX_HD void solve_begin(Env<R, P> &e, SolveCtx
             }
         }
         E_I(misc, M_NNCACHE) = n;
-        ri_load_vel(e, c);
-        int j0 = h.robot_j0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int s = 0; s < RI_BODIES; s++) { int b = ri_body(e, s); c.minv[s] = T_R(body_minv, b); c.iinv[s] = T_R(body_iinv, b); }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int j = 0; j < RI_JOINTS; j++) {
-            const int kind = RI_KIND(j), jj = j0 + j;
-            const R *p = &T_R(joint_p, jj * JOINT_PARAMS);
-            R *f = c.f[j];
-            c.lim[j] = E_R(jlim, jj);
-            if (kind == J_PIVOT || kind == J_PIN) {
-                f[0] = E_R(jr1x, jj); f[1] = E_R(jr1y, jj); f[2] = E_R(jr2x, jj); f[3] = E_R(jr2y, jj);
-                if (kind == J_PIVOT) {
-                    f[4] = E_R(jk0, jj); f[5] = E_R(jk1, jj); f[6] = E_R(jk2, jj); f[7] = E_R(jk3, jj);
-                    f[8] = E_R(jb0, jj); f[9] = E_R(jb1, jj); f[10] = E_R(ja0, jj); f[11] = E_R(ja1, jj);
-                } else {
-                    f[4] = E_R(jk0, jj); f[5] = E_R(jk1, jj); f[6] = E_R(jk2, jj); f[7] = E_R(jb0, jj); f[8] = E_R(ja0, jj);
-                }
-            } else if (kind == J_GEAR) {
-                f[0] = p[0]; f[1] = E_R(jb0, jj); f[2] = E_R(ja0, jj); f[3] = p[5]; f[4] = R(1) / p[5];      // 1 / ratio once per substep, not per iteration
-            } else if (kind == J_SPRING) {
-                f[0] = p[0]; f[1] = p[6]; f[2] = R(0);
-                // spring torque, applied right here exactly as cpDampedRotarySpring's preStep does
-                int a = T_I(joint_a, jj), b = T_I(joint_b, jj);
-                R j_spring = R((E_P(ang, a) - E_P(ang, b)) - T_P(p_joint, jj * 7 + 4)) * p[5];
-                c.w[RI_SA(j)] -= j_spring * c.iinv[RI_SA(j)]; c.w[RI_SB(j)] += j_spring * c.iinv[RI_SB(j)];
-            } else if (kind == J_LIMIT) {
-                f[0] = p[0]; f[1] = E_R(jb0, jj); f[2] = E_R(ja0, jj);
-            } else {
-                f[0] = p[0]; f[1] = E_R(jrate, jj); f[2] = E_R(ja0, jj);
-            }
-        }
-        ri_store_vel(e, c);       // the contact warm start (next step) must see the spring impulses
-    } else {
-        int isl = lane_island(e, lane, nl);
-        if (isl >= 0) {
-            int jp = T_I(island_j, isl), jg = jp + 1, b = T_I(joint_b, jp);
-            c.bbody = b; c.bj = jp;
-            c.bminv = T_R(body_minv, b); c.biinv = T_R(body_iinv, b);
-            c.bk[0] = E_R(jk0, jp); c.bk[1] = E_R(jk1, jp); c.bk[2] = E_R(jk2, jp); c.bk[3] = E_R(jk3, jp);
-            c.bbias[0] = E_R(jb0, jp); c.bbias[1] = E_R(jb1, jp); c.bbias[2] = E_R(jb0, jg);
-            c.bacc[0] = E_R(ja0, jp); c.bacc[1] = E_R(ja1, jp); c.bacc[2] = E_R(ja0, jg);
-            c.blim[0] = E_R(jlim, jp); c.blim[1] = E_R(jlim, jg);
-            c.bgear = T_R(joint_p, jg * JOINT_PARAMS);
-        }
     }
+    const R js0 = RB(2, o[0]), js1 = RB(3, o[0]);
+#define MGX_PIN_BCAST(f, J) c.pin[f][0] = RB(J, o[0]); c.pin[f][1] = RB(J, o[1]); c.pin[f][2] = RB(J, o[2]); \
+                            c.pin[f][3] = RB(J, o[3]); c.pin[f][4] = RB(J, o[4]); c.pin[f][5] = RB(J, o[5]);
+    MGX_PIN_BCAST(0, 4) MGX_PIN_BCAST(1, 7)
+#undef MGX_PIN_BCAST
+    const R lb[2] = {RB(5, o[0]), RB(8, o[0])};
+    c.mot_rate[0] = RB(6, o[0]); c.mot_rate[1] = RB(9, o[0]);
+    MGX_UNROLL for (int f = 0; f < 2; f++) {
+        // cpRotaryLimitJoint: inside its range (bias 0) the joint does nothing and forgets its impulse; else the
+        // accumulated impulse is clamped to the side that pushes back
+        c.lim_lo[f] = lb[f] < R(0) ? R(0) : (lb[f] > R(0) ? -c.lim_max[f] : R(0));
+        c.lim_hi[f] = lb[f] < R(0) ? c.lim_max[f] : R(0);
+        if (lb[f] == R(0)) c.acc[3 + 3 * f] = R(0);
+        c.lim_b[f] = lb[f];
+    }
+    c.acc[0] = R(0); c.acc[1] = R(0);
+    ri_load_vel(e, c);
+    c.rw -= js0 * c.r_iinv; c.ew[0] += js0 * c.e_iinv[0];
+    c.rw -= js1 * c.r_iinv; c.ew[1] += js1 * c.e_iinv[1];
+    if (is_block_lane(c, lane)) { c.mvx = E_R(vx, c.mbody); c.mvy = E_R(vy, c.mbody); c.mw = E_R(w, c.mbody); }
+    // the contact warm start (next step) must see the spring impulses
+    if (c.has_contacts && lane == 0) { E_R(w, h.robot_body) = c.rw; E_R(w, h.eye_body[0]) = c.ew[0]; E_R(w, h.eye_body[1]) = c.ew[1]; }
 }
 // solve step B: cached arbiter impulses (lane 0, LDS)
-template <typename R, typename P> MGX_HD void solve_warm_contacts(Env<R, P> &e, int lane) {
-    if (lane == 0) contacts_warm_start(e);
+template <typename R, typename P> MGX_HD void solve_warm_contacts(Env<R, P> &e, const SolveCtx<R> &c, int lane) {
+    if (c.has_contacts && lane == 0) contacts_warm_start(e);
 }
-// solve step C: islands pick up the velocities and apply their cached joint impulses
-template <typename R, typename P> MGX_HD void solve_warm_joints(Env<R, P> &e, SolveCtx<R> &c, int lane, int nl) {
-    if (lane == 0) {
-        ri_load_vel(e, c);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int j = 0; j < RI_JOINTS; j++)
-            reg_apply_cached<R>(RI_KIND(j), c.f[j], c.minv[RI_SA(j)], c.iinv[RI_SA(j)], c.minv[RI_SB(j)], c.iinv[RI_SB(j)],
-                                c.vx[RI_SA(j)], c.vy[RI_SA(j)], c.w[RI_SA(j)], c.vx[RI_SB(j)], c.vy[RI_SB(j)], c.w[RI_SB(j)]);
-    }
-    if (c.bbody >= 0) {
-        bi_load_vel(e, c);
-        // pivot then gear cached impulses (a = static body)
-        c.bvx += c.bacc[0] * c.bminv; c.bvy += c.bacc[1] * c.bminv; c.bw += c.biinv * (R(0) * c.bacc[1] - R(0) * c.bacc[0]);
-        c.bw += c.bacc[2] * c.biinv;
-    } else if (lane != 0 || e.h->n_islands > nl - 1) {
-        // islands without a lane of their own: through LDS (lane 0 takes them all when L is small)
-        if (e.h->n_islands > nl - 1 && lane == 0)
-            for (int k = 0; k < e.h->n_islands; k++) { int jp = T_I(island_j, k); joint_apply_cached(e, jp); joint_apply_cached(e, jp + 1); }
+// after contacts ran on the LDS velocities: everybody reloads
+template <typename R, typename P> MGX_HD void solve_reload(const Env<R, P> &e, SolveCtx<R> &c, int lane) {
+    ri_load_vel(e, c);
+    if (is_block_lane(c, lane)) { c.mvx = E_R(vx, c.mbody); c.mvy = E_R(vy, c.mbody); c.mw = E_R(w, c.mbody); }
+}
+// the lanes that keep the robot's pair take the robot's velocity from the island's registers
+template <typename R> MGX_HD void pg_take_robot(SolveCtx<R> &c, int lane) {
+    if ((lane & (ROW - 1)) == 0) { c.mvx = c.rvx; c.mvy = c.rvy; c.mw = c.rw; }
+}
+// solve step C: cached joint impulses (cpConstraint applyCachedImpulse, joint order): the pairs ...
+template <typename R, typename P> MGX_HD void solve_warm_pg(Env<R, P> &e, SolveCtx<R> &c, int lane) {
+    if (c.has_contacts) solve_reload(e, c, lane);
+    pg_take_robot(c, lane);
+    c.mvx += c.pa0 * c.mminv; c.mvy += c.pa1 * c.mminv;      // (both anchors are body origins: no torque)
+    c.mw += c.ga * c.miinv;
+}
+// ... then the robot's joints 2..9 (springs have no cached impulse)
+template <typename R> MGX_HD void solve_warm_chain(SolveCtx<R> &c) {
+    c.rvx = RB(0, mvx); c.rvy = RB(0, mvy); c.rw = RB(0, mw);
+    MGX_UNROLL for (int f = 0; f < 2; f++) {
+        const R *pn = c.pin[f];
+        const R jn = c.acc[2 + 3 * f];
+        const R jx = pn[2] * jn, jy = pn[3] * jn;
+        c.rvx -= jx * c.r_minv; c.rvy -= jy * c.r_minv; c.rw -= c.r_iinv * (pn[0] * jy - pn[1] * jx);
+        c.fvx[f] += jx * c.f_minv[f]; c.fvy[f] += jy * c.f_minv[f];
+        const R jl = c.acc[3 + 3 * f];
+        c.rw -= jl * c.r_iinv; c.fw[f] += jl * c.f_iinv[f];
+        const R jm = c.acc[4 + 3 * f];
+        c.rw -= jm * c.r_iinv; c.fw[f] += jm * c.f_iinv[f];
     }
 }
-// solve step D1 / D2 / D3: one Gauss-Seidel iteration = [publish island velocities] [contacts] [islands]
-template <typename R, typename P> MGX_HD void solve_iter_publish(Env<R, P> &e, SolveCtx<R> &c, int lane) {
+// solve step D: one Gauss-Seidel iteration = [publish island velocities] [contacts] [pairs] [robot joints 2..9]
+template <typename R, typename P> MGX_HD void solve_iter_publish(Env<R, P> &e, const SolveCtx<R> &c, int lane) {
     if (!c.has_contacts) return;
     if (lane == 0) ri_store_vel(e, c);
-    bi_store_vel(e, c);
+    if (is_block_lane(c, lane)) { E_R(vx, c.mbody) = c.mvx; E_R(vy, c.mbody) = c.mvy; E_R(w, c.mbody) = c.mw; }
 }
-template <typename R, typename P> MGX_HD void solve_iter_contacts(Env<R, P> &e, SolveCtx<R> &c, int lane) {
+template <typename R, typename P> MGX_HD void solve_iter_contacts(Env<R, P> &e, const SolveCtx<R> &c, int lane) {
     if (!c.has_contacts || lane != 0) return;
     int nk = E_I(misc, M_NK);
     if (nk == 0) return;
@@ -977,45 +871,78 @@ template <typename R, typename P> MGX_HD void solve_iter_contacts(Env<R, P> &e, 
         cur = nxt;
     }
 }
-template <typename R, typename P> MGX_HD void solve_iter_joints(Env<R, P> &e, SolveCtx<R> &c, int lane, int nl) {
-    if (c.has_contacts) { if (lane == 0) ri_load_vel(e, c); bi_load_vel(e, c); }
-    if (lane == 0) {
-        if (e.h->n_islands > nl - 1) {
-            // not enough lanes for the block islands: lane 0 runs them through LDS, in joint order relative to the robot
-            if (!c.has_contacts) { /* LDS copy of block velocities is current: blocks never enter the robot's registers */ }
-            for (int k = 0; k < e.h->n_islands; k++) { int jp = T_I(island_j, k); joint_apply_impulse(e, jp); joint_apply_impulse(e, jp + 1); }
-        }
-#define MGX_RI_APPLY(j, ZA, ZB, KA) reg_apply_joint<R, ZA, ZB, KA>(RI_KIND(j), c.f[j], c.lim[j], c.minv[RI_SA(j)], c.iinv[RI_SA(j)], \
-            c.minv[RI_SB(j)], c.iinv[RI_SB(j)], c.vx[RI_SA(j)], c.vy[RI_SA(j)], c.w[RI_SA(j)], c.vx[RI_SB(j)], c.vy[RI_SB(j)], c.w[RI_SB(j)])
-        // Robot.setup order: pivot + gear from the kinematic control body (anchors at both origins), two eye springs, then per
-        // finger {pin (anchored at the finger's origin), limit, motor}
-        MGX_RI_APPLY(0, true, true, true); MGX_RI_APPLY(1, false, false, true); MGX_RI_APPLY(2, false, false, false); MGX_RI_APPLY(3, false, false, false);
-        MGX_RI_APPLY(4, false, true, false); MGX_RI_APPLY(5, false, false, false); MGX_RI_APPLY(6, false, false, false);
-        MGX_RI_APPLY(7, false, true, false); MGX_RI_APPLY(8, false, false, false); MGX_RI_APPLY(9, false, false, false);
-#undef MGX_RI_APPLY
+// cpPivotJoint + cpGearJoint applyImpulse of the lane's pair: first body immovable (kinematic / static), both anchors at the
+// body origins (Robot.setup's pair to the control body, entities.py:255-263; a block's pair, :703-711)
+template <typename R, typename P> MGX_HD void solve_iter_pg(Env<R, P> &e, SolveCtx<R> &c, int lane) {
+    if (c.has_contacts) solve_reload(e, c, lane);
+    pg_take_robot(c, lane);
+    {
+        const R vrx = c.mvx - c.avx, vry = c.mvy - c.avy;
+        const R dx = c.pb0 - vrx, dy = c.pb1 - vry;
+        R jx = dx * c.pk0 + dy * c.pk1, jy = dx * c.pk2 + dy * c.pk3;
+        const R ox = c.pa0, oy = c.pa1;
+        R nxv = ox + jx, nyv = oy + jy;
+        clamp_len(nxv, nyv, c.plim);
+        c.pa0 = nxv; c.pa1 = nyv;
+        jx = nxv - ox; jy = nyv - oy;
+        c.mvx += jx * c.mminv; c.mvy += jy * c.mminv;
     }
-    bi_iterate(c);
+    {
+        const R wr = c.mw * c.gratio - c.aw;
+        R jj = (c.gb - wr) * c.gim;
+        const R jold = c.ga;
+        const R jn = r_clamp(jold + jj, -c.glim, c.glim);
+        c.ga = jn; jj = jn - jold;
+        c.mw = c.mw + jj * c.miinv;
+    }
 }
-// solve step E: write velocities and accumulators back, then next substep's Robot.update
-template <typename R, typename P> MGX_HD void solve_end(Env<R, P> &e, SolveCtx<R> &c, int lane) {
-    if (lane == 0) {
-        ri_store_vel(e, c);
-        int j0 = e.h->robot_j0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int j = 0; j < RI_JOINTS; j++) {
-            const int kind = RI_KIND(j), jj = j0 + j;
-            if (kind == J_PIVOT) { E_R(ja0, jj) = c.f[j][10]; E_R(ja1, jj) = c.f[j][11]; }
-            else if (kind == J_PIN) E_R(ja0, jj) = c.f[j][8];
-            else if (kind != J_SPRING) E_R(ja0, jj) = c.f[j][2];
+// robot joints 2..9 in Robot.setup order: two eye springs, then per finger {pin (anchored at the finger's origin), limit,
+// motor}; cpDampedRotarySpring / cpPinJoint / cpRotaryLimitJoint / cpSimpleMotor applyImpulse
+template <typename R> MGX_HD void solve_iter_chain(SolveCtx<R> &c) {
+    c.rvx = RB(0, mvx); c.rvy = RB(0, mvy); c.rw = RB(0, mw);
+    MGX_UNROLL for (int k = 0; k < 2; k++) {
+        const R wrn = c.rw - c.ew[k];
+        const R w_damp = (c.acc[k] - wrn) * c.s_coef[k];
+        c.acc[k] = wrn + w_damp;                              // target_wrn
+        const R j_damp = w_damp * c.s_im[k];
+        c.rw = c.rw + j_damp * c.r_iinv; c.ew[k] = c.ew[k] - j_damp * c.e_iinv[k];
+    }
+    MGX_UNROLL for (int f = 0; f < 2; f++) {
+        const R ma = c.r_minv, ia = c.r_iinv, mb = c.f_minv[f], ib = c.f_iinv[f];
+        {
+            const R *pn = c.pin[f];                           // r1x r1y nx ny n_mass bias
+            const R vrx = c.fvx[f] - (c.rvx - pn[1] * c.rw), vry = c.fvy[f] - (c.rvy + pn[0] * c.rw);
+            const R vrn = vrx * pn[2] + vry * pn[3];
+            R jn = (pn[5] - vrn) * pn[4];
+            const R jold = c.acc[2 + 3 * f];
+            const R jnew = r_clamp(jold + jn, -c.pin_lim[f], c.pin_lim[f]);
+            c.acc[2 + 3 * f] = jnew; jn = jnew - jold;
+            const R jx = pn[2] * jn, jy = pn[3] * jn;
+            c.rvx -= jx * ma; c.rvy -= jy * ma; c.rw -= ia * (pn[0] * jy - pn[1] * jx);
+            c.fvx[f] += jx * mb; c.fvy[f] += jy * mb;
         }
-        ph_control(e);
+        {
+            const R wr = c.fw[f] - c.rw;
+            R jj = -(c.lim_b[f] + wr) * c.lim_im[f];
+            const R jold = c.acc[3 + 3 * f];
+            const R jn = r_clamp(jold + jj, c.lim_lo[f], c.lim_hi[f]);
+            c.acc[3 + 3 * f] = jn; jj = jn - jold;
+            c.rw = c.rw - jj * ia; c.fw[f] = c.fw[f] + jj * ib;
+        }
+        {
+            const R wr = c.fw[f] - c.rw + c.mot_rate[f];
+            R jj = -wr * c.mot_im[f];
+            const R jold = c.acc[4 + 3 * f];
+            const R jn = r_clamp(jold + jj, -c.mot_lim[f], c.mot_lim[f]);
+            c.acc[4 + 3 * f] = jn; jj = jn - jold;
+            c.rw = c.rw - jj * ia; c.fw[f] = c.fw[f] + jj * ib;
+        }
     }
-    if (c.bbody >= 0) {
-        bi_store_vel(e, c);
-        E_R(ja0, c.bj) = c.bacc[0]; E_R(ja1, c.bj) = c.bacc[1]; E_R(ja0, c.bj + 1) = c.bacc[2];
-    }
+}
+// solve step E: velocities back into the working set, then next substep's Robot.update
+template <typename R, typename P> MGX_HD void solve_end(Env<R, P> &e, SolveCtx<R> &c, int lane) {
+    if (lane == 0) { ri_store_vel(e, c); ph_control(e); }
+    if (is_block_lane(c, lane) && lane < ROW) { E_R(vx, c.mbody) = c.mvx; E_R(vy, c.mbody) = c.mvy; E_R(w, c.mbody) = c.mw; }
 }
 
 // ---------------------------------------------------------------- phase: publish the contact cache for the next substep
@@ -1057,7 +984,7 @@ MGX_HD void ph_init_work(Env<R, P> &e, int lane, int nl) {
         E_P(px, b) = P(0); E_P(py, b) = P(0); E_P(ang, b) = P(0); E_P(c, b) = P(1); E_P(s, b) = P(0);
         E_R(vx, b) = R(0); E_R(vy, b) = R(0); E_R(w, b) = R(0); E_R(vbx, b) = R(0); E_R(vby, b) = R(0); E_R(wb, b) = R(0);
     }
-    for (int j = lane; j < e.h->n_joints; j += nl) { E_R(ja0, j) = R(0); E_R(ja1, j) = R(0); E_R(jrate, j) = R(0); E_R(jb0, j) = R(0); E_R(jb1, j) = R(0); }
+    for (int j = lane; j < e.h->n_joints; j += nl) { E_R(ja0, j) = R(0); E_R(ja1, j) = R(0); E_R(jrate, j) = R(0); }
     for (int c = lane; c < e.h->cache_slots; c += nl) E_I(cmatched, c) = 0;
     if (lane == 0) for (int i = 0; i < M_N; i++) E_I(misc, i) = 0;
 }
@@ -1183,19 +1110,21 @@ MGX_HD void reset_env_state(const TmplHeader &h, const int32_t *ti, const R *tr,
     X(ph_broad_count(e, lane, nl))                                 \
     X(ph_broad_write(e, lane, nl))                                 \
     X(ph_narrow(e, lane, nl))                                      \
-    X(ph_arbiters_joints(e, lane, nl))                             \
+    X(ph_arbiters_joints(e, ctx, lane, nl))                        \
     X(solve_begin(e, ctx, lane, nl))                               \
-    X(solve_warm_contacts(e, lane))                                \
-    X(solve_warm_joints(e, ctx, lane, nl))                         \
+    X(solve_warm_contacts(e, ctx, lane))                           \
+    X(solve_warm_pg(e, ctx, lane))                                 \
+    X(solve_warm_chain(ctx))                                       \
     MGX_SOLVE_ITERATIONS(X)                                        \
     X(solve_end(e, ctx, lane))                                     \
     X(ph_cache_commit(e, lane, nl))
 
-// `iterations` Gauss-Seidel sweeps; each is three lane-group-synchronised steps (ctx = this lane's SolveCtx)
+// `iterations` Gauss-Seidel sweeps; each is four lane-group-synchronised steps (ctx = this lane's SolveCtx)
 #define MGX_SOLVE_ITERATIONS(X)                                    \
     for (int it_ = 0; it_ < iterations; it_++) {                   \
         X(solve_iter_publish(e, ctx, lane))                        \
         X(solve_iter_contacts(e, ctx, lane))                       \
-        X(solve_iter_joints(e, ctx, lane, nl))                     \
+        X(solve_iter_pg(e, ctx, lane))                             \
+        X(solve_iter_chain(ctx))                                   \
     }
 

@@ -57,9 +57,9 @@ template <typename R, typename P> MGX_HD int tmpl_total_words(const TmplHeader &
 constexpr bool probe_prefix(const char *s, const char *p) { return *p == 0 ? true : (*s == *p && probe_prefix(s + 1, p + 1)); }
 constexpr int probe_phase_id(const char *s) {
     const char *names[] = {"ph_init_work", "ph_load_state", "ph_integrate", "ph_shapes", "ph_broad_count", "ph_broad_write", "ph_narrow",
-                           "ph_arbiters_joints", "solve_begin", "solve_warm_contacts", "solve_warm_joints", "solve_iter_publish",
-                           "solve_iter_contacts", "solve_iter_joints", "solve_end", "ph_cache_commit"};
-    for (int i = 0; i < 16; i++) if (probe_prefix(s, names[i])) return i;
+                           "ph_arbiters_joints", "solve_begin", "solve_warm_contacts", "solve_warm_pg", "solve_iter_publish",
+                           "solve_iter_contacts", "solve_iter_pg", "solve_end", "ph_cache_commit", "solve_warm_chain", "solve_iter_chain"};
+    for (int i = 0; i < 18; i++) if (probe_prefix(s, names[i])) return i;
     return 19;
 }
 #endif
@@ -132,7 +132,11 @@ __global__ __launch_bounds__(64, (L == 64 ? MGX_L64_WAVES : MGX_LN_WAVES)) void 
 // The workgroup is ONE wavefront: its LDS operations execute in program order, so what a phase boundary needs is only that
 // the compiler keeps the phases' LDS accesses in order -- a wavefront-scope fence, not s_waitcnt + s_barrier.
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#ifdef MGX_PHASE_MARKERS   // development: phase names as comments in the -S output (tools/step_asm_phases.py)
+#define SYNC(stmt) asm volatile("; MGX_PHASE " #stmt ::: "memory"); stmt; WAVE_SYNC();
+#else
 #define SYNC(stmt) stmt; WAVE_SYNC();
+#endif
 #endif
     SYNC(ph_init_work(e, lane, nl))
     SYNC(ph_load_state(e, sp, sf, si, stride, env, lane, nl))
@@ -150,9 +154,11 @@ __global__ __launch_bounds__(64, (L == 64 ? MGX_L64_WAVES : MGX_LN_WAVES)) void 
     __syncthreads();
     if (lane == 0) ph_control(e);
     __syncthreads();
+    solve_ctx_init(e, ctx, lane, nl);
     for (int sub = 0; sub < n_sub; sub++) {
         MGX_SUBSTEP_PHASES(SYNC)
     }
+    SYNC(solve_ctx_flush(e, ctx, lane, nl))
     if (valid) ph_store_state(e, sp, sf, si, stride, env, lane, nl);
     if (ho.queue) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -14,6 +14,11 @@
 #else
 #define MGX_HD inline
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MGX_UNROLL _Pragma("unroll")
+#else
+#define MGX_UNROLL
+#endif
 
 namespace mgx {
 
@@ -138,8 +143,9 @@ struct WorkOff {
     int vx, vy, w, vbx, vby, wb;
     // world-space shape data
     int wx, wy, wnx, wny, bbl, bbb, bbr, bbt;
-    // joints: anchors, effective mass (k00..k11 | n.x n.y imass -), bias(2), accumulators(2), motor rate / spring target
-    int jr1x, jr1y, jr2x, jr2y, jk0, jk1, jk2, jk3, jb0, jb1, ja0, ja1, jrate, jlim;
+    // joints: accumulated impulses (2; in registers during the env-step, here only between ph_load_state / ph_store_state and
+    // the solver context), motor rate (Robot.update -> the motors' preStep), max impulse per substep
+    int ja0, ja1, jrate, jlim;
     // contact points
     int knx, kny, kr1x, kr1y, kr2x, kr2y, knm, ktm, kbias, kjb, kjn, kjt, kmu;
     // manifold scratch per overlapping pair: n(2) + 2 x (p1, p2)(4)  [mn and mp are adjacent: ncj may lie over both]
@@ -162,13 +168,12 @@ struct WorkOff {
     // 4 world vertices (x y nx ny: -1.4 %), 5 shape boxes, 6 overlap records (pair count hash offset), 7 contact ints, 8 cache ints
     // (5..8: nothing measurable one by one, -1.5 % together)
     static constexpr bool AOS_V = MGX_AOS & 16, AOS_BB = MGX_AOS & 32, AOS_OV = MGX_AOS & 64, AOS_KI = MGX_AOS & 128, AOS_C = MGX_AOS & 256;
-    static constexpr int BODY_P = AOS_BP ? 5 : 1, BODY_R = AOS_BR ? 6 : 1, JOINT_R = AOS_J ? 15 : 1, CONTACT_R = AOS_K ? 13 : 1;
+    static constexpr int BODY_P = AOS_BP ? 5 : 1, BODY_R = AOS_BR ? 6 : 1, JOINT_R = AOS_J ? 4 : 1, CONTACT_R = AOS_K ? 13 : 1;
     static constexpr int S_px = BODY_P, S_py = BODY_P, S_ang = BODY_P, S_c = BODY_P, S_s = BODY_P;
     static constexpr int S_vx = BODY_R, S_vy = BODY_R, S_w = BODY_R, S_vbx = BODY_R, S_vby = BODY_R, S_wb = BODY_R;
     static constexpr int VERT_R = AOS_V ? 4 : 1, BOX_R = AOS_BB ? 4 : 1, OV_I = AOS_OV ? 2 : 1, KI_I = AOS_KI ? 2 : 1, C_I = AOS_C ? 3 : 1;
     static constexpr int S_wx = VERT_R, S_wy = VERT_R, S_wnx = VERT_R, S_wny = VERT_R, S_bbl = BOX_R, S_bbb = BOX_R, S_bbr = BOX_R, S_bbt = BOX_R;
-    static constexpr int S_jr1x = JOINT_R, S_jr1y = JOINT_R, S_jr2x = JOINT_R, S_jr2y = JOINT_R, S_jk0 = JOINT_R, S_jk1 = JOINT_R, S_jk2 = JOINT_R,
-                         S_jk3 = JOINT_R, S_jb0 = JOINT_R, S_jb1 = JOINT_R, S_ja0 = JOINT_R, S_ja1 = JOINT_R, S_jrate = JOINT_R, S_jlim = JOINT_R;
+    static constexpr int S_ja0 = JOINT_R, S_ja1 = JOINT_R, S_jrate = JOINT_R, S_jlim = JOINT_R;
     static constexpr int S_knx = CONTACT_R, S_kny = CONTACT_R, S_kr1x = CONTACT_R, S_kr1y = CONTACT_R, S_kr2x = CONTACT_R, S_kr2y = CONTACT_R,
                          S_knm = CONTACT_R, S_ktm = CONTACT_R, S_kbias = CONTACT_R, S_kjb = CONTACT_R, S_kjn = CONTACT_R, S_kjt = CONTACT_R, S_kmu = CONTACT_R;
     static constexpr int S_mn = 1, S_mp = 1, S_cj = 1, S_ncj = 1;
@@ -194,8 +199,7 @@ struct WorkOff {
         knx = o; kny = o + sk; kr1x = o + 2 * sk; kr1y = o + 3 * sk; kr2x = o + 4 * sk; kr2y = o + 5 * sk; knm = o + 6 * sk; ktm = o + 7 * sk;
         kbias = o + 8 * sk; kjb = o + 9 * sk; kjn = o + 10 * sk; kjt = o + 11 * sk; kmu = o + 12 * sk; o += 13 * nk;
         if (o < geom_end) o = geom_end;
-        jr1x = o; jr1y = o + sj; jr2x = o + 2 * sj; jr2y = o + 3 * sj; jk0 = o + 4 * sj; jk1 = o + 5 * sj; jk2 = o + 6 * sj; jk3 = o + 7 * sj;
-        jb0 = o + 8 * sj; jb1 = o + 9 * sj; ja0 = o + 10 * sj; ja1 = o + 11 * sj; jrate = o + 12 * sj; jlim = o + 13 * sj; o += 15 * nj;
+        ja0 = o; ja1 = o + sj; jrate = o + 2 * sj; jlim = o + 3 * sj; o += 4 * nj;
         mn = o; o += nov * 2; mp = o; o += nov * 8;
         cj = o; o += nc * 4;
         // the cache being built is written from solve_begin on, when the manifolds (ph_narrow .. ph_arbiters_joints) are dead

@@ -82,7 +82,7 @@ class EmuBatch:
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).ctypes.data
         self.L.emu_reset(self.h, self.mode, self.sp.ctypes.data, self.sf.ctypes.data, self.si.ctypes.data, m)
 
-    def run(self, actions, n_sub=10, nl=4, count_step=True):
+    def run(self, actions, n_sub=10, nl=16, count_step=True):
         a = np.ascontiguousarray(actions, dtype=np.int32)
         done = np.zeros(self.n, dtype=np.uint8)
         self.L.emu_run(self.h, self.mode, self.sp.ctypes.data, self.sf.ctypes.data, self.si.ctypes.data,

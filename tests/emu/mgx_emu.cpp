@@ -50,17 +50,20 @@ template <typename R, typename P> struct Emu : EmuBase {
         for (int ei = 0; ei < n_envs; ei++) {
             Env<R, P> e = env();
             std::vector<SolveCtx<R>> ctxs(nl);
+            for (int lane = 0; lane < nl; lane++) ctxs[lane].row = &ctxs[lane & ~(ROW - 1)];     // what DPP row_newbcast reads on the device
 #define RUN(stmt) for (int lane = 0; lane < nl; lane++) { SolveCtx<R> &ctx = ctxs[lane]; (void)ctx; stmt; }
             RUN(ph_init_work(e, lane, nl))
             RUN(ph_load_state(e, sp, sf, si, (long)n_envs, (long)ei, lane, nl))
             RUN(ph_refresh_trig(e, lane, nl))
             e.wi[e.wo.misc + M_ACTION] = actions[ei];
             ph_control(e);
+            RUN(solve_ctx_init(e, ctx, lane, nl))
             for (int sub = 0; sub < n_sub; sub++) { MGX_SUBSTEP_PHASES(RUN) }
             if (count_step) {
                 e.wi[e.wo.misc + M_STEPS] += 1;
                 if (done) done[ei] = e.wi[e.wo.misc + M_STEPS] >= h.max_episode_steps ? 1 : 0;
             }
+            RUN(solve_ctx_flush(e, ctx, lane, nl))
             RUN(ph_store_state(e, sp, sf, si, (long)n_envs, (long)ei, lane, nl))
 #undef RUN
         }
