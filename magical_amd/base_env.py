@@ -437,7 +437,15 @@ class BaseEnv(abc.ABC):
         """Does sample_variation() draw anything for this task variant?  (The reference's on_reset branches on constructor
         flags only, so the answer is the same for every env and episode; asked on a scratch stream.)"""
         if getattr(self, '_variation_active', None) is None:
-            self._variation_active = self.sample_variation(np.random.RandomState(0), 0) is not None
+            # the hook writes env 0's row of the task's per-env tables (FixColour._keep_env, FindDupe._is_target_env,
+            # Cluster._class_env): the probe must leave them as they were -- its first call may come from step() at an episode
+            # end of an env restored with set_state() and never reset(), right before that table is scored
+            saved = {a: (None if getattr(self, a, None) is None else np.array(getattr(self, a), copy=True)) for a in self.TASK_STATE_ATTRS}
+            try:
+                self._variation_active = self.sample_variation(np.random.RandomState(0), 0) is not None
+            finally:
+                for a, v in saved.items():
+                    setattr(self, a, v)
         return self._variation_active
 
     def default_entity_poses(self):

@@ -72,16 +72,21 @@ def wrap_preproc(env_cls, preproc):
                 old.copy_(torch.where(fill_mask.view(-1, 1, 1, 1, 1) != 0, new, old))
 
         def get_state(self):
+            # the snapshot always holds the channels-last stack u8[N, 96, 96, 12] (what self._stack is), whether the frames live
+            # there or as planes in a ring: a checkpoint does not depend on obs_ring / MGX_OBS_RING
             d = super().get_state()
-            d['stack'] = self._stack.clone() if self._ring is None else self._ring_window().clone()
+            d['stack'] = self._stack.clone() if self._ring is None else self._ring_window().permute(0, 2, 3, 1).contiguous()
             d['stack_allo'] = None if self._stack_allo is None else self._stack_allo.clone()
             return d
 
         def set_state(self, d):
             super().set_state(d)
+            want = (self.n_envs, 96, 96, 12)
+            if tuple(d['stack'].shape) != want:
+                raise ValueError(f"snapshot frame stack has shape {tuple(d['stack'].shape)}, expected {want} (channels last)")
             if self._ring is not None:
                 self._ring_k = 3
-                self._ring[:, 0:4].copy_(d['stack'].view(self.n_envs, 4, 3, 96, 96))
+                self._ring[:, 0:4].copy_(d['stack'].permute(0, 3, 1, 2).reshape(self.n_envs, 4, 3, 96, 96))
                 return
             self._stack.copy_(d['stack'])
             if self._stack_allo is not None:

@@ -3,6 +3,8 @@
 // the engine owns only its small constant template buffers and timing events.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <array>
+#include <mutex>
 #include <iterator>
 #include <thread>
 #include <chrono>
@@ -50,14 +52,20 @@ struct DeviceGuard {
 #define ON_DEVICE(e) DeviceGuard guard__((e)->device); if (!guard__.ok) return fail(MGX_ERR_HIP, "hipSetDevice failed")
 
 // Dynamic LDS above 64 KB needs an opt-in per kernel function AND per device: remember the largest size granted so far for
-// each (instantiation, device) -- `Tag` makes the table one per kernel.
-template <typename Tag> int ensure_lds(const void *kern, size_t lds, int device) {
-    static thread_local size_t granted[MAX_DEVICES] = {0};
+// each (kernel function, device).  Keyed by the kernel's address: instantiations of one template share their function-pointer
+// type, so a table per type (or per tag declared in a generic lambda) would be shared by all of them.
+static int ensure_lds(const void *kern, size_t lds, int device) {
+    static std::mutex mu;
+    static std::unordered_map<const void *, std::array<size_t, MAX_DEVICES>> granted;
     if (lds > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "kernel working set does not fit the CU's 160 KB of LDS");
+    if (lds <= 65536) return MGX_OK;
     const int d = device >= 0 && device < MAX_DEVICES ? device : 0;
-    if (lds > 65536 && lds > granted[d]) {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = granted.find(kern);
+    if (it == granted.end()) it = granted.emplace(kern, std::array<size_t, MAX_DEVICES>{}).first;
+    if (lds > it->second[d]) {
         HIP_OK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        granted[d] = lds;
+        it->second[d] = lds;
     }
     return MGX_OK;
 }
@@ -518,10 +526,10 @@ static long step_slots(mgx_engine *e);
 template <typename R, typename P, int L>
 static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const int32_t *actions, uint8_t *done, int n_sub,
                          int count_step, hipStream_t st, const StepHandoff &ho) {
-    auto kern = k_step<R, P, L>;
+    void (*kern)(TmplDev, P *, R *, int32_t *, const int32_t *, uint8_t *, int, int, int, int, StepHandoff);
+    if constexpr (L == 64) kern = k_step_env<R, P>; else kern = k_step<R, P, L>;
     size_t lds = step_lds_bytes(e, L);
-    struct Tag { char c; };
-    if (int rc = ensure_lds<Tag>((const void *)kern, lds, e->device)) return rc;
+    if (int rc = ensure_lds((const void *)kern, lds, e->device)) return rc;
     int epb = 64 / L, blocks = (e->n_envs + epb - 1) / epb;
     // More step workgroups than the chip holds at once (LDS: 160 KB per CU; registers: one wavefront per SIMD, two for the
     // one-env-per-wavefront instantiation): they are dispatched longest first, by the durations of the previous launch.
@@ -713,10 +721,9 @@ static int reset_common(mgx_engine *e, void *state_p, void *state_f, int32_t *st
     size_t lds = e->env_worlds ? 0 : (size_t)e->tdev.n_words * 4;
     int blocks = (e->n_envs + 63) / 64;
     {
-        struct TagA { char c; }; struct TagB { char c; }; struct TagC { char c; };
-        int rc = e->dtype == MGX_F32 ? ensure_lds<TagA>((const void *)k_reset<float, double>, lds, e->device)
-               : e->dtype == MGX_F64 ? ensure_lds<TagB>((const void *)k_reset<double, double>, lds, e->device)
-                                     : ensure_lds<TagC>((const void *)k_reset<float, float>, lds, e->device);
+        int rc = e->dtype == MGX_F32 ? ensure_lds((const void *)k_reset<float, double>, lds, e->device)
+               : e->dtype == MGX_F64 ? ensure_lds((const void *)k_reset<double, double>, lds, e->device)
+                                     : ensure_lds((const void *)k_reset<float, float>, lds, e->device);
         if (rc) return rc;
     }
     if (e->dtype == MGX_F32) hipLaunchKernelGGL((k_reset<float, double>), dim3(blocks), dim3(64), lds, st, e->tdev, (double *)state_p, (float *)state_f, state_i, mask, (const double *)ent_pose, e->n_envs);
@@ -766,8 +773,7 @@ static int launch_raster(mgx_engine *e, const void *sp, uint8_t *out, int64_t en
                          const RasterHandoff &ho = RasterHandoff{}) {
     size_t lds = e->lds_raster;
     auto go = [&](auto kern) -> int {
-        struct Tag { char c; };       // (a local type of this generic lambda: one table per instantiation)
-        if (int rc = ensure_lds<Tag>((const void *)kern, lds, e->device)) return rc;
+        if (int rc = ensure_lds((const void *)kern, lds, e->device)) return rc;
         hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, fill, e->n_envs, ho);
         return MGX_OK;
     };
@@ -787,8 +793,7 @@ static int launch_raster_deferred(mgx_engine *e, const void *sp, uint8_t *out, i
                                   const RasterHandoff &ho) {
     size_t lds = e->lds_raster;
     auto go = [&](auto kern) -> int {
-        struct Tag { char c; };
-        if (int rc = ensure_lds<Tag>((const void *)kern, lds, e->device)) return rc;
+        if (int rc = ensure_lds((const void *)kern, lds, e->device)) return rc;
         hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, e->n_envs, ho);
         return MGX_OK;
     };
@@ -854,17 +859,27 @@ int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t 
     if (e->hand_epoch == 0) e->hand_epoch = 1;        // 0 is what the zeroed tables hold
     StepHandoff sh{e->d_queue, e->d_hand, e->d_hand + 1, e->hand_tail, e->hand_epoch};
     RasterHandoff rh{e->d_queue, e->d_hand + 1, e->hand_started, (unsigned)step_blocks(e), e->hand_epoch, e->d_deferred, e->d_hand + 2, 1};
-    e->hand_tail += (unsigned)e->n_envs; e->hand_started += (unsigned)step_blocks(e);
+    // A failure between here and the second launch leaves the device's hand-off counters and their host mirrors out of step (a
+    // later call would hand the producers a wrong base): drain both streams, zero counters and tables, start over at 0.  The
+    // mirrors themselves move only once both launches are in flight.
+    auto recover = [&](int rc) {
+        (void)hipStreamSynchronize(e->st2); (void)hipStreamSynchronize(st);
+        (void)hipMemset(e->d_hand, 0, 16); (void)hipMemset(e->d_queue, 0, (size_t)e->n_envs * 8); (void)hipMemset(e->d_deferred, 0, (size_t)e->n_envs * 4);
+        (void)hipDeviceSynchronize();
+        e->hand_tail = e->hand_started = 0;
+        return rc;
+    };
     // the raster stream joins the caller's stream here (the observation tensor may still be read by earlier work on it) ...
     HIP_OK(hipEventRecord(e->ev_fork, st));
     HIP_OK(hipStreamWaitEvent(e->st2, e->ev_fork, 0));
     int rc = step_common(e, state_p, state_f, state_i, actions, done, PHYS_STEPS, 1, stream, sh);
-    if (rc) return rc;
+    if (rc) return recover(rc);
     rc = timing_begin(e, 1, e->st2);
-    if (rc) return rc;
+    if (rc) return recover(rc);
     rc = e->dtype == MGX_F32_PURE ? launch_raster<float>(e, state_p, out, env_stride, view, layout, nullptr, e->st2, rh)
                                   : launch_raster<double>(e, state_p, out, env_stride, view, layout, nullptr, e->st2, rh);
-    if (rc) return rc;
+    if (rc) return recover(rc);
+    e->hand_tail += (unsigned)e->n_envs; e->hand_started += (unsigned)step_blocks(e);
     rc = timing_end(e, 1, e->st2);
     if (rc) return rc;
     // ... and the caller's stream waits for it: whatever comes next on `stream` sees the finished observation
@@ -893,9 +908,8 @@ int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_
     size_t lds = e->lds_raster;
     int blocks = (NATIVE_RES * NATIVE_RES + 255) / 256;
     {
-        struct TagA { char c; }; struct TagB { char c; };
-        int rc = e->dtype == MGX_F32_PURE ? ensure_lds<TagA>((const void *)k_raster_native<float>, lds, e->device)
-                                          : ensure_lds<TagB>((const void *)k_raster_native<double>, lds, e->device);
+        int rc = e->dtype == MGX_F32_PURE ? ensure_lds((const void *)k_raster_native<float>, lds, e->device)
+                                          : ensure_lds((const void *)k_raster_native<double>, lds, e->device);
         if (rc) return rc;
     }
     if (e->dtype == MGX_F32_PURE) hipLaunchKernelGGL((k_raster_native<float>), dim3(blocks), dim3(256), lds, st, e->rdev, (const float *)state_p, out, view, (long)env, e->n_envs);

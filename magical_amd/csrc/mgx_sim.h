@@ -28,7 +28,37 @@ template <> MGX_HD float r_sqrt<float>(float x) { return sqrtf(x); }
 template <> MGX_HD double r_sqrt<double>(double x) { return sqrt(x); }
 template <typename R> MGX_HD void r_sincos(R a, R &s, R &c);
 template <> MGX_HD void r_sincos<float>(float a, float &s, float &c) { s = sinf(a); c = cosf(a); }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_LIBM_SINCOS)
+// cpvforangle for the pose type, once per body and substep.  The library's sincos spends ~220 fp64 instructions on one lane
+// group's six angles (Payne-Hanek path and all); body angles stay within a few thousand radians, so: Cody-Waite reduction
+// against pi/2 in three parts (exact products through fma) and the fdlibm kernels on [-pi/4, pi/4] -- < 1 ulp, ~45 instructions.
+template <> MGX_HD void r_sincos<double>(double a, double &s, double &c) {
+    const double n = __builtin_rint(a * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-n, 1.57079632679489655800e+00, a);
+    r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
+    r = __builtin_fma(-n, -1.49738490485916983e-33, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = __builtin_fma(r * z, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+    const int q = (int)n;
+    const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
+#else
 template <> MGX_HD void r_sincos<double>(double a, double &s, double &c) { s = sin(a); c = cos(a); }
+#endif
 template <typename R> MGX_HD R r_abs(R x) { return x < R(0) ? -x : x; }
 template <typename R> MGX_HD R r_min(R a, R b) { return a < b ? a : b; }
 template <typename R> MGX_HD R r_max(R a, R b) { return a > b ? a : b; }
@@ -241,8 +271,9 @@ template <typename R, typename P> MGX_HD EdgeRef<R> support_edge(const Env<R, P>
 template <typename R> struct ManifoldOut {
     int count; R nx, ny; R p[8]; int h0, h1;
     MGX_HD void push(R p1x, R p1y, R p2x, R p2y, int hash) {
-        R *q = p + 4 * count; q[0] = p1x; q[1] = p1y; q[2] = p2x; q[3] = p2y;
-        if (count == 0) h0 = hash; else h1 = hash;
+        // (no run-time index into p: the array would live in scratch memory)
+        if (count == 0) { p[0] = p1x; p[1] = p1y; p[2] = p2x; p[3] = p2y; h0 = hash; }
+        else { p[4] = p1x; p[5] = p1y; p[6] = p2x; p[7] = p2y; h1 = hash; }
         count++;
     }
 };
@@ -430,7 +461,8 @@ template <typename R, typename P> MGX_HD void ph_narrow(Env<R, P> &e, int lane, 
         collide_pair(e, pr & 0xFF, pr >> 8, m);
         E_I(mcnt, q) = m.count | ((m.h0 | (m.h1 << 8)) << 8);        // point count (0..2) | the two point hashes
         E_R(mn, 2 * q) = m.nx; E_R(mn, 2 * q + 1) = m.ny;
-        for (int i = 0; i < 4 * m.count; i++) E_R(mp, 8 * q + i) = m.p[i];
+        if (m.count > 0) { E_R(mp, 8 * q + 0) = m.p[0]; E_R(mp, 8 * q + 1) = m.p[1]; E_R(mp, 8 * q + 2) = m.p[2]; E_R(mp, 8 * q + 3) = m.p[3]; }
+        if (m.count > 1) { E_R(mp, 8 * q + 4) = m.p[4]; E_R(mp, 8 * q + 5) = m.p[5]; E_R(mp, 8 * q + 6) = m.p[6]; E_R(mp, 8 * q + 7) = m.p[7]; }
     }
 }
 

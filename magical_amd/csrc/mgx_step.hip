@@ -72,10 +72,17 @@ constexpr int probe_phase_id(const char *s) {
 #ifndef MGX_LN_WAVES
 #define MGX_LN_WAVES 1      // register budget of the several-envs-per-wave instantiations, in waves per SIMD (512 / n VGPRs)
 #endif
+// Register budget of the several-envs-per-wave instantiations: 224 of the SIMD's 512 (amdgpu_num_vgpr counts in units of two on
+// gfx90a+, where VGPRs and AGPRs are one file), a dozen values spilled outside the substep loop -- so that THREE 96-register
+// rasteriser wavefronts fit beside a step wavefront in the fused env-step (mgx_engine_step_render) instead of two.
+#ifndef MGX_STEP_NUM_VGPR
+#define MGX_STEP_NUM_VGPR 112
+#endif
+#define MGX_STEP_VGPR_ATTR __attribute__((amdgpu_num_vgpr(MGX_STEP_NUM_VGPR)))
 template <typename R, typename P, int L>
-__global__ __launch_bounds__(64, (L == 64 ? MGX_L64_WAVES : MGX_LN_WAVES)) void k_step(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
-                                             const int32_t *__restrict__ actions, uint8_t *__restrict__ done,
-                                             int n_envs, int n_sub, int count_step, int iterations, StepHandoff ho) {
+__device__ __forceinline__ void step_body(const TmplDev &t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
+                                          const int32_t *__restrict__ actions, uint8_t *__restrict__ done,
+                                          int n_envs, int n_sub, int count_step, int iterations, const StepHandoff &ho) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
     if (ho.queue) {
@@ -166,8 +173,9 @@ __global__ __launch_bounds__(64, (L == 64 ? MGX_L64_WAVES : MGX_LN_WAVES)) void 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler may drop the fence's own wait: keep this one)
         if (valid && lane == 0) {
             const unsigned ticket = __hip_atomic_fetch_add(ho.tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ho.queue[ticket - ho.base], ((unsigned long long)ho.epoch << 32) | (unsigned long long)env,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket - ho.base < (unsigned)n_envs)       // (never false while the host's mirror of *tail is right: keeps a wrong base in bounds)
+                __hip_atomic_store(&ho.queue[ticket - ho.base], ((unsigned long long)ho.epoch << 32) | (unsigned long long)env,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (t.dur && tid == 0) t.dur[wg] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 6);
@@ -175,6 +183,20 @@ __global__ __launch_bounds__(64, (L == 64 ? MGX_L64_WAVES : MGX_LN_WAVES)) void 
     if (t.dbg_clk && tid == 0) for (int i = 0; i < 20; i++) t.dbg_clk[(long)blockIdx.x * 32 + i] = pacc[i];
 #endif
 #undef SYNC
+}
+// several envs per wavefront (L = 16, 32) ...
+template <typename R, typename P, int L>
+__global__ __launch_bounds__(64, MGX_LN_WAVES) MGX_STEP_VGPR_ATTR void k_step(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
+                                                                              const int32_t *__restrict__ actions, uint8_t *__restrict__ done,
+                                                                              int n_envs, int n_sub, int count_step, int iterations, StepHandoff ho) {
+    step_body<R, P, L>(t, sp, sf, si, actions, done, n_envs, n_sub, count_step, iterations, ho);
+}
+// ... and one env per wavefront (the per-env-world mode)
+template <typename R, typename P>
+__global__ __launch_bounds__(64, MGX_L64_WAVES) void k_step_env(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
+                                                                const int32_t *__restrict__ actions, uint8_t *__restrict__ done,
+                                                                int n_envs, int n_sub, int count_step, int iterations, StepHandoff ho) {
+    step_body<R, P, 64>(t, sp, sf, si, actions, done, n_envs, n_sub, count_step, iterations, ho);
 }
 
 // Longest-first dispatch order of the step workgroups for the NEXT launch, from the durations the last one left: a counting

@@ -7,7 +7,7 @@ amplify 1e-16 perturbations to 1e-3 within ~20 env-steps).
 import numpy as np
 import pytest
 
-from tests.util import (EPS_F32, EPS_F64, F32_OPS_FACTOR, TASKS, OracleEnvelope, comparable_mask, masked_err, new_ref, perturb_bodies, quantiles, ref_body_index,
+from tests.util import (EPS_F32, EPS_F64, F32_OPS_FACTOR, FLOOR_F32, FLOOR_F64, EnvelopeTally, TASKS, OracleEnvelope, comparable_mask, masked_err, new_ref, perturb_bodies, quantiles, ref_body_index,
                         velround_step)
 
 pytestmark = pytest.mark.gpu
@@ -49,7 +49,7 @@ def test_f64_engine_tracks_oracle(task):
     env = _make(f'{task}-Demo-v0', n, dtype='f64')
     env.reset()
     orc = OracleEnvelope([lambda: new_ref(task)] * n, K=8, eps=EPS_F64, seed=1)
-    first = []
+    first, tally = [], EnvelopeTally()
     for s in range(t):
         env.step(tape[s])
         got = env.get_bodies()[:, 1:, :3]
@@ -57,7 +57,8 @@ def test_f64_engine_tracks_oracle(task):
         errs = np.array([masked_err(got[k], want[k], orc.mask) for k in range(n)])
         if s == 0:
             first = errs
-        assert (errs <= 2 * orc.running + 1e-12).all(), (task, s, errs, orc.running)
+        tally.check(errs, orc.running, 2.0, FLOOR_F64, (task, s))
+    tally.assert_mostly_decided(what=task)
     assert np.median(first) < 1e-10, (task, first)
     env.close()
 
@@ -346,6 +347,7 @@ def test_rand_dynamics_matches_oracle(task):
     mask = comparable_mask(refs[0])
     # the oracle's own spread: 8 replicas per env (same draws), poses perturbed by 1e-13
     orc = OracleEnvelope([lambda k=k: mk(k) for k in range(n)], K=8, eps=EPS_F64, seed=3, base=refs)
+    tally = EnvelopeTally()
     for s in range(2 * ep):
         _, _, done, _ = env.step(tape[s])
         for k, r in enumerate(refs):
@@ -361,9 +363,10 @@ def test_rand_dynamics_matches_oracle(task):
             continue
         got = env.get_bodies()
         errs = np.array([masked_err(got[k, 1:, :3], r.bodies()[idx][:, :3], mask[:, :3]) for k, r in enumerate(refs)])
-        assert (errs <= 2 * orc.running + 1e-12).all(), (task, s, errs, orc.running)
+        tally.check(errs, orc.running, 2.0, FLOOR_F64, (task, s))
         if s % ep == 0:
             assert np.median(errs) < 1e-10, (task, s, errs)
+    tally.assert_mostly_decided(what=task)
     # the limits matter: default dynamics give different poses after one step
     dflt = _make(f'{task}-Demo-v0', n, dtype='f64', max_episode_steps=ep)
     dflt.reset()
@@ -503,6 +506,7 @@ def test_pose_randomisation_matches_oracle(task, variant, flags, dtype):
     first = [r.reset() for r in refs]
     orc = OracleEnvelope([lambda k=k: mk(k) for k in range(n)], K=8, eps=EPS_F64 if f64 else EPS_F32, seed=4, base=[r.env for r in refs], fp32_state=not f64)
     factor = 2.0 if f64 else F32_OPS_FACTOR
+    tally = EnvelopeTally()
     idx = ref_body_index(refs[0].env)
     mask = comparable_mask(refs[0].env)
     def check_reset(obs_now, firsts):
@@ -531,9 +535,10 @@ def test_pose_randomisation_matches_oracle(task, variant, flags, dtype):
         # rounding only in most envs -- at some drawn robot angles the device's and libm's sin / cos differ in the last bit,
         # the finger roots' zero-length pins start 1e-17 apart in another direction and the reference dynamics amplify
         # that within the step: exactly what they do to the replicas
-        assert (errs <= factor * orc.running + 1e-12).all(), (task, dtype, s, errs, orc.running)
+        tally.check(errs, orc.running, factor, FLOOR_F64 if f64 else FLOOR_F32, (task, dtype, s))
         if s % ep == 0 and f64:
             assert np.median(errs) < 1e-8, (task, s, errs)
+    tally.assert_mostly_decided(what=(task, dtype))
     env.close()
 
 
@@ -583,8 +588,9 @@ def test_per_env_worlds_match_oracle(task, variant, flags, dtype):
     first = [r.reset() for r in refs]
     orc = OracleEnvelope([lambda k=k: mk(k) for k in range(n)], K=8, eps=EPS_F64 if f64 else EPS_F32, seed=5, base=[r.env for r in refs], fp32_state=not f64)
     factor = 2.0 if f64 else F32_OPS_FACTOR
+    tally = EnvelopeTally()
     ents = env._entities
-    def compare(bound, what, typical=None):
+    def compare(bound, what, typical=None):         # bound: per-env absolute bounds, or None = the oracle's running envelope
         poses = env.get_poses()
         errs, env_err = [], np.zeros(n)
         for k, r in enumerate(refs):
@@ -599,7 +605,10 @@ def test_per_env_worlds_match_oracle(task, variant, flags, dtype):
                 want = np.asarray(r.env.task.main_pose(ref_ent))
                 errs.append(np.abs(poses[k, ent.body] - want).max())
                 env_err[k] = max(env_err[k], errs[-1])
-        assert (env_err <= bound).all(), (task, dtype, what, env_err, bound)
+        if bound is None:
+            tally.check(env_err, orc.running, factor, FLOOR_F64 if f64 else FLOOR_F32, (task, dtype, what))
+        else:
+            assert (env_err <= bound).all(), (task, dtype, what, env_err, bound)
         if typical is not None:
             assert np.median(errs) < typical, (task, what, np.median(errs))
     def check_reset(obs_now, firsts):
@@ -622,7 +631,8 @@ def test_per_env_worlds_match_oracle(task, variant, flags, dtype):
             continue
         # rounding only for the typical body; a random layout may start with a finger against a block or a wall, where the
         # reference dynamics amplify a rounding to ~1e-4 within one env-step -- in the replicas too
-        compare(factor * orc.running + 1e-12, f'step {s}', typical=1e-8 if (f64 and s % ep == 0) else None)
+        compare(None, f'step {s}', typical=1e-8 if (f64 and s % ep == 0) else None)
+    tally.assert_mostly_decided(what=(task, dtype))
     env.close()
 
 
@@ -895,6 +905,31 @@ def test_checkpoint_resume(name):
     for (ow, dw, sw), (og, dg, sg) in zip(want, got):
         assert all(torch.equal(ow[k], og[k]) for k in ow) and np.array_equal(dw, dg) and np.array_equal(sw, sg)
     assert torch.equal(a.state_p, b.state_p) and torch.equal(a.state_f, b.state_f)
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['FixColour-TestAll-LoRes4E-v0', 'FindDupe-TestAll-LoRes4E-v0', 'ClusterColour-TestAll-LoRes4E-v0'])
+def test_restored_env_without_reset_scores_env0_from_the_snapshot(name):
+    """set_state() into an env that was never reset(): the first sample_variation_is_active() probe then runs inside step() at
+    the episode end, right before scoring; it must not overwrite env 0's row of the task's per-env tables (round-2 advisor)."""
+    n, ep = 8, 5
+    a = _make(name, n, max_episode_steps=ep); a.seed(11); a.reset()
+    tape = _tape(4, ep, n)
+    for s in range(2):
+        a.step(tape[s])
+    snap = a.get_state()
+    b = _make(name, n, max_episode_steps=ep)          # no reset(), no seed(): everything comes from the snapshot
+    b.set_state(snap)
+    tables = {k: np.array(getattr(b, k), copy=True) for k in b.TASK_STATE_ATTRS}
+    assert tables, name
+    assert b.sample_variation_is_active()
+    for k, v in tables.items():
+        assert np.array_equal(getattr(b, k), v), k
+    for s in range(2, ep):
+        _, _, da, ia = a.step(tape[s])
+        _, _, db, ib = b.step(tape[s])
+    assert da.all() and db.all() and np.array_equal(ia['eval_score'], ib['eval_score'])
     a.close(); b.close()
 
 
@@ -1174,6 +1209,17 @@ def test_planar_frame_ring_equals_the_inplace_stack(name, n, ring, overlap):
     o1 = a.step(tape[0])[0].clone()
     a.set_state(st)
     assert torch.equal(a.step(tape[0])[0], o1)
+    # ... and across the two frame-stack modes: the snapshot holds the channels-last stack either way (round-2 advisor: a ring env
+    # that loaded a non-ring snapshot used to scramble its frame history)
+    assert tuple(st['stack'].shape) == (n, 96, 96, 12)
+    b.set_state(st)
+    assert torch.equal(b.step(tape[0])[0], o1)
+    sb = b.get_state()
+    a.set_state(sb)
+    assert torch.equal(a.step(tape[1])[0], b.step(tape[1])[0])
+    bad = dict(st); bad['stack'] = st['stack'].permute(0, 3, 1, 2).contiguous()
+    with pytest.raises(ValueError, match='channels last'):
+        a.set_state(bad)
     a.close(); b.close()
 
 

@@ -22,12 +22,13 @@ def main():
         src = os.path.join(d, 'mark.hip')
         with open(src, 'w') as f:
             f.write('#define MGX_PHASE_MARKERS 1\n#include "%s/magical_amd/csrc/mgx_step.hip"\n' % ROOT)
-            f.write('template __global__ void mgx::k_step<%s,%s,%s>(mgx::TmplDev, %s*, %s*, int32_t*, const int32_t*, uint8_t*, int,int,int,int, mgx::StepHandoff);\n' % (R, P, L, P, R))
+            kern = 'k_step_env<%s,%s>' % (R, P) if L == '64' else 'k_step<%s,%s,%s>' % (R, P, L)
+            f.write('template __global__ void mgx::%s(mgx::TmplDev, %s*, %s*, int32_t*, const int32_t*, uint8_t*, int,int,int,int, mgx::StepHandoff);\n' % (kern, P, R))
         out = os.environ.get('MGX_ASM_OUT', os.path.join(d, 'mark.s'))
         subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S', '-o', out, src,
                                '-Wno-unused-parameter', '-Wno-unused-command-line-argument'] + defs)
         lines = open(out).read().split('\n')
-    phase, counts, order = 'prologue', collections.defaultdict(collections.Counter), ['prologue']
+    phase, counts, order, maxv = 'prologue', collections.defaultdict(collections.Counter), ['prologue'], {}
     for l in lines:
         m = re.search(r'; MGX_PHASE (\w+)', l)
         if m:
@@ -47,11 +48,13 @@ def main():
                'vmem' if op.startswith(('global_', 'scratch_', 'buffer_', 'flat_')) else
                'f64' if '_f64' in op else 'valu')
         counts[phase][cls] += 1
+        for r in re.findall(r'\bv(\d+)\b', l) + [x[1] for x in re.findall(r'\bv\[(\d+):(\d+)\]', l)]:
+            maxv[phase] = max(maxv.get(phase, 0), int(r))
     cols = ['valu', 'f64', 'lds', 'salu', 'wait', 'nop', 'branch', 'vmem']
-    print('%-22s %6s  ' % ('phase', 'total') + ' '.join('%6s' % c for c in cols))
+    print('%-22s %6s  ' % ('phase', 'total') + ' '.join('%6s' % c for c in cols) + '   max v#')
     for ph in order:
         c = counts[ph]
-        print('%-22s %6d  ' % (ph, sum(c.values())) + ' '.join('%6d' % c[k] for k in cols))
+        print('%-22s %6d  ' % (ph, sum(c.values())) + ' '.join('%6d' % c[k] for k in cols) + '   %5d' % maxv.get(ph, 0))
     print('%-22s %6d' % ('all', sum(sum(c.values()) for c in counts.values())))
 
 

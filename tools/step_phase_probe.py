@@ -21,14 +21,14 @@ ms = (time.perf_counter() - t0) * 1e3
 env._lib.mgx_engine_debug_step_clocks(env._engine, None)
 c = clk.cpu().numpy().astype(np.float64)
 names = ["ph_init_work", "ph_load_state", "ph_integrate", "ph_shapes", "ph_broad_count", "ph_broad_write", "ph_narrow",
-         "ph_arbiters_joints", "solve_begin", "solve_warm_contacts", "solve_warm_joints", "solve_iter_publish",
-         "solve_iter_contacts", "solve_iter_joints", "solve_end", "ph_cache_commit"]
+         "ph_arbiters_joints", "solve_begin", "solve_warm_contacts", "solve_warm_pg", "solve_iter_publish",
+         "solve_iter_contacts", "solve_iter_pg", "solve_end", "ph_cache_commit", "solve_warm_chain", "solve_iter_chain"]
 tot = c[:, :20].sum(axis=1).mean()
 print('%s L=%d lds=%dB: launch %.3f ms; instrumented cycles per workgroup %.0f' % (task, env.lanes_per_env, env._lib.mgx_engine_lds_bytes(env._engine, 0), ms, tot))
 tt = c[:, :20].sum(axis=1)
 print('  per-workgroup total: p50 %.0f p90 %.0f p99 %.0f max %.0f' % tuple(np.percentile(tt, [50, 90, 99, 100])))
 w = int(np.argmax(tt))
 print('  slowest workgroup:', ', '.join('%s %.0f' % (n, c[w, i]) for i, n in enumerate(names) if c[w, i] > 0.03 * tt[w]))
-for i, n in enumerate(names + ['', '', '', 'other']):
+for i, n in enumerate(names + ['', 'other']):
     if n and c[:, i].mean() > 0:
         print('  %-22s %8.0f cyc  %5.1f %%   (max %8.0f)' % (n, c[:, i].mean(), 100 * c[:, i].mean() / tot, c[:, i].max()))
