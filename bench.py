@@ -77,22 +77,18 @@ def cpu_baseline(seconds=12.0):
 CONFIG5_TASKS = ['MoveToCorner', 'MoveToRegion', 'MatchRegions', 'MakeLine', 'FindDupe', 'FixColour', 'ClusterColour', 'ClusterShape']
 
 
-def main_config5(args):
-    """BASELINE.json configs[4] / SURVEY.md section 8d config 5: the 8 Demo tasks at once, `--envs5` envs per task sharded by env index
-    over the job's GPUs (8192 / 8 = 1024 per task per GPU), every rank stepping its 8 engines concurrently on 8 HIP streams
-    (magical_amd.distributed.TaskFleet), auto-reset at each task's own episode length, and ONE all_gather of the per-env
-    scores of all tasks at the end of the rollout.  A "step" = one env-step of every task; value = env-steps/s of the job."""
+def run_config5(envs5, K, W, rank=0, world=1, device='cuda:0', dtype='f32', concurrent=True):
+    """The body of the config-5 line for one rank (also what tests/test_gpu_parity.py runs at rank size, 8 x 1024 envs): the 8 Demo
+    tasks as 8 engines on 8 HIP streams over this rank's env shard, W untimed + K timed env-steps of every task with auto-reset at each
+    task's own episode length, the last finished episode's score of every env kept, ONE gather of the [envs, 8] score table at the
+    end (inside the timed region).  Returns (scores of the whole job [envs5, 8], episodes finished on this rank, seconds)."""
     import torch
     import torch.distributed as dist
-    from magical_amd.distributed import TaskFleet, env_shard, gather_rollout_results, init_from_env
-    rank, world, local_rank = init_from_env(backend='nccl')
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    torch.cuda.set_device(local_rank)
-    device = f'cuda:{local_rank}'
-    lo, hi = env_shard(args.envs5, rank, world)
-    n, K, W = hi - lo, args.steps, args.warmup
+    from magical_amd.distributed import TaskFleet, env_shard, gather_rollout_results
+    lo, hi = env_shard(envs5, rank, world)
+    n = hi - lo
     names = [f'{t}-Demo-LoRes4E-v0' for t in CONFIG5_TASKS]
-    fleet = TaskFleet(names, n, device, seed=0, first_env=lo, dtype=args.dtype)
+    fleet = TaskFleet(names, n, device, seed=0, first_env=lo, dtype=dtype, concurrent=concurrent)
     nt = len(names)
     tapes = [torch.as_tensor(np.random.RandomState(1000 * k + rank).randint(0, 18, size=(W + K, n)).astype(np.int32), device=device) for k in range(nt)]
     fleet.reset()
@@ -100,7 +96,7 @@ def main_config5(args):
         fleet.step([tp[s] for tp in tapes])
     last = np.zeros((nt, n), dtype=np.float64)
     n_eps = 0
-    gather_rollout_results(torch.zeros((n, nt), dtype=torch.float64, device=device), args.envs5)      # RCCL warm-up
+    gather_rollout_results(torch.zeros((n, nt), dtype=torch.float64, device=device), envs5)      # RCCL warm-up
 
     def barrier():
         fleet.synchronize()
@@ -116,9 +112,28 @@ def main_config5(args):
                 n_eps += int(done.sum())
                 last[k, done] = o[3]['eval_score'][done]
     fleet.synchronize()
-    all_scores = gather_rollout_results(torch.as_tensor(last.T.copy(), device=device), args.envs5)      # [envs5, n_tasks] on every rank
+    all_scores = gather_rollout_results(torch.as_tensor(last.T.copy(), device=device), envs5)      # [envs5, n_tasks] on every rank
     barrier()
     elapsed = time.perf_counter() - t0
+    fleet.close()
+    return all_scores, n_eps, elapsed
+
+
+def main_config5(args):
+    """BASELINE.json configs[4] / SURVEY.md section 8d config 5: the 8 Demo tasks at once, `--envs5` envs per task sharded by env index
+    over the job's GPUs (8192 / 8 = 1024 per task per GPU), every rank stepping its 8 engines concurrently on 8 HIP streams
+    (magical_amd.distributed.TaskFleet), auto-reset at each task's own episode length, and ONE all_gather of the per-env
+    scores of all tasks at the end of the rollout.  A "step" = one env-step of every task; value = env-steps/s of the job."""
+    import torch
+    import torch.distributed as dist
+    from magical_amd.distributed import env_shard, init_from_env
+    rank, world, local_rank = init_from_env(backend='nccl')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    device = f'cuda:{local_rank}'
+    lo, hi = env_shard(args.envs5, rank, world)
+    n, K, W, nt = hi - lo, args.steps, args.warmup, len(CONFIG5_TASKS)
+    all_scores, n_eps, elapsed = run_config5(args.envs5, K, W, rank, world, device, args.dtype)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -134,7 +149,6 @@ def main_config5(args):
                'roofline': None, 'note': 'a step = one env-step of each of the 8 tasks; kernels of different engines overlap, so per-kernel '
                                          'roofline figures are those of the single-task lines (python bench.py --task ...)'}
         print(json.dumps(out))
-    fleet.close()
     if world > 1:
         dist.destroy_process_group()
 
