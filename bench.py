@@ -32,18 +32,32 @@ N_ENVS = 4096
 
 
 def _cpu_worker(args):
-    seed, seconds = args
+    seed, seconds, use_pymunk = args
     from oracle.env_ref import LoRes4ERef, RefEnv
     env = LoRes4ERef(RefEnv('MoveToCorner'))
     rng = np.random.RandomState(seed)
     env.reset()
+    phys = None
+    if use_pymunk:
+        # the reference's real physics engine where it can be imported (oracle/pymunk_backend.py): pymunk steps the world, the
+        # port's painter renders the poses it reached (pyglet / GL cannot be had headless here)
+        phys = RefEnv('MoveToCorner', backend='pymunk')
+        phys.reset()
     n = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        _, _, done, _ = env.step(rng.randint(18))
+        a = rng.randint(18)
+        if phys is not None:
+            _, done, _ = phys.step(a)
+            b = env.env.bodies(); b[:, :6] = phys.bodies()[:, :6]; env.env.set_bodies(b)
+            env.frames.append(env.env.render('ego')); env._obs()
+        else:
+            _, _, done, _ = env.step(a)
         n += 1
         if done:
             env.reset()
+            if phys is not None:
+                phys.reset()
     return n, time.perf_counter() - t0
 
 
@@ -64,14 +78,17 @@ def cpu_baseline(seconds=12.0):
     except Exception:
         pass
     cores = min(cores, 64)
+    from oracle import pymunk_backend
+    use_pymunk, pm_detail = pymunk_backend.probe()
     ctx = mp.get_context('spawn')
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(1000 + k, seconds) for k in range(cores)])
+        res = pool.map(_cpu_worker, [(1000 + k, seconds, use_pymunk) for k in range(cores)])
     steps = sum(r[0] for r in res)
     wall = max(r[1] for r in res)
-    return {'value': steps / wall, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{steps} env-steps of MoveToCorner-Demo-LoRes4E (oracle/ fp64 C port incl. 384x384 ego render, '
-                      f'4-frame stack, 4x4 box filter), {cores} processes x {seconds:.0f} s, random actions'}
+    what = (f'pymunk {pm_detail} physics + the oracle\'s painter' if use_pymunk else 'oracle/ fp64 C port') + ' incl. 384x384 ego render, 4-frame stack, 4x4 box filter'
+    return {'value': steps / wall, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'pymunk' if use_pymunk else 'port',
+            'sample': f'{steps} env-steps of MoveToCorner-Demo-LoRes4E ({what}), {cores} processes x {seconds:.0f} s, random actions',
+            'pymunk_importable': bool(use_pymunk)}
 
 
 CONFIG5_TASKS = ['MoveToCorner', 'MoveToRegion', 'MatchRegions', 'MakeLine', 'FindDupe', 'FixColour', 'ClusterColour', 'ClusterShape']

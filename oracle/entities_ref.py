@@ -82,8 +82,15 @@ class PhysVars:
 class RefWorld:
     """One pm.Space + gym_render.Viewer geom list (base_env.py:177-234)."""
 
-    def __init__(self, phys_vars=None, phys_iter=10):
-        self.L = lib()
+    def __init__(self, phys_vars=None, phys_iter=10, backend=None):
+        # backend 'pymunk': the same tables instantiated as real pymunk objects (oracle/pymunk_backend.py duck-types the C
+        # library's ref_* API); raises ImportError where pymunk is not importable
+        if backend == 'pymunk':
+            from .pymunk_backend import PymunkBackend
+            self.L = PymunkBackend()
+        else:
+            assert backend is None, backend
+            self.L = lib()
         self.h = self.L.ref_new()
         self.phys_vars = phys_vars or PhysVars()
         # base_env.py:194-196

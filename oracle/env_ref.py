@@ -19,10 +19,10 @@ PHYS_ITER = 10
 
 
 class RefEnv:
-    def __init__(self, task, max_episode_steps=None, gjk_warm=True, rand_dynamics=False, seed=None, **task_flags):
+    def __init__(self, task, max_episode_steps=None, gjk_warm=True, rand_dynamics=False, seed=None, backend=None, **task_flags):
         self.task_cls = TASKS[task]
         self.max_episode_steps = max_episode_steps or self.task_cls.ep_len
-        self.L = lib()
+        self.backend = backend                            # None: the C restatement; 'pymunk': oracle/pymunk_backend.py
         self.world = None
         self.task = None
         self.gjk_warm = gjk_warm
@@ -34,14 +34,14 @@ class RefEnv:
     def reset(self):
         # base_env.py:198-203: the physics variables are drawn before anything else touches the rng
         pv = PhysVars.sample(self.rng) if self.rand_dynamics else None
-        self.world = RefWorld(phys_vars=pv, phys_iter=PHYS_ITER)
+        self.world = RefWorld(phys_vars=pv, phys_iter=PHYS_ITER, backend=self.backend)
         self.L.ref_set_gjk_warm(self.world.h, 1 if self.gjk_warm else 0)
         self.arena = self.world.add(ArenaBoundaries())
         self.task = self.task_cls(self.world, rng=self.rng, **self.task_flags)
         if 'poses' in self.task.choices:
             # poses were drawn on that world; the episode runs in a fresh one built at them (placement_ref.py)
             choices = self.task.choices
-            self.world = RefWorld(phys_vars=pv, phys_iter=PHYS_ITER)
+            self.world = RefWorld(phys_vars=pv, phys_iter=PHYS_ITER, backend=self.backend)
             self.L.ref_set_gjk_warm(self.world.h, 1 if self.gjk_warm else 0)
             self.arena = self.world.add(ArenaBoundaries())
             self.task = self.task_cls(self.world, rng=None, replay=choices, **self.task_flags)
@@ -51,6 +51,10 @@ class RefEnv:
     @property
     def h(self):
         return self.world.h
+
+    @property
+    def L(self):
+        return self.world.L if self.world is not None else lib()
 
     # base_env.py:255-292 (without the render)
     def step(self, action):
