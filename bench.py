@@ -31,6 +31,51 @@ TASK = 'MoveToCorner-Demo-LoRes4E-v0'
 N_ENVS = 4096
 
 
+_RESOURCES = None
+
+
+def kernel_resources():
+    """{kernel symbol: {vgpr, agpr, sgpr_spill, vgpr_spill, scratch_bytes_per_lane, lds}} from the notes of the shipped code object
+    (llvm-readelf --notes on the gfx950 image inside libmagical_hip.so); {} where the tool is missing."""
+    global _RESOURCES
+    if _RESOURCES is not None:
+        return _RESOURCES
+    import re, struct, subprocess, tempfile
+    _RESOURCES = {}
+    try:
+        from magical_amd import _native
+        data = open(_native.LIB_PATH, 'rb').read()
+        i = data.find(b'__CLANG_OFFLOAD_BUNDLE__')
+        n = struct.unpack_from('<Q', data, i + 24)[0]
+        off = i + 32
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from('<QQQ', data, off); off += 24
+            triple = data[off:off + tl].decode(); off += tl
+            if 'gfx950' in triple:
+                with tempfile.NamedTemporaryFile(suffix='.co') as f:
+                    f.write(data[i + o:i + o + sz]); f.flush()
+                    txt = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-readelf', '--notes', f.name], capture_output=True, text=True, timeout=60).stdout
+                for blk in txt.split('- .agpr_count:')[1:]:
+                    g = lambda k: int(re.search(r'\.' + k + r':\s+(\d+)', blk).group(1))
+                    name = re.search(r'\.name:\s+(\S+)', blk).group(1)
+                    _RESOURCES[name] = {'vgpr': g('vgpr_count'), 'agpr': int(blk.split()[0]), 'sgpr_spill': g('sgpr_spill_count'), 'vgpr_spill': g('vgpr_spill_count'),
+                                        'scratch_bytes_per_lane': g('private_segment_fixed_size')}
+    except Exception:
+        pass
+    return _RESOURCES
+
+
+def scratch_bytes(kernel, n_envs, lanes_per_env):
+    """Static scratch footprint of one launch: private segment bytes per lane x lanes launched (step: n_envs x lanes_per_env;
+    raster: 256 per env), for the instantiation the default workload uses; None if the code object cannot be read."""
+    res = kernel_resources()
+    want = ('k_stepIfdLi%d' % lanes_per_env) if kernel == 'k_step' else 'k_rasterIdLi1ELi5'
+    for name, r in res.items():
+        if want in name and 'deferred' not in name:
+            return r['scratch_bytes_per_lane'] * (n_envs * lanes_per_env if kernel == 'k_step' else n_envs * 256)
+    return None
+
+
 def _cpu_worker(args):
     seed, seconds, use_pymunk = args
     from oracle.env_ref import LoRes4ERef, RefEnv
@@ -183,33 +228,11 @@ def window_plan(K, W, ep, n):
     return preroll, share, ahead
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=400)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--task', default=TASK)
-    ap.add_argument('--envs', type=int, default=N_ENVS)
-    ap.add_argument('--lanes', type=int, default=0)
-    ap.add_argument('--dtype', default='f32')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--obs-ring', type=int, default=0, help='with a -LoResCHW4E- task: frames kept as planes in a ring of this many frames '
-                    '(MGX_OBS_PLANAR; the channels-first stack is a window of the ring), priced on the 28.3 KB row of SURVEY.md 8(d)')
-    ap.add_argument('--config5', action='store_true', help='BASELINE.json configs[4]: all 8 tasks x Demo-LoRes4E, --envs5 envs per task sharded over '
-                                                           'the GPUs, one engine + HIP stream per task on every GPU, one RCCL gather at the end')
-    ap.add_argument('--envs5', type=int, default=8192, help='envs per task over the whole job (config 5)')
-    args = ap.parse_args()
-    if args.config5:
-        return main_config5(args)
-
+def measure(args, rank, world, device):
+    """One bench line: W untimed + K timed env-steps of args.task at args.envs envs per GPU.  Returns the line's dict on rank 0."""
     import torch
     import torch.distributed as dist
-    from magical_amd.distributed import gather_rollout_results, init_from_env
-    rank, world, local_rank = init_from_env(backend='nccl')      # "nccl" == RCCL on ROCm
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    torch.cuda.set_device(local_rank)
-    device = f'cuda:{local_rank}'
-
+    from magical_amd.distributed import gather_rollout_results
     import magical_amd
     env = magical_amd.make(args.task, n_envs=args.envs, device=device, lanes_per_env=args.lanes, dtype=args.dtype, obs_ring=args.obs_ring)
     ring = bool(args.obs_ring) and '-LoResCHW4E-' in args.task
@@ -281,6 +304,7 @@ def main():
         env.overlap = True
     env.set_timing(0)
 
+    out = None
     if rank == 0:
         value = n * world * K / elapsed
         # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): persistent state read once + written once;
@@ -313,6 +337,33 @@ def main():
                     break
                 except Exception:
                     continue
+        # what bounds the kernel, from the SQ counter passes of the same command (profiles/rNN_pmc_alu_*.json, tools/pmc_alu_summary.py;
+        # like `traffic`, collected by rocprofv3 outside this process and committed): VALU issue utilisation against the dense vector
+        # peak, resident wavefronts per SIMD, share of wave-cycles parked on s_waitcnt / stalled at issue, scratch footprint
+        alu, alu_src = None, None
+        if key and n == N_ENVS and args.dtype == 'f32':
+            for rnd in ('r03',):
+                pa = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_alu_{key}.json')
+                try:
+                    alu = json.load(open(pa))
+                    alu_src = f'profiles/{rnd}_pmc_alu_{key}.json (rocprofv3 --pmc, three passes of eight SQ counters, kernels one after the other)'
+                    break
+                except Exception:
+                    continue
+        def alu_fields(kname):
+            d = ((alu or {}).get(kname) or {}).get('derived') or {}
+            return {k: d.get(k) for k in ('valu_util', 'valu_busy', 'occupancy_waves_per_simd', 'wait_share', 'issue_stall_share', 'active_share',
+                                          'lds_conflict_share', 'valu_insts_per_wave')}
+        def bound_of(kname):
+            # HBM-bound only if the counters' traffic moves at more than half the achievable copy rate; else what the SQ counters show
+            f = alu_fields(kname)
+            if traffic and kname == dom and traffic / (kernels[dom][0] * 1e-3) / 1e9 > 0.5 * 6300:
+                return 'hbm'
+            if f.get('valu_util') is None:
+                return 'hbm (nominal: no SQ counter pass committed for this workload)'
+            if f['valu_util'] > 0.5:
+                return 'valu'
+            return 'latency (issue: one dependent instruction stream per wavefront; VALU and HBM both far from their peaks)'
         # SURVEY.md §8(d) has two byte rows for the LoRes4E env-step: the headline one (state + ONE new 96x96x3 frame,
         # 28.3 KB: what a ring of frames would move) and the parenthetical one this layout really needs (the contiguous
         # [96,96,12] stack re-materialised: 9 B read + 12 B written per pixel, 194 KB).  `frac` prices the kernel against the
@@ -340,8 +391,9 @@ def main():
                        'roofline_bytes_row': 'SURVEY.md 8(d) headline row: state + ONE new 96x96x3 frame per env-step (ring of planar frames)' if ring else
                                              'SURVEY.md 8(d) parenthetical row: [96,96,12] stack re-materialised each step (9 B read + 12 B '
                                              'written per pixel + pose rows); frac_new_frame_row uses the 28.3 KB headline row'},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'roofline': {'bound': bound_of(dom), 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         **alu_fields(dom), 'alu_source': alu_src, 'scratch_bytes': scratch_bytes(dom, n, env.lanes_per_env),
                          'frac_new_frame_row': (ring_bytes / (kernels[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom == 'k_raster' else None,
                          'launch_mode': ('fused: k_raster runs concurrently with k_step and consumes envs as they finish, so its launch duration '
                                          'includes hand-off waits' if alone_ms else 'one kernel after the other'),
@@ -350,12 +402,65 @@ def main():
                              'avg_launch_ms': alone_ms, 'frac': kernels[dom][1] / (alone_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          'avg_launch_ms': kernels[dom][0], 'algorithmic_bytes_per_launch': kernels[dom][1],
                          'other_kernels': {k: {'avg_launch_ms': v[0], 'algorithmic_bytes_per_launch': v[1],
-                                               'achieved_GBs': v[1] / (v[0] * 1e-3) / 1e9} for k, v in kernels.items() if k != dom}},
+                                               'achieved_GBs': v[1] / (v[0] * 1e-3) / 1e9, 'bound': bound_of(k), **alu_fields(k),
+                                               'scratch_bytes': scratch_bytes(k, n, env.lanes_per_env)} for k, v in kernels.items() if k != dom}},
         }
+    env.close()
+    return out if rank == 0 else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=400)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--task', default=TASK)
+    ap.add_argument('--envs', type=int, default=N_ENVS)
+    ap.add_argument('--lanes', type=int, default=0)
+    ap.add_argument('--dtype', default='f32')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='default line only: skip the two short secondary lines (all-fp64 build, ClusterColour)')
+    ap.add_argument('--obs-ring', type=int, default=0, help='with a -LoResCHW4E- task: frames kept as planes in a ring of this many frames '
+                    '(MGX_OBS_PLANAR; the channels-first stack is a window of the ring), priced on the 28.3 KB row of SURVEY.md 8(d)')
+    ap.add_argument('--config5', action='store_true', help='BASELINE.json configs[4]: all 8 tasks x Demo-LoRes4E, --envs5 envs per task sharded over '
+                                                           'the GPUs, one engine + HIP stream per task on every GPU, one RCCL gather at the end')
+    ap.add_argument('--envs5', type=int, default=8192, help='envs per task over the whole job (config 5)')
+    args = ap.parse_args()
+    if args.config5:
+        return main_config5(args)
+
+    import torch
+    import torch.distributed as dist
+    from magical_amd.distributed import gather_rollout_results, init_from_env
+    rank, world, local_rank = init_from_env(backend='nccl')      # "nccl" == RCCL on ROCm
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    device = f'cuda:{local_rank}'
+
+    out = measure(args, rank, world, device)
+    if rank == 0:
+        # Driver-executed, outside the headline's timed region: the reference-precision build and BASELINE.json configs[3]
+        # (ClusterColour, many contacts) on short windows with the same window plan -- so that these lines are not builder-run only
+        default_line = (world == 1 and args.task == TASK and args.dtype == 'f32' and args.envs == N_ENVS and not args.obs_ring and not args.lanes)
+        if default_line and not args.no_secondary:
+            import copy
+            sec = {}
+            for key, over in (('f64', {'dtype': 'f64'}), ('clustercolour', {'task': 'ClusterColour-Demo-LoRes4E-v0'})):
+                a2 = copy.copy(args)
+                a2.steps, a2.warmup = 40, 5
+                for k, v in over.items():
+                    setattr(a2, k, v)
+                try:
+                    o2 = measure(a2, rank, world, device)
+                    sec[f'{key}_env_steps_per_s'] = o2['value']
+                    sec[key] = {'task': a2.task, 'dtype': a2.dtype, 'steps': a2.steps, 'warmup': a2.warmup, 'ms_per_step': o2['ms_per_step'],
+                                'episodes_finished': o2['config']['episodes_finished'], 'roofline': o2['roofline']}
+                except Exception as ex:          # the headline must not be lost to a secondary line
+                    sec[key] = {'error': f'{type(ex).__name__}: {ex}'}
+            out['secondary'] = sec
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    env.close()
     if world > 1:
         dist.destroy_process_group()
 

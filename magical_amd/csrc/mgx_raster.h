@@ -114,7 +114,7 @@ MGX_HD void raster_setup_bodies(Raster &rs, const P *sp, long stride, long env, 
             if (row >= 0) v[c] = (double)sp[(long)row * stride + env];
         }
         double s, c;
-        r_sincos<double>(v[2], s, c);
+        r_sincos_lib(v[2], s, c);
         RD(bx, b) = v[0]; RD(by, b) = v[1]; RD(ba, b) = v[2]; RD(bc, b) = c; RD(bs, b) = s;
     }
 }
@@ -186,7 +186,7 @@ MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_
         double da = 0.0, dc = 1.0, ds = 0.0;
         if (xf == XF_EYE && eye_body >= 0) {
             da = RD(ba, eye_body) - RD(ba, body);
-            r_sincos<double>(da, ds, dc);
+            r_sincos_lib(da, ds, dc);
         }
         // centre = image of the local origin; phase = world angle of vertex 0 minus camera rotation
         double lx = 0.0, ly = 0.0;
@@ -333,7 +333,7 @@ MGX_HD bool ngon_contains(const Raster &rs, int k, double x, double y) {
     double th = atan2(qy, qx) - RD(pphi, k);
     double kk = rz_floor(th / step);
     double mid = RD(pphi, k) + (kk + 0.5) * step, s, c;
-    r_sincos<double>(mid, s, c);
+    r_sincos_lib(mid, s, c);
     return qx * c + qy * s <= apo;
 }
 // max coverage alpha of a smooth line loop at a sample; OUR model of GL_LINE_SMOOTH (driver-defined):

@@ -28,6 +28,9 @@ template <> MGX_HD float r_sqrt<float>(float x) { return sqrtf(x); }
 template <> MGX_HD double r_sqrt<double>(double x) { return sqrt(x); }
 template <typename R> MGX_HD void r_sincos(R a, R &s, R &c);
 template <> MGX_HD void r_sincos<float>(float a, float &s, float &c) { s = sinf(a); c = cosf(a); }
+// the library's sincos, whatever r_sincos<double> is below: the rasteriser's set-up keeps it (three call sites once per frame:
+// inlining the short form there costs the 96-register variant 30 more spilled registers)
+MGX_HD void r_sincos_lib(double a, double &s, double &c) { s = sin(a); c = cos(a); }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_LIBM_SINCOS)
 // cpvforangle for the pose type, once per body and substep.  The library's sincos spends ~220 fp64 instructions on one lane
 // group's six angles (Payne-Hanek path and all); body angles stay within a few thousand radians, so: Cody-Waite reduction

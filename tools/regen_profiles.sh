@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-measure the round's profile set on the GPU box (run through gpurun from the repo root:
-#   gpurun --timeout 3600 -- 'bash tools/regen_profiles.sh r02'); results land in gpurun_out/final/, to be copied into profiles/.
-R=${1:-r02}
+#   gpurun --timeout 3600 -- 'bash tools/regen_profiles.sh r03'); results land in gpurun_out/final/, to be copied into profiles/.
+R=${1:-r03}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/final; rm -rf $O; mkdir -p $O
@@ -33,6 +33,18 @@ for t in mtc cc; do
     MGX_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $c -f csv -d /tmp/pmc_${t}_$c -o run -- $B --no-cpu-baseline --steps 100 --task $task > /dev/null 2>&1
   done
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pmc_${t}_FETCH_SIZE /tmp/pmc_${t}_WRITE_SIZE > $O/${R}_pmc_traffic_${t}_lores4e.json
+done
+# what bounds the kernels: SQ counters, three passes of eight (tools/pmc_alu_summary.py), kernels one after the other
+PA=SQ_WAVES,SQ_WAVE_CYCLES,SQ_BUSY_CU_CYCLES,SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_INSTS_VALU
+PB=SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_INSTS_VMEM,SQ_INSTS_FLAT_FLATSEG,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_ACTIVE_INST_LDS,SQ_ACTIVE_INST_SCA
+PC=SQ_THREAD_CYCLES_VALU,SQ_INSTS_VALU_FMA_F32,SQ_INSTS_VALU_FMA_F64,SQ_INSTS_VALU_ADD_F64,SQ_INSTS_VALU_MUL_F64,SQ_INSTS_SMEM,SQ_INSTS_BRANCH,SQ_INSTS_VALU_TRANS_F32
+for t in mtc cc; do
+  task=MoveToCorner-Demo-LoRes4E-v0; [ $t = cc ] && task=$CC
+  for p in A B C; do
+    eval set=\$P$p
+    MGX_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc ${set//,/ } -f csv -d /tmp/alu_${t}_$p -o run -- $B --no-cpu-baseline --no-secondary --steps 60 --task $task > /dev/null 2>&1
+  done
+  python $GRAFT_REPO_ROOT/tools/pmc_alu_summary.py /tmp/alu_${t}_A /tmp/alu_${t}_B /tmp/alu_${t}_C > $O/${R}_pmc_alu_${t}_lores4e.json
 done
 cd $GRAFT_REPO_ROOT
 timeout 1500 python tools/rollout_all_tasks.py --variant all --envs 4096 > $O/${R}_rollout_all_60_variants_4096x1gpu.jsonl 2>> $O/err.txt
