@@ -32,7 +32,8 @@ struct RasterDev {
     const double *goal_xyhw_env;   // [n_goals * 4][n_envs] per-env goal rectangles x, y (top-left), h, w (NULL: the template's)
     int tq_hbm;                    // the draw list's fp64 part is not staged in LDS: the set-up reads it from HBM (the host's choice)
     int compact;                   // draw-list vertex records without the edge-function coefficients (RasterOff; the host's choice)
-    int qcap;                      // queue entries in use (<= QCAP; tests shrink it to exercise the overflow rounds)
+    int qcap;                      // queue entries in use (<= qcap_lds; tests shrink it to exercise the overflow rounds)
+    int qcap_lds;                  // queue entries the LDS layout holds (<= QCAP; the host's choice by world, configure_launch)
     int ecap;                      // phase E records in use (<= ECAP; likewise)
 };
 
@@ -64,7 +65,9 @@ __device__ __forceinline__ int raster_staged_words(const RasterDev &t, const uin
 __device__ __forceinline__ const double *raster_tq(const RasterDev &t, const uint32_t *blob, const uint32_t *lds, const TmplHeader &h) {
     return reinterpret_cast<const double *>((t.tq_hbm ? blob : lds) + raster_off_q(h, t.off_i));
 }
-constexpr int QCAP = 1024;     // LDS queue of undecided pixels per env; what does not fit waits in a bitmap for another round
+constexpr int QCAP = 1024;     // LDS queue of undecided pixels per env (largest layout); what does not fit waits in a bitmap for another round
+constexpr int QCAP_SMALL = 640;   // ... of the worlds without a goal region and with at most one block (MoveToCorner: 440 queued pixels per frame
+                                  // at the median, 550 at p99.9, 660 at most over 2 x 10^5 frames, tools/dev/nq_stats.py): 6 KB less LDS
 constexpr int OVF_WORDS = LORES * LORES / 32;
 constexpr int ECAP = 256;      // phase E records per round (uncertain pixels beyond that wait in the bitmap like queue overflow)
 // k_raster is instantiated for 3, 4 and 5 workgroups per CU (= waves per SIMD: VGPR caps 168 / 128 / 96); the host picks
@@ -273,11 +276,12 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
 #define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + (i)] = wall_clock64() - clk0;
 #endif
     long env = blockIdx.x;
+    if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + 9] = clk0;        // (absolute: tools/dev/fused_timeline.py)
     // the shared draw list does not depend on the env: stage it before waiting for the hand-off
     if (!t.tmpl_stride_words) { const int n = raster_staged_words(t, t.words); for (int i = tid; i < n; i += 256) lds[i] = t.words[i]; }
     if (ho.mode) {
         // one lane waits / decides, one agent-scope acquire per workgroup, then plain loads (cdna guide, G16)
-        int32_t *slot = reinterpret_cast<int32_t *>(lds + t.lds_tmpl_words + t.off_tiles) + (N_TILES * 3 + QCAP * 4 + 5);    // = q_count[5], unused below
+        int32_t *slot = reinterpret_cast<int32_t *>(lds + t.lds_tmpl_words + t.off_tiles) + (N_TILES * 3 + t.qcap_lds * 4 + 5);    // = q_count[5], unused below
         if (tid == 0) {
             long got = -1;
             if (ho.mode == 1) {
