@@ -536,7 +536,7 @@ template <typename R, typename P, int L>
 static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const int32_t *actions, uint8_t *done, int n_sub,
                          int count_step, hipStream_t st, const StepHandoff &ho) {
     void (*kern)(TmplDev, P *, R *, int32_t *, const int32_t *, uint8_t *, int, int, int, int, StepHandoff);
-    if constexpr (L == 64) kern = k_step_env<R, P>; else kern = k_step<R, P, L>;
+    if constexpr (L == 64) kern = k_step_env<R, P>; else if constexpr (sizeof(R) == 8) kern = k_step_wide<R, P, L>; else kern = k_step<R, P, L>;
     size_t lds = step_lds_bytes(e, L);
     if (int rc = ensure_lds((const void *)kern, lds, e->device)) return rc;
     int epb = 64 / L, blocks = (e->n_envs + epb - 1) / epb;

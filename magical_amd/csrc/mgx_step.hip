@@ -191,6 +191,13 @@ __global__ __launch_bounds__(64, MGX_LN_WAVES) MGX_STEP_VGPR_ATTR void k_step(Tm
                                                                               int n_envs, int n_sub, int count_step, int iterations, StepHandoff ho) {
     step_body<R, P, L>(t, sp, sf, si, actions, done, n_envs, n_sub, count_step, iterations, ho);
 }
+// (the all-fp64 validation build keeps the whole register file: at 224 its solver would run out of scratch memory)
+template <typename R, typename P, int L>
+__global__ __launch_bounds__(64, MGX_LN_WAVES) void k_step_wide(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,
+                                                                const int32_t *__restrict__ actions, uint8_t *__restrict__ done,
+                                                                int n_envs, int n_sub, int count_step, int iterations, StepHandoff ho) {
+    step_body<R, P, L>(t, sp, sf, si, actions, done, n_envs, n_sub, count_step, iterations, ho);
+}
 // ... and one env per wavefront (the per-env-world mode)
 template <typename R, typename P>
 __global__ __launch_bounds__(64, MGX_L64_WAVES) void k_step_env(TmplDev t, P *__restrict__ sp, R *__restrict__ sf, int32_t *__restrict__ si,

@@ -6,31 +6,32 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/final; rm -rf $O; mkdir -p $O
 B="python $GRAFT_REPO_ROOT/bench.py"
+NS="--no-cpu-baseline --no-secondary"
 CC=ClusterColour-Demo-LoRes4E-v0
 timeout 600 $B > $O/${R}_bench_mtc_lores4e.json 2> $O/err.txt
 timeout 300 $B --steps 20 --warmup 5 --no-cpu-baseline > $O/${R}_bench_mtc_lores4e_20steps.json 2>> $O/err.txt
-MGX_NO_OVERLAP=1 timeout 300 $B --no-cpu-baseline > $O/${R}_bench_mtc_lores4e_serial.json 2>> $O/err.txt
-timeout 300 $B --no-cpu-baseline --task $CC > $O/${R}_bench_clustercolour_lores4e.json 2>> $O/err.txt
-MGX_NO_OVERLAP=1 timeout 300 $B --no-cpu-baseline --task $CC > $O/${R}_bench_clustercolour_lores4e_serial.json 2>> $O/err.txt
-timeout 300 $B --no-cpu-baseline --task MoveToCorner-Demo-v0 > $O/${R}_bench_mtc_state_only.json 2>> $O/err.txt
-timeout 300 $B --no-cpu-baseline --dtype f64 > $O/${R}_bench_mtc_lores4e_f64.json 2>> $O/err.txt
-timeout 300 $B --no-cpu-baseline --dtype f64 --task $CC > $O/${R}_bench_clustercolour_lores4e_f64.json 2>> $O/err.txt
-timeout 300 $B --no-cpu-baseline --task MoveToCorner-Demo-LoResCHW4E-v0 --obs-ring 35 > $O/${R}_bench_mtc_loreschw4e_ring35.json 2>> $O/err.txt
-timeout 300 $B --no-cpu-baseline --task MoveToCorner-Demo-LoResCHW4E-v0 > $O/${R}_bench_mtc_loreschw4e_inplace_stack.json 2>> $O/err.txt
+MGX_NO_OVERLAP=1 timeout 300 $B $NS > $O/${R}_bench_mtc_lores4e_serial.json 2>> $O/err.txt
+timeout 300 $B $NS --task $CC > $O/${R}_bench_clustercolour_lores4e.json 2>> $O/err.txt
+MGX_NO_OVERLAP=1 timeout 300 $B $NS --task $CC > $O/${R}_bench_clustercolour_lores4e_serial.json 2>> $O/err.txt
+timeout 300 $B $NS --task MoveToCorner-Demo-v0 > $O/${R}_bench_mtc_state_only.json 2>> $O/err.txt
+timeout 300 $B $NS --dtype f64 > $O/${R}_bench_mtc_lores4e_f64.json 2>> $O/err.txt
+timeout 300 $B $NS --dtype f64 --task $CC > $O/${R}_bench_clustercolour_lores4e_f64.json 2>> $O/err.txt
+timeout 300 $B $NS --task MoveToCorner-Demo-LoResCHW4E-v0 --obs-ring 35 > $O/${R}_bench_mtc_loreschw4e_ring35.json 2>> $O/err.txt
+timeout 300 $B $NS --task MoveToCorner-Demo-LoResCHW4E-v0 > $O/${R}_bench_mtc_loreschw4e_inplace_stack.json 2>> $O/err.txt
 timeout 600 $B --config5 --envs5 1024 > $O/${R}_bench_config5_1gpu_8x1024.json 2>> $O/err.txt
 cd /tmp
 # kernel-trace statistics of the same commands (fused, one-after-the-other, ClusterColour)
-rocprofv3 --kernel-trace --stats -f csv -d /tmp/p1 -o mtc -- $B --no-cpu-baseline > $O/${R}_bench_mtc_lores4e_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats -f csv -d /tmp/p1 -o mtc -- $B $NS > $O/${R}_bench_mtc_lores4e_under_rocprof.json 2> /dev/null
 cp /tmp/p1/mtc_kernel_stats.csv $O/${R}_bench_mtc_lores4e_kernel_stats.csv
-MGX_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -f csv -d /tmp/p3 -o mtcs -- $B --no-cpu-baseline > /dev/null 2>&1
+MGX_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -f csv -d /tmp/p3 -o mtcs -- $B $NS > /dev/null 2>&1
 cp /tmp/p3/mtcs_kernel_stats.csv $O/${R}_bench_mtc_lores4e_serial_kernel_stats.csv
-rocprofv3 --kernel-trace --stats -f csv -d /tmp/p2 -o cc -- $B --no-cpu-baseline --task $CC > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d /tmp/p2 -o cc -- $B $NS --task $CC > /dev/null 2>&1
 cp /tmp/p2/cc_kernel_stats.csv $O/${R}_bench_cc_lores4e_kernel_stats.csv
 # HBM traffic: one counter per pass, kernel-trace only (MI355X_MICROARCH.md); kernels one after the other
 for t in mtc cc; do
   task=MoveToCorner-Demo-LoRes4E-v0; [ $t = cc ] && task=$CC
   for c in FETCH_SIZE WRITE_SIZE; do
-    MGX_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $c -f csv -d /tmp/pmc_${t}_$c -o run -- $B --no-cpu-baseline --steps 100 --task $task > /dev/null 2>&1
+    MGX_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $c -f csv -d /tmp/pmc_${t}_$c -o run -- $B $NS --steps 100 --task $task > /dev/null 2>&1
   done
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pmc_${t}_FETCH_SIZE /tmp/pmc_${t}_WRITE_SIZE > $O/${R}_pmc_traffic_${t}_lores4e.json
 done
