@@ -329,7 +329,7 @@ def measure(args, rank, world, device):
         traffic, traffic_src = None, None
         key = {TASK: 'mtc_lores4e', 'ClusterColour-Demo-LoRes4E-v0': 'cc_lores4e'}.get(args.task)
         if key and n == N_ENVS and args.dtype == 'f32':
-            for rnd in ('r02', 'r01'):
+            for rnd in ('r03', 'r02', 'r01'):
                 pmc = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_traffic_{key}.json')
                 try:
                     traffic = float(json.load(open(pmc))[dom]['hbm_traffic_bytes_per_launch'])
@@ -361,9 +361,9 @@ def measure(args, rank, world, device):
                 return 'hbm'
             if f.get('valu_util') is None:
                 return 'hbm (nominal: no SQ counter pass committed for this workload)'
-            if f['valu_util'] > 0.5:
-                return 'valu'
-            return 'latency (issue: one dependent instruction stream per wavefront; VALU and HBM both far from their peaks)'
+            if (f.get('valu_busy') or 0) > 0.6:
+                return 'valu (the SIMDs have a vector instruction in flight in most busy cycles; HBM far from its peak)'
+            return 'latency (one dependent instruction stream per wavefront, waiting on LDS for much of it; VALU and HBM both far from their peaks)'
         # SURVEY.md §8(d) has two byte rows for the LoRes4E env-step: the headline one (state + ONE new 96x96x3 frame,
         # 28.3 KB: what a ring of frames would move) and the parenthetical one this layout really needs (the contiguous
         # [96,96,12] stack re-materialised: 9 B read + 12 B written per pixel, 194 KB).  `frac` prices the kernel against the
