@@ -110,6 +110,29 @@ template <typename R> MGX_HD void anchor_rot(R c, R s, R ax, R ay, R &rx, R &ry)
     ry = r_add_nc(r_mul_nc(c, ay), r_mul_nc(s, ax));
 }
 
+// 1 / x.  The fp32 device build takes v_rcp_f32 (1 ulp) instead of the correctly rounded division's ten instructions: the
+// effective masses it feeds are rounded to fp32 anyway, like everything downstream of them.
+template <typename R> MGX_HD R r_rcp(R x) { return R(1) / x; }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_NO_FAST_MINMAX)
+template <> MGX_HD float r_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+// length and inverse length of a pose-precision vector whose direction is consumed in fp32 (the pin joints' axis): v_rsq_f64 and
+// one Newton step (relative error ~1e-15) instead of a correctly rounded fp64 sqrt and division (~55 fp64 instructions).  The
+// all-fp64 build keeps the exact forms.  inv = 0 for a zero vector (cpvnormalize of cpvzero).
+template <typename R, typename P> MGX_HD void p_len_inv(P d2, P &len, P &inv) {
+    len = r_sqrt<P>(d2);
+    inv = len != P(0) ? P(1) / len : P(0);
+}
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_NO_FAST_MINMAX)
+template <> MGX_HD void p_len_inv<float, double>(double d2, double &len, double &inv) {
+    double y = __builtin_amdgcn_rsq(d2);
+    y = y * __builtin_fma(-0.5 * d2 * y, y, 1.5);
+    const bool pos = d2 > 0.0;
+    inv = pos ? y : 0.0;
+    len = pos ? d2 * y : 0.0;
+}
+#endif
+
 // cpvclamp(v, lim): v scaled back to length lim when longer.  The fp32 device build is branch-free with v_rsq_f32 (1 ulp)
 // instead of a correctly rounded sqrt and division (37 instructions, and the solver runs it in every iteration for the
 // robot's pivot and every sliding block's); a scale of exactly 1 leaves an unclamped vector as it is.
@@ -199,45 +222,53 @@ template <typename R, typename P> MGX_HD void ph_shapes(Env<R, P> &e, int lane, 
         int b = T_I(shape_body, sh), vo = T_I(shape_voff, sh), nv = T_I(shape_nv, sh);
         R bx = R(E_P(px, b)), by = R(E_P(py, b)), c = R(E_P(c, b)), s = R(E_P(s, b)), rad = T_R(shape_r, sh);
         R l = r_inf<R>(), r = -r_inf<R>(), bo = r_inf<R>(), t = -r_inf<R>();
+        // (the next vertex's local record is in flight while this one is transformed and stored: the loop would otherwise pay one
+        // LDS round trip per vertex on a wavefront that has nothing else to run)
+        R lx = T_R(lvx, vo), ly = T_R(lvy, vo), nx = T_R(lnx, vo), ny = T_R(lny, vo);
         for (int i = 0; i < nv; i++) {
-            R lx = T_R(lvx, vo + i), ly = T_R(lvy, vo + i);
+            const int in = i + 1 < nv ? i + 1 : i;
+            const R lx1 = T_R(lvx, vo + in), ly1 = T_R(lvy, vo + in), nx1 = T_R(lnx, vo + in), ny1 = T_R(lny, vo + in);
             R x = bx + (c * lx - s * ly), y = by + (c * ly + s * lx);
             E_R(wx, vo + i) = x; E_R(wy, vo + i) = y;
-            R nx = T_R(lnx, vo + i), ny = T_R(lny, vo + i);
             E_R(wnx, vo + i) = c * nx - s * ny; E_R(wny, vo + i) = c * ny + s * nx;
             l = r_min(l, x); r = r_max(r, x); bo = r_min(bo, y); t = r_max(t, y);
+            lx = lx1; ly = ly1; nx = nx1; ny = ny1;
         }
         E_R(bbl, sh) = l - rad; E_R(bbb, sh) = bo - rad; E_R(bbr, sh) = r + rad; E_R(bbt, sh) = t + rad;
     }
 }
 
 // ---------------------------------------------------------------- phase: broadphase
-// The candidate list already encodes QueryReject's body/group filters; what is left per substep is
-// the BB test.  Each lane owns a contiguous chunk so that the compacted list keeps pair order
-// (= arbiter solve order).
-template <typename R, typename P> MGX_HD void ph_broad_count(Env<R, P> &e, int lane, int nl) {
-    int np = e.h->n_pairs, chunk = (np + nl - 1) / nl;
-    int p0 = lane * chunk, p1 = p0 + chunk < np ? p0 + chunk : np;
-    uint8_t *flag = reinterpret_cast<uint8_t *>(&E_I(flag, 0));
-    int count = 0;
-    for (int p = p0; p < p1; p++) {
-        int pr = T_I(pair, p), a = pr & 0xFF, b = pr >> 8;
-        bool hit = E_R(bbl, a) <= E_R(bbr, b) && E_R(bbl, b) <= E_R(bbr, a) &&
-                   E_R(bbb, a) <= E_R(bbt, b) && E_R(bbb, b) <= E_R(bbt, a);
-        flag[p] = hit ? 1 : 0;
-        count += hit ? 1 : 0;
-    }
-    E_I(cnt, lane) = count;
+// The candidate list already encodes QueryReject's body/group filters; what is left per substep is the BB test, and the
+// overlapping pairs compacted IN PAIR ORDER (= arbiter solve order).  Device: the group's lanes test nl consecutive pairs at a
+// time; a wavefront ballot gives every lane the hits of its group, so a pair's place in the list is the running total plus the
+// hits of the lanes before it -- one phase, no LDS counters, no flags (round 2 counted per lane chunk, synchronised, then wrote).
+template <typename R, typename P> MGX_HD bool pair_boxes_overlap(const Env<R, P> &e, int p) {
+    const int pr = T_I(pair, p), a = pr & 0xFF, b = pr >> 8;
+    return E_R(bbl, a) <= E_R(bbr, b) && E_R(bbl, b) <= E_R(bbr, a) && E_R(bbb, a) <= E_R(bbt, b) && E_R(bbb, b) <= E_R(bbt, a);
 }
-template <typename R, typename P> MGX_HD void ph_broad_write(Env<R, P> &e, int lane, int nl) {
-    int np = e.h->n_pairs, chunk = (np + nl - 1) / nl;
-    int p0 = lane * chunk, p1 = p0 + chunk < np ? p0 + chunk : np;
-    const uint8_t *flag = reinterpret_cast<const uint8_t *>(&E_I(flag, 0));
-    int off = 0, total = 0;
-    for (int l = 0; l < nl; l++) { int c = E_I(cnt, l); if (l < lane) off += c; total += c; }
-    int cap = e.h->max_overlaps;
-    for (int p = p0; p < p1; p++)
-        if (flag[p]) { if (off < cap) E_I(ov, off) = p; off++; }
+template <typename R, typename P> MGX_HD void ph_broad(Env<R, P> &e, int lane, int nl) {
+    const int np = e.h->n_pairs, cap = e.h->max_overlaps;
+    int total = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (n_pairs is the same for every lane of the wavefront: envs of one world, or one env per wavefront)
+    const int wave_lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int shift = wave_lane - lane;
+    const unsigned long long group_mask = nl >= 64 ? ~0ull : ((1ull << nl) - 1ull);
+    for (int base = 0; base < np; base += nl) {
+        const int p = base + lane;
+        const bool hit = p < np && pair_boxes_overlap(e, p);
+        const unsigned long long hits = (__builtin_amdgcn_ballot_w64(hit) >> shift) & group_mask;
+        const int pos = total + __builtin_popcountll(hits & ((1ull << lane) - 1ull));
+        if (hit && pos < cap) E_I(ov, pos) = p;
+        total += __builtin_popcountll(hits);
+    }
+#else
+    // host emulation (lanes run one after the other): lane 0 does the whole list
+    if (lane != 0) return;
+    for (int p = 0; p < np; p++)
+        if (pair_boxes_overlap(e, p)) { if (total < cap) E_I(ov, total) = p; total++; }
+#endif
     if (lane == 0) {
         if (total > cap) { E_I(misc, M_OVERFLOW) += 1; total = cap; }
         E_I(misc, M_NOV) = total;
@@ -505,6 +536,7 @@ template <typename R> struct SolveCtx {
     R lim_im[2], lim_b[2], lim_lo[2], lim_hi[2], lim_max[2];     // finger limits: effective mass, clamp range of the accumulated impulse
     R mot_im[2], mot_rate[2], mot_lim[2];              // finger motors
     R acc[8];                                          // springs' target_wrn (2) | per finger: pin, limit, motor impulses
+    int b_robot, b_eye[2], b_finger[2];                // body indices (read from the header once per env-step, not before every access)
     int has_contacts;
 #if !defined(__HIP_DEVICE_COMPILE__)
     const SolveCtx *row;                               // host emulation: the 16 contexts of this lane's row
@@ -533,24 +565,16 @@ template <typename R, typename P> MGX_HD void joints_prestep(Env<R, P> &e, Solve
     (void)nl;
     const int rowlane = lane & (ROW - 1);
     if (c.mj >= 0) {
+        // both anchors of these pivots are body origins (Robot.setup's pair to the control body, entities.py:255-258; a block's pair
+        // to the static body, :703-707): r1 = r2 = 0, K = (m_a^-1 + m_b^-1) I is a constant of the env-step (solve_ctx_init), and
+        // the bias is the clamped position error -- zero whenever max_bias is 0, which it is in every world the reference builds
         const int j = c.mj, a = T_I(joint_a, j), b = c.mbody;
         const R *p = &T_R(joint_p, j * JOINT_PARAMS);
-        const P *pp = &T_P(p_joint, j * 7);
-        P q1x, q1y, q2x, q2y;
-        anchor_rot<P>(E_P(c, a), E_P(s, a), pp[0], pp[1], q1x, q1y);
-        anchor_rot<P>(E_P(c, b), E_P(s, b), pp[2], pp[3], q2x, q2y);
-        const R r1x = R(q1x), r1y = R(q1y), r2x = R(q2x), r2y = R(q2y);
-        const P ddx = r_add_nc<P>(E_P(px, b), q2x) - r_add_nc<P>(E_P(px, a), q1x);
-        const P ddy = r_add_nc<P>(E_P(py, b), q2y) - r_add_nc<P>(E_P(py, a), q1y);
-        const R ma = T_R(body_minv, a), ia = T_R(body_iinv, a), mb = c.mminv, ib = c.miinv;
-        const R msum = ma + mb;
-        const R k11 = msum + r1y * r1y * ia + r2y * r2y * ib;
-        const R k12 = -r1x * r1y * ia - r2x * r2y * ib;
-        const R k22 = msum + r1x * r1x * ia + r2x * r2x * ib;
-        const R det_inv = R(1) / (k11 * k22 - k12 * k12);
-        c.pk0 = k22 * det_inv; c.pk1 = -k12 * det_inv; c.pk2 = -k12 * det_inv; c.pk3 = k11 * det_inv;
-        R bx = -R(ddx) * p[7], by = -R(ddy) * p[7];
-        clamp_len(bx, by, p[8]);
+        R bx = R(0), by = R(0);
+        if (p[8] > R(0)) {
+            bx = -R(E_P(px, b) - E_P(px, a)) * p[7]; by = -R(E_P(py, b) - E_P(py, a)) * p[7];
+            clamp_len(bx, by, p[8]);
+        }
         c.pb0 = bx; c.pb1 = by;
         const R *pg = &T_R(joint_p, (j + 1) * JOINT_PARAMS);
         const P *ppg = &T_P(p_joint, (j + 1) * 7);
@@ -565,19 +589,20 @@ template <typename R, typename P> MGX_HD void joints_prestep(Env<R, P> &e, Solve
         const int jj = j0 + rowlane, a = T_I(joint_a, jj), b = T_I(joint_b, jj);
         const R *p = &T_R(joint_p, jj * JOINT_PARAMS);
         const P *pp = &T_P(p_joint, jj * 7);
-        P q1x, q1y, q2x, q2y;
+        // (the finger-side anchor is the finger's origin, entities.py:334-341: r2 = 0; the robot-side anchor position is formed
+        // with the rounding sequence k_reset places the finger roots with, so the zero-length pin starts exact)
+        P q1x, q1y;
         anchor_rot<P>(E_P(c, a), E_P(s, a), pp[0], pp[1], q1x, q1y);
-        anchor_rot<P>(E_P(c, b), E_P(s, b), pp[2], pp[3], q2x, q2y);
-        const R r1x = R(q1x), r1y = R(q1y), r2x = R(q2x), r2y = R(q2y);
-        const P ddx = r_add_nc<P>(E_P(px, b), q2x) - r_add_nc<P>(E_P(px, a), q1x);
-        const P ddy = r_add_nc<P>(E_P(py, b), q2y) - r_add_nc<P>(E_P(py, a), q1y);
-        const P dist = r_sqrt<P>(ddx * ddx + ddy * ddy);
-        const P inv = dist != P(0) ? P(1) / dist : P(0);
+        const R r1x = R(q1x), r1y = R(q1y);
+        const P ddx = E_P(px, b) - r_add_nc<P>(E_P(px, a), q1x);
+        const P ddy = E_P(py, b) - r_add_nc<P>(E_P(py, a), q1y);
+        P dist, inv;
+        p_len_inv<R, P>(ddx * ddx + ddy * ddy, dist, inv);
         const R nx = R(ddx * inv), ny = R(ddy * inv);
-        const R rcn1 = r1x * ny - r1y * nx, rcn2 = r2x * ny - r2y * nx;
-        const R ma = T_R(body_minv, a), ia = T_R(body_iinv, a), mb = T_R(body_minv, b), ib = T_R(body_iinv, b);
+        const R rcn1 = r1x * ny - r1y * nx;
+        const R ma = T_R(body_minv, a), ia = T_R(body_iinv, a), mb = T_R(body_minv, b);
         c.o[0] = r1x; c.o[1] = r1y; c.o[2] = nx; c.o[3] = ny;
-        c.o[4] = R(1) / (ma + ia * rcn1 * rcn1 + mb + ib * rcn2 * rcn2);
+        c.o[4] = r_rcp<R>(ma + ia * rcn1 * rcn1 + mb);
         c.o[5] = r_clamp(-R(dist - pp[4]) * p[7], -p[8], p[8]);
     } else if (rowlane == 5 || rowlane == 8) {                // cpRotaryLimitJointPreStep
         const int jj = j0 + rowlane, a = T_I(joint_a, jj), b = T_I(joint_b, jj);
@@ -634,7 +659,7 @@ template <typename R, typename P> MGX_HD void ph_arbiters_joints(Env<R, P> &e, S
             E_I(kab, k) = A | (B << 8); E_I(kfirst, k) = first ? 1 : 0;
             E_R(knx, k) = nx; E_R(kny, k) = ny;
             E_R(kr1x, k) = r1x; E_R(kr1y, k) = r1y; E_R(kr2x, k) = r2x; E_R(kr2y, k) = r2y;
-            E_R(knm, k) = R(1) / kn; E_R(ktm, k) = R(1) / kt;
+            E_R(knm, k) = r_rcp<R>(kn); E_R(ktm, k) = r_rcp<R>(kt);
             E_R(kbias, k) = -brate * r_min(R(0), dist + slop);
             E_R(kjb, k) = R(0); E_R(kjn, k) = jn; E_R(kjt, k) = jt; E_R(kmu, k) = mu;
         }
@@ -729,16 +754,14 @@ template <typename R, typename P> MGX_HD int ri_body(const Env<R, P> &e, int slo
 }
 // the robot island's velocities, LDS <-> the (uniform) registers of every lane
 template <typename R, typename P> MGX_HD void ri_load_vel(const Env<R, P> &e, SolveCtx<R> &c) {
-    const TmplHeader &h = *e.h;
-    c.rvx = E_R(vx, h.robot_body); c.rvy = E_R(vy, h.robot_body); c.rw = E_R(w, h.robot_body);
-    c.ew[0] = E_R(w, h.eye_body[0]); c.ew[1] = E_R(w, h.eye_body[1]);
-    MGX_UNROLL for (int f = 0; f < 2; f++) { const int b = h.finger_body[f]; c.fvx[f] = E_R(vx, b); c.fvy[f] = E_R(vy, b); c.fw[f] = E_R(w, b); }
+    c.rvx = E_R(vx, c.b_robot); c.rvy = E_R(vy, c.b_robot); c.rw = E_R(w, c.b_robot);
+    c.ew[0] = E_R(w, c.b_eye[0]); c.ew[1] = E_R(w, c.b_eye[1]);
+    MGX_UNROLL for (int f = 0; f < 2; f++) { const int b = c.b_finger[f]; c.fvx[f] = E_R(vx, b); c.fvy[f] = E_R(vy, b); c.fw[f] = E_R(w, b); }
 }
 template <typename R, typename P> MGX_HD void ri_store_vel(Env<R, P> &e, const SolveCtx<R> &c) {
-    const TmplHeader &h = *e.h;
-    E_R(vx, h.robot_body) = c.rvx; E_R(vy, h.robot_body) = c.rvy; E_R(w, h.robot_body) = c.rw;
-    E_R(w, h.eye_body[0]) = c.ew[0]; E_R(w, h.eye_body[1]) = c.ew[1];
-    MGX_UNROLL for (int f = 0; f < 2; f++) { const int b = h.finger_body[f]; E_R(vx, b) = c.fvx[f]; E_R(vy, b) = c.fvy[f]; E_R(w, b) = c.fw[f]; }
+    E_R(vx, c.b_robot) = c.rvx; E_R(vy, c.b_robot) = c.rvy; E_R(w, c.b_robot) = c.rw;
+    E_R(w, c.b_eye[0]) = c.ew[0]; E_R(w, c.b_eye[1]) = c.ew[1];
+    MGX_UNROLL for (int f = 0; f < 2; f++) { const int b = c.b_finger[f]; E_R(vx, b) = c.fvx[f]; E_R(vy, b) = c.fvy[f]; E_R(w, b) = c.fw[f]; }
 }
 // does this lane keep a block's pair?  (lane 1 + k <-> island k; rowlane 0 keeps the robot's)
 template <typename R> MGX_HD bool is_block_lane(const SolveCtx<R> &c, int lane) { return c.mj >= 0 && (lane & (ROW - 1)) != 0; }
@@ -750,6 +773,7 @@ template <typename R, typename P> MGX_HD void solve_ctx_init(Env<R, P> &e, Solve
     const TmplHeader &h = *e.h;
     const int rowlane = lane & (ROW - 1), j0 = h.robot_j0;
     c.mj = -1; c.mbody = -1;
+    c.b_robot = h.robot_body; c.b_eye[0] = h.eye_body[0]; c.b_eye[1] = h.eye_body[1]; c.b_finger[0] = h.finger_body[0]; c.b_finger[1] = h.finger_body[1];
     if (rowlane == 0) { c.mj = j0; c.mbody = h.robot_body; }
     else if (lane < ROW && lane - 1 < h.n_islands) { c.mj = T_I(island_j, lane - 1); c.mbody = T_I(joint_b, c.mj); }
     c.pk0 = c.pk1 = c.pk2 = c.pk3 = c.pb0 = c.pb1 = c.pa0 = c.pa1 = c.plim = R(0);
@@ -761,6 +785,10 @@ template <typename R, typename P> MGX_HD void solve_ctx_init(Env<R, P> &e, Solve
         c.plim = E_R(jlim, j); c.glim = E_R(jlim, j + 1);
         c.gim = T_R(joint_p, (j + 1) * JOINT_PARAMS); c.gratio = T_R(joint_p, (j + 1) * JOINT_PARAMS + 5);
         c.mminv = T_R(body_minv, c.mbody); c.miinv = T_R(body_iinv, c.mbody);
+        // cpPivotJointPreStep's K^-1 with r1 = r2 = 0 (joints_prestep): k11 = k22 = m_a^-1 + m_b^-1, k12 = 0
+        const R msum = T_R(body_minv, T_I(joint_a, j)) + c.mminv;
+        const R det_inv = R(1) / (msum * msum);
+        c.pk0 = msum * det_inv; c.pk3 = msum * det_inv;
     }
     c.r_minv = T_R(body_minv, h.robot_body); c.r_iinv = T_R(body_iinv, h.robot_body);
     MGX_UNROLL for (int k = 0; k < 2; k++) {
@@ -851,7 +879,7 @@ template <typename R, typename P> MGX_HD void solve_begin(Env<R, P> &e, SolveCtx
     c.rw -= js1 * c.r_iinv; c.ew[1] += js1 * c.e_iinv[1];
     if (is_block_lane(c, lane)) { c.mvx = E_R(vx, c.mbody); c.mvy = E_R(vy, c.mbody); c.mw = E_R(w, c.mbody); }
     // the contact warm start (next step) must see the spring impulses
-    if (c.has_contacts && lane == 0) { E_R(w, h.robot_body) = c.rw; E_R(w, h.eye_body[0]) = c.ew[0]; E_R(w, h.eye_body[1]) = c.ew[1]; }
+    if (c.has_contacts && lane == 0) { E_R(w, c.b_robot) = c.rw; E_R(w, c.b_eye[0]) = c.ew[0]; E_R(w, c.b_eye[1]) = c.ew[1]; }
 }
 // solve step B: cached arbiter impulses (lane 0, LDS)
 template <typename R, typename P> MGX_HD void solve_warm_contacts(Env<R, P> &e, const SolveCtx<R> &c, int lane) {
@@ -1142,8 +1170,7 @@ MGX_HD void reset_env_state(const TmplHeader &h, const int32_t *ti, const R *tr,
 #define MGX_SUBSTEP_PHASES(X)                                      \
     X(ph_integrate(e, lane, nl))                                   \
     X(ph_shapes(e, lane, nl))                                      \
-    X(ph_broad_count(e, lane, nl))                                 \
-    X(ph_broad_write(e, lane, nl))                                 \
+    X(ph_broad(e, lane, nl))                                       \
     X(ph_narrow(e, lane, nl))                                      \
     X(ph_arbiters_joints(e, ctx, lane, nl))                        \
     X(solve_begin(e, ctx, lane, nl))                               \

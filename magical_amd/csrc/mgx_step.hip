@@ -56,7 +56,7 @@ template <typename R, typename P> MGX_HD int tmpl_total_words(const TmplHeader &
 #ifdef MGX_STEP_PROBE
 constexpr bool probe_prefix(const char *s, const char *p) { return *p == 0 ? true : (*s == *p && probe_prefix(s + 1, p + 1)); }
 constexpr int probe_phase_id(const char *s) {
-    const char *names[] = {"ph_init_work", "ph_load_state", "ph_integrate", "ph_shapes", "ph_broad_count", "ph_broad_write", "ph_narrow",
+    const char *names[] = {"ph_init_work", "ph_load_state", "ph_integrate", "ph_shapes", "ph_broad", "ph_broad_(unused)", "ph_narrow",
                            "ph_arbiters_joints", "solve_begin", "solve_warm_contacts", "solve_warm_pg", "solve_iter_publish",
                            "solve_iter_contacts", "solve_iter_pg", "solve_end", "ph_cache_commit", "solve_warm_chain", "solve_iter_chain"};
     for (int i = 0; i < 18; i++) if (probe_prefix(s, names[i])) return i;

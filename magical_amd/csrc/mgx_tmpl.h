@@ -154,7 +154,7 @@ struct WorkOff {
     int cj, ncj;
     int n_r;
     // int region
-    int ov, mcnt, koff, kab, kfirst, chead, nchead, cmatched, misc, flag, cnt;
+    int ov, mcnt, koff, kab, kfirst, chead, nchead, cmatched, misc;
     int n_i;
     // element strides of the fields (1 = plain array)
 #ifndef MGX_AOS
@@ -178,7 +178,7 @@ struct WorkOff {
                          S_knm = CONTACT_R, S_ktm = CONTACT_R, S_kbias = CONTACT_R, S_kjb = CONTACT_R, S_kjn = CONTACT_R, S_kjt = CONTACT_R, S_kmu = CONTACT_R;
     static constexpr int S_mn = 1, S_mp = 1, S_cj = 1, S_ncj = 1;
     static constexpr int S_ov = OV_I, S_mcnt = OV_I, S_koff = 1, S_kab = KI_I, S_kfirst = KI_I, S_chead = C_I, S_nchead = C_I,
-                         S_cmatched = C_I, S_misc = 1, S_flag = 1, S_cnt = 1;
+                         S_cmatched = C_I, S_misc = 1;
     MGX_HD explicit WorkOff(const TmplHeader &h) {
         int nb = h.n_bodies, nv = h.n_verts, ns = h.n_shapes, nj = h.n_joints;
         int nk = h.max_contacts, nov = h.max_overlaps, nc = h.cache_slots;
@@ -212,14 +212,7 @@ struct WorkOff {
         koff = o; o += nc;
         chead = o; nchead = o + sc; cmatched = o + 2 * sc; o += 3 * nc;
         misc = o; o += M_N;
-        // likewise the broadphase's pair flags and compaction counters (ph_broad_*) and the contacts' body / first-touch ints
-        const int shared_i = o;
-        flag = o; o += (h.n_pairs + 3) / 4;   // one byte per candidate pair
-        cnt = o; o += 64;                      // per-lane counters for ordered compaction
-        const int broad_end = o;
-        if (ALIAS) o = shared_i;
         kab = o; kfirst = o + ski; o += 2 * nk;
-        if (o < broad_end) o = broad_end;
         n_i = o;
     }
 };

@@ -20,7 +20,7 @@ env.substeps(tape[41], 10); torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) * 1e3
 env._lib.mgx_engine_debug_step_clocks(env._engine, None)
 c = clk.cpu().numpy().astype(np.float64)
-names = ["ph_init_work", "ph_load_state", "ph_integrate", "ph_shapes", "ph_broad_count", "ph_broad_write", "ph_narrow",
+names = ["ph_init_work", "ph_load_state", "ph_integrate", "ph_shapes", "ph_broad", "ph_broad_(unused)", "ph_narrow",
          "ph_arbiters_joints", "solve_begin", "solve_warm_contacts", "solve_warm_pg", "solve_iter_publish",
          "solve_iter_contacts", "solve_iter_pg", "solve_end", "ph_cache_commit", "solve_warm_chain", "solve_iter_chain"]
 tot = c[:, :20].sum(axis=1).mean()
