@@ -386,8 +386,8 @@ def measure(args, rank, world, device):
                                                   '(their episode clocks were set ahead; scoring + auto-reset + stack refill are timed)') if share else
                                                  f'{K // ep} whole episodes of every env',
                        'arith': 'fp32 velocities/impulses/contacts + fp64 poses; fp64 rasteriser' if args.dtype == 'f32' else args.dtype,
-                       'broadphase': 'pre-filtered candidate-pair list, AABB-tested brute force, compacted in pair order through LDS counters '
-                                     '(<= 27 shapes per env: measured faster than sort-and-sweep; DESIGN.md 3.1)',
+                       'broadphase': 'pre-filtered candidate-pair list, AABB-tested brute force by the env\'s lane group and compacted in pair order '
+                                     'through a wavefront ballot (<= 27 shapes per env: measured faster than sort-and-sweep; DESIGN.md 3.1)',
                        'roofline_bytes_row': 'SURVEY.md 8(d) headline row: state + ONE new 96x96x3 frame per env-step (ring of planar frames)' if ring else
                                              'SURVEY.md 8(d) parenthetical row: [96,96,12] stack re-materialised each step (9 B read + 12 B '
                                              'written per pixel + pose rows); frac_new_frame_row uses the 28.3 KB headline row'},
