@@ -214,6 +214,22 @@ int mgx_engine_set_goal_rects(mgx_engine *e, const double *goal_xyhw);
  * (match_regions.py:193-213, find_dupe.py:203-216, fix_colour.py:193-202). */
 int mgx_engine_score_overlaps(mgx_engine *e, const void *state_p, const uint8_t *mask, uint8_t *out, void *stream);
 int mgx_engine_n_goals(const mgx_engine *e);
+/* score_on_end_of_traj() of the tasks that score from block POSITIONS, whole, on the device: out = DEVICE double[N] (0 where
+ * mask == 0), fp64 with every operation in numpy's order (contraction off), so that the score equals the reference's bit for bit:
+ *   MGX_SCORE_CORNER   move_to_corner.py:66-75   entities = {the block}; params = {furthest distance sqrt(2), range sqrt(2) - sqrt(2)/2}
+ *   MGX_SCORE_LINE     make_line.py:31-71,142-152 entities = the blocks in task order (an episode has the first k present ones);
+ *                                                 params = {inlier distance, max separation}
+ *   MGX_SCORE_CLUSTER  cluster.py:166-216         entities = the blocks, cls_default[k] = class of block k in the world's own layout,
+ *                                                 cls_env = DEVICE int8 [N][n] per-env classes (variants that redraw colours /
+ *                                                 types) or NULL; n_classes <= 8
+ * Blocks an env's episode does not have (per-env worlds) take no part.  dot_mode / mm_mode say how the HOST's numpy evaluates the
+ * two library primitives the reference's code goes through -- np.linalg.norm of a 2-vector (BLAS ddot) and the [n,2] @ [2,1]
+ * product of make_line.py:47 -- 0: x*x + y*y, 1: fma(y, y, x*x), 2: fma(x, x, y*y); the caller finds out by probing its numpy
+ * (magical_amd/benchmarks/_scoring.py), because that is what "the reference's result" is on its machine. */
+enum mgx_score_task { MGX_SCORE_CORNER = 1, MGX_SCORE_LINE = 2, MGX_SCORE_CLUSTER = 3 };
+int mgx_engine_score_points(mgx_engine *e, const void *state_p, int task, int n, const int32_t *entities, const int32_t *cls_default,
+                            int n_classes, const int8_t *cls_env, const double *params, int dot_mode, int mm_mode,
+                            const uint8_t *mask, double *out, void *stream);
 int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t env_stride, int view, int layout,
                       const uint8_t *fill_mask, void *stream);
 /* BaseEnv.step() physics + its observation in ONE call (base_env.py:255-292 with the wrappers of

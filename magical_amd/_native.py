@@ -17,6 +17,7 @@ _DEPS = _SOURCES + ['mgx_step.hip', 'mgx_raster.hip', 'mgx_raster_body.inc', 'mg
 # enums (include/mgx.h)
 MGX_F32, MGX_F64, MGX_F32_PURE = 0, 1, 2
 VIEW_EGO, VIEW_ALLO = 0, 1
+SCORE_CORNER, SCORE_LINE, SCORE_CLUSTER = 1, 2, 3
 OBS_FRAME, OBS_STACK4, OBS_STACK3_HI, OBS_SLOT_LO, OBS_PLANAR = 0, 1, 2, 3, 4
 INFO = {k: i for i, k in enumerate([
     'n_bodies', 'n_shapes', 'n_joints', 'n_pairs', 'n_prims', 'state_rows_p', 'state_rows_f', 'state_rows_i',
@@ -102,6 +103,7 @@ def lib():
         'mgx_engine_set_goal_rects': [vp, vp],
         'mgx_engine_score_overlaps': [vp, vp, vp, vp, vp],
         'mgx_engine_n_goals': [vp],
+        'mgx_engine_score_points': [vp, vp, i32, i32, ip, ip, i32, vp, dp, i32, i32, vp, vp, vp],
         'mgx_engine_create': [vp, i32, i32, i32, i32, C.POINTER(vp)],
         'mgx_engine_state_shape': [vp, ip, ip, ip, ip, ip],
         'mgx_engine_lanes_per_env': [vp],
@@ -140,7 +142,7 @@ EXPORTED_SYMBOLS = [
     'mgx_world_add_robot', 'mgx_world_add_shape', 'mgx_world_add_goal', 'mgx_world_finalize', 'mgx_world_info',
     'mgx_world_entity', 'mgx_world_body_table', 'mgx_world_n_state_entries', 'mgx_world_state_entry',
     'mgx_world_goal_bb', 'mgx_world_entity_shapes', 'mgx_world_prim_table', 'mgx_world_palette', 'mgx_rng_bounded_batch', 'mgx_rng_doubles_batch', 'mgx_rng_shuffle_batch', 'mgx_world_placement_collides', 'mgx_world_randomise_all_poses', 'mgx_world_randomise_all_poses_batch',
-    'mgx_engine_create', 'mgx_engine_destroy', 'mgx_engine_set_entity_colours', 'mgx_engine_set_goal_rects', 'mgx_engine_score_overlaps', 'mgx_engine_n_goals',
+    'mgx_engine_create', 'mgx_engine_destroy', 'mgx_engine_set_entity_colours', 'mgx_engine_set_goal_rects', 'mgx_engine_score_overlaps', 'mgx_engine_n_goals', 'mgx_engine_score_points',
     'mgx_world_variant', 'mgx_engine_enable_env_worlds', 'mgx_engine_set_env_variants', 'mgx_engine_env_randomise_all_poses_batch', 'mgx_engine_env_world_info',
     'mgx_engine_state_shape', 'mgx_engine_lanes_per_env', 'mgx_engine_lds_bytes', 'mgx_engine_reset', 'mgx_engine_reset_poses',
     'mgx_engine_step', 'mgx_engine_substeps', 'mgx_engine_render', 'mgx_engine_step_render', 'mgx_engine_handoff_stats', 'mgx_engine_render_native',

@@ -89,7 +89,7 @@ class BaseEnv(abc.ABC):
     def __init__(self, *, n_envs=1, device='cuda:0', res_hw=(384, 384), fps=8, phys_steps=10, phys_iter=10,
                  max_episode_steps=None, rand_dynamics=False, ego_view=True, allo_view=True,
                  dtype='f32', lanes_per_env=0, auto_reset=True, copy_obs=False, strict_capacity=False, overlap=True, batch_draws=True,
-                 obs_ring=None, terminal_observation=False):
+                 obs_ring=None, terminal_observation=False, device_scores=True):
         import torch
         if fps != 8 or phys_steps != 10 or phys_iter != 10:
             raise NotImplementedError('the engine is built for the registered rates: fps=8, 10 substeps, 10 iterations '
@@ -99,6 +99,8 @@ class BaseEnv(abc.ABC):
         self.res_hw, self.max_episode_steps = tuple(res_hw), max_episode_steps
         self.ego_view, self.allo_view, self.rand_dynamics = ego_view, allo_view, rand_dynamics
         self.auto_reset, self.copy_obs, self.strict_capacity = auto_reset, bool(copy_obs), bool(strict_capacity)
+        # the point tasks' episode-end scores on the device (mgx_engine_score_points) where that is bit-exact; False: always on the host
+        self.device_scores = bool(device_scores) and not os.environ.get('MGX_HOST_SCORES')
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise nat.MgxError('magical_amd runs on an MI355X (torch device "cuda:N"); there is no CPU fallback')
@@ -343,7 +345,8 @@ class BaseEnv(abc.ABC):
             # snapshots while the GPU resets and renders.  Tasks with per-episode draws keep per-env tables that the draws
             # overwrite, so they score first, as before.
             early = (self.auto_reset and not self.rand_dynamics and not self.variable_worlds and not self.sample_variation_is_active())
-            snap_p = snap_i = snap_o = None
+            snap_p = snap_i = snap_o = snap_s = None
+            dev_scores = self._device_point_scores()
             term = term_token = None
             want_term = self.terminal_observation and self.auto_reset
             if want_term and not early:
@@ -353,7 +356,10 @@ class BaseEnv(abc.ABC):
                 # waits for the event only, and scores while the GPU is still busy
                 pin = self._pinned_snapshots()
                 snap_i = pin['i']; snap_i.copy_(self.state_i[2], non_blocking=True)
-                if self.score_needs_poses:
+                if dev_scores:
+                    self._enqueue_point_scores(self._done_dev)
+                    snap_s = pin['s']; snap_s.copy_(self._score_dev, non_blocking=True)
+                elif self.score_needs_poses:
                     snap_p = pin['p']; snap_p.copy_(self.state_p, non_blocking=True)
                 else:
                     self._enqueue_region_overlaps(self._done_dev)
@@ -366,7 +372,13 @@ class BaseEnv(abc.ABC):
                 self._fill_idx = idx
                 obs = self._observe(fill_mask=fill)
                 pin['ev'].synchronize()
-            if self.score_needs_poses:
+            if dev_scores:
+                # the point tasks' scores come off the device whole (mgx_engine_score_points): no pose rows leave the GPU
+                if not early:
+                    self._enqueue_point_scores(self._done_dev)
+                    snap_s = self._score_dev.cpu()
+                eval_score[idx] = snap_s.numpy()[idx]
+            elif self.score_needs_poses:
                 eval_score[idx] = self.score_on_end_of_traj(self.get_poses(sel, source=snap_p))
             elif early:
                 self._overlap = snap_o.numpy() if sel is None else snap_o.numpy()[:, :, sel]
@@ -617,12 +629,52 @@ class BaseEnv(abc.ABC):
         pin = getattr(self, '_pin', None)
         if pin is None:
             pin = {'i': torch.empty(self.n_envs, dtype=torch.int32).pin_memory(), 'ev': torch.cuda.Event()}
-            if self.score_needs_poses:
+            if self._device_point_scores():
+                pin['s'] = torch.empty(self.n_envs, dtype=torch.float64).pin_memory()
+            elif self.score_needs_poses:
                 pin['p'] = torch.empty(tuple(self.state_p.shape), dtype=self.state_p.dtype).pin_memory()
             else:
                 pin['o'] = torch.empty((len(self._goal_ent_idx), len(self._entities), self.n_envs), dtype=torch.uint8).pin_memory()
             self._pin = pin
         return pin
+
+    def device_score_spec(self):
+        """Task hook: what mgx_engine_score_points needs to compute score_on_end_of_traj() on the device (None: the task scores on
+        the host, from downloaded poses or overlap sets)."""
+        return None
+
+    def _device_point_scores(self):
+        """Can the episode-end scores of this task be computed on the device, bit for bit?  (a point task, and a numpy whose two
+        library primitives round in one of the ways the kernel knows: _scoring.numpy_dot_modes)"""
+        use = getattr(self, '_use_dev_scores', None)
+        if use is None:
+            from .benchmarks._scoring import numpy_dot_modes
+            use = self._use_dev_scores = (self.score_needs_poses and self.device_scores and self.device_score_spec() is not None
+                                          and numpy_dot_modes() is not None)
+        return use
+
+    def _enqueue_point_scores(self, mask_dev=None):
+        """score_on_end_of_traj() of the envs in the mask -> self._score_dev (float64[N] on the device), nothing synchronised."""
+        import torch
+        from .benchmarks._scoring import numpy_dot_modes
+        spec = self.device_score_spec()
+        dot_mode, mm_mode = numpy_dot_modes()
+        if getattr(self, '_score_dev', None) is None:
+            self._score_dev = torch.zeros(self.n_envs, dtype=torch.float64, device=self.device)
+        ents = np.ascontiguousarray(spec['ents'], dtype=np.int32)
+        cls_default = np.ascontiguousarray(spec.get('cls_default', [0] * len(ents)), dtype=np.int32)
+        params = np.ascontiguousarray(spec['params'], dtype=np.float64)
+        cls_env = spec.get('cls_env')
+        cls_ptr = None
+        if cls_env is not None:     # per-env classes (variants that redraw colours / types): the table as it stands now
+            self._cls_dev = torch.as_tensor(np.ascontiguousarray(cls_env, dtype=np.int8), device=self.device)
+            assert tuple(self._cls_dev.shape) == (self.n_envs, len(ents))
+            cls_ptr = self._cls_dev.data_ptr()
+        nat.check(self._lib.mgx_engine_score_points(
+            self._engine, self.state_p.data_ptr(), spec['task'], len(ents), ents.ctypes.data_as(C.POINTER(C.c_int)),
+            cls_default.ctypes.data_as(C.POINTER(C.c_int)), int(spec.get('n_classes', 1)), cls_ptr,
+            params.ctypes.data_as(C.POINTER(C.c_double)), dot_mode, mm_mode, None if mask_dev is None else mask_dev.data_ptr(),
+            self._score_dev.data_ptr(), self._stream()))
 
     def _enqueue_region_overlaps(self, mask_dev=None):
         import torch

@@ -47,6 +47,42 @@ def row_norm(d):
     return _row_norm_impl(d) if len(d) else np.empty(0, dtype=np.float64)
 
 
+_NUMPY_DOT_MODES = None
+
+
+def numpy_dot_modes():
+    """(dot_mode, mm_mode) for mgx_engine_score_points, or None where this numpy does something else.  The reference's point scores go
+    through two library kernels whose rounding depends on the build: np.dot of a 2-vector with itself (np.linalg.norm, BLAS ddot) and the
+    [n, 2] @ [2, 1] product of make_line.py:47.  Each is compared, on 2048 probe rows, with the three ways a sum of two products can be
+    rounded -- 0: round(round(x x') + round(y y')), 1: fma(y, y', round(x x')), 2: fma(x, x', round(y y')) -- evaluated EXACTLY (rational
+    arithmetic, one rounding where an fma has one); the mode is the one that reproduces every row."""
+    global _NUMPY_DOT_MODES
+    if _NUMPY_DOT_MODES is None:
+        from fractions import Fraction
+        rs = np.random.RandomState(20260929)
+        a = rs.uniform(-2.0, 2.0, size=(2048, 2)); b = rs.uniform(-2.0, 2.0, size=(2048, 2))
+        a[:256] *= rs.uniform(1e-6, 1.0, size=(256, 1))
+
+        def cands(ax, ay, bx, by):
+            fx, fy = Fraction(ax) * Fraction(bx), Fraction(ay) * Fraction(by)
+            return (ax * bx + ay * by, float(Fraction(ax * bx) + fy), float(fx + Fraction(ay * by)))
+        dot_want = np.array([np.dot(r, r) for r in a])
+        dot_c = np.array([cands(r[0], r[1], r[0], r[1]) for r in a])
+        # the product as longest_line() forms it: offs[n, 2] @ unit[:, None] -> [n, 1], n = 3 or 4 blocks (matmul picks its kernel by
+        # shape: a [1, 2] @ [2, 1] product goes another way than these on the builds seen); both shapes must round the same way
+        pick = lambda want, c: next((m for m in range(3) if np.array_equal(c[:, m], want)), None)
+        d = pick(dot_want, dot_c)
+        m = -1
+        for n in (4, 3):
+            rows = (2048 // n) * n
+            mm_want = np.concatenate([np.squeeze(a[i:i + n] @ b[i // n][:, None], axis=1) for i in range(0, rows, n)])
+            mm_c = np.array([cands(a[i, 0], a[i, 1], b[i // n, 0], b[i // n, 1]) for i in range(rows)])
+            mn = pick(mm_want, mm_c)
+            m = mn if m in (-1, mn) else None
+        _NUMPY_DOT_MODES = (d, m) if d is not None and m is not None else False
+    return _NUMPY_DOT_MODES or None
+
+
 def entity_shapes(env, ent):
     """[(kind, radius, local_verts[n,2])] of a block entity, from the native world."""
     L, w = env._lib, env._world

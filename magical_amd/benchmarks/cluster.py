@@ -136,6 +136,12 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
         self.__class_of_block = np.array([list(self.__characteristic_values).index(v) for v in c_values_list], dtype=np.int64)
         self.add_entities([robot])
 
+    def device_score_spec(self):   # the same score on the device (mgx_engine_score_points)
+        from .. import _native as nat
+        return dict(task=nat.SCORE_CLUSTER, ents=[e.ent_id for e in self.__shape_ents], params=(0.0, 0.0),
+                    cls_default=[int(c) for c in self.__class_of_block] + [0] * (len(self.__shape_ents) - len(self.__class_of_block)),
+                    n_classes=len(self.__characteristic_values), cls_env=self._class_env)
+
     def score_on_end_of_traj(self, poses):   # cluster.py:166-216
         pos = poses[:, [e.body for e in self.__shape_ents], :2]            # [M, n_blocks, 2]
         M, n_blocks = pos.shape[0], pos.shape[1]

@@ -137,6 +137,10 @@ class MakeLineEnv(BaseEnv):
             var['randomise_poses'] = (all_ents, dict(rand_pos=True, rand_rot=True, rel_pos_linf_limits=pos_limits, rel_rot_limits=rot_limit))
         return var
 
+    def device_score_spec(self):   # the same score on the device (mgx_engine_score_points)
+        from .. import _native as nat
+        return dict(task=nat.SCORE_LINE, ents=[b.ent_id for b in self._blocks], params=(self.inlier_dist, self.max_sep))
+
     def score_on_end_of_traj(self, poses):   # make_line.py:142-152
         bodies = [b.body for b in self._blocks]
         if not self.variable_worlds:

@@ -77,6 +77,10 @@ class MoveToCornerEnv(BaseEnv):
         self.add_entities([shape])
         self.__shape_ref = shape
 
+    def device_score_spec(self):   # the same score on the device (mgx_engine_score_points)
+        from .. import _native as nat
+        return dict(task=nat.SCORE_CORNER, ents=[self.__shape_ref.ent_id], params=(np.sqrt(2), np.sqrt(2) - np.sqrt(2) / 2))
+
     def score_on_end_of_traj(self, poses):   # move_to_corner.py:66-75
         shape_pos = poses[:, self.__shape_ref.body, :2]
         dist = row_norm(np.asarray([-1.0, 1.0]) - shape_pos)   # target is top left

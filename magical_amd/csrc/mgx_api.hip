@@ -960,6 +960,37 @@ int mgx_engine_score_overlaps(mgx_engine *e, const void *state_p, const uint8_t 
     HIP_OK(hipGetLastError());
     return MGX_OK;
 }
+int mgx_engine_score_points(mgx_engine *e, const void *state_p, int task, int n, const int32_t *entities, const int32_t *cls_default, int n_classes,
+                            const int8_t *cls_env, const double *params, int dot_mode, int mm_mode, const uint8_t *mask, double *out, void *stream) {
+    if (!e || !state_p || !out || !entities || !params) return fail(MGX_ERR_ARG, "NULL argument");
+    if (task < SP_CORNER || task > SP_CLUSTER) return fail(MGX_ERR_ARG, "task must be MGX_SCORE_CORNER, _LINE or _CLUSTER");
+    if (n < 1 || n > SP_MAX_BLOCKS) return fail(MGX_ERR_CAPACITY, "1 .. 16 blocks");
+    if (task == SP_CLUSTER && (!cls_default || n_classes < 1 || n_classes > SP_MAX_CLASSES)) return fail(MGX_ERR_ARG, "cluster score: classes 1 .. 8 and the default class table");
+    if (dot_mode < 0 || dot_mode > 2 || mm_mode < 0 || mm_mode > 2) return fail(MGX_ERR_ARG, "dot_mode / mm_mode: 0 plain, 1 fma on the second product, 2 fma on the first");
+    ON_DEVICE(e);
+    const int ne = (int)e->w.entities.size();
+    ScorePointsDev s{};
+    s.task = task; s.n = n; s.n_classes = n_classes; s.dot_mode = dot_mode; s.mm_mode = mm_mode;
+    s.p0 = params[0]; s.p1 = params[1]; s.p2 = 0.0;
+    s.cls_env = cls_env; s.ent_present_env = e->d_ent_present_env;
+    std::vector<int> prow(3 * e->w.bodies.size(), -1);
+    for (int m : e->w.state_map) { const int comp = m & 15, b = (m >> 4) & 0xFF, row = m >> 12; if (comp < 3) prow[3 * b + comp] = row; }
+    for (int k = 0; k < n; k++) {
+        const int en = entities[k];
+        if (en < 0 || en >= ne || e->w.entities[en].kind != 1) return fail(MGX_ERR_ARG, "score entities must be blocks of the engine's world");
+        const int body = e->w.entities[en].body;
+        s.ent[k] = en; s.row_x[k] = prow[3 * body]; s.row_y[k] = prow[3 * body + 1];
+        s.cls_default[k] = cls_default ? cls_default[k] : 0;
+        if (s.row_x[k] < 0 || s.row_y[k] < 0) return fail(MGX_ERR_STATE, "block without persistent pose rows");
+        if (task == SP_CLUSTER && (s.cls_default[k] < 0 || s.cls_default[k] >= n_classes)) return fail(MGX_ERR_ARG, "class out of range");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (e->n_envs + 63) / 64;
+    if (e->dtype == MGX_F32_PURE) hipLaunchKernelGGL((k_score_points<float>), dim3(blocks), dim3(64), 0, st, s, (const float *)state_p, mask, out, e->n_envs);
+    else hipLaunchKernelGGL((k_score_points<double>), dim3(blocks), dim3(64), 0, st, s, (const double *)state_p, mask, out, e->n_envs);
+    HIP_OK(hipGetLastError());
+    return MGX_OK;
+}
 int mgx_engine_n_goals(const mgx_engine *e) { return e ? e->n_goals : 0; }
 }  // extern "C"
 

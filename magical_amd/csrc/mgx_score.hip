@@ -116,6 +116,134 @@ __global__ __launch_bounds__(64) void k_score(ScoreDev s, const P *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- the point tasks' score_on_end_of_traj(), whole, on the device
+// MoveToCorner (move_to_corner.py:66-75), MakeLine (make_line.py:31-71,142-152), ClusterColour / ClusterShape (cluster.py:166-216)
+// score from block POSITIONS alone.  fp64, contraction off, every operation in numpy's order, so the result is the reference's
+// bit for bit (tests: the reference's own outputs in tests/golden/reference_vectors.json).  Two of numpy's primitives go through
+// library kernels whose use of FMA depends on the host's BLAS / numpy build -- np.linalg.norm of a 1-D vector (BLAS ddot) and
+// `offs @ unit` (matmul's small-matrix kernel): the host finds out which form its numpy takes (benchmarks/_scoring.py probes
+// exactly rounded candidates against the live primitives) and hands the answer down as dot_mode / mm_mode.
+constexpr int SP_MAX_BLOCKS = 16, SP_MAX_CLASSES = 8;
+enum { SP_CORNER = 1, SP_LINE = 2, SP_CLUSTER = 3 };
+enum { SP_DOT_PLAIN = 0, SP_DOT_FMA_SECOND = 1, SP_DOT_FMA_FIRST = 2 };      // x*x + y*y | fma(y, y, x*x) | fma(x, x, y*y)
+
+struct ScorePointsDev {
+    int task, n;                        // blocks of the task, in the task's order
+    int32_t ent[SP_MAX_BLOCKS];         // their entity indices (presence table) ...
+    int32_t row_x[SP_MAX_BLOCKS], row_y[SP_MAX_BLOCKS];      // ... and the pose-blob rows of their positions
+    int32_t cls_default[SP_MAX_BLOCKS]; // cluster: class of every block in the world's own layout
+    const int8_t *cls_env;              // cluster: [N][n] per-env classes (Test* variants that redraw them) or NULL
+    const uint8_t *ent_present_env;     // [n_entities][N] or NULL (all present)
+    int n_classes, dot_mode, mm_mode;
+    double p0, p1, p2;                  // corner: furthest distance, range | line: inlier distance, max separation
+};
+
+__device__ inline double sp_dot2(double ax, double ay, double bx, double by, int mode) {
+#pragma clang fp contract(off)
+    if (mode == SP_DOT_FMA_SECOND) return __builtin_fma(ay, by, ax * bx);
+    if (mode == SP_DOT_FMA_FIRST) return __builtin_fma(ax, bx, ay * by);
+    return ax * bx + ay * by;
+}
+
+template <typename P>
+__global__ __launch_bounds__(64) void k_score_points(ScorePointsDev s, const P *__restrict__ sp, const uint8_t *__restrict__ mask,
+                                                     double *__restrict__ out, int n_envs) {
+#pragma clang fp contract(off)
+    const long env = (long)blockIdx.x * 64 + threadIdx.x;
+    if (env >= n_envs) return;
+    const long N = n_envs;
+    if (mask && !mask[env]) { out[env] = 0.0; return; }
+    double px[SP_MAX_BLOCKS], py[SP_MAX_BLOCKS];
+    bool on[SP_MAX_BLOCKS];
+    int n_on = 0;
+#pragma unroll
+    for (int k = 0; k < SP_MAX_BLOCKS; k++) {
+        px[k] = py[k] = 0.0; on[k] = false;
+        if (k < s.n) {
+            px[k] = (double)sp[(long)s.row_x[k] * N + env]; py[k] = (double)sp[(long)s.row_y[k] * N + env];
+            on[k] = !s.ent_present_env || s.ent_present_env[(long)s.ent[k] * N + env] != 0;
+            n_on += on[k] ? 1 : 0;
+        }
+    }
+    double score = 0.0;
+    if (s.task == SP_CORNER) {
+        // dist = np.linalg.norm((-1, 1) - shape_pos); score = min(1, max(0, furthest - dist) / range)
+        const double dx = -1.0 - px[0], dy = 1.0 - py[0];
+        const double dist = sqrt(sp_dot2(dx, dy, dx, dy, s.dot_mode));
+        score = fmin(1.0, fmax(0.0, s.p0 - dist) / s.p1);
+    } else if (s.task == SP_LINE) {
+        // the episode's blocks are the first n_on of the list (make_line.py:100-102); longest_line over their positions
+        const int npts = n_on;
+        int best = npts < 1 ? npts : 1;
+        for (int i = 0; i + 1 < npts; i++)
+            for (int j = i + 1; j < npts; j++) {
+                double ox[SP_MAX_BLOCKS], oy[SP_MAX_BLOCKS], proj[SP_MAX_BLOCKS];
+                const double jx = px[j] - px[i], jy = py[j] - py[i];
+                const double nrm = sqrt(sp_dot2(jx, jy, jx, jy, s.dot_mode));
+                const double ux = jx / nrm, uy = jy / nrm;
+                int n_in = 0;
+#pragma unroll
+                for (int p = 0; p < SP_MAX_BLOCKS; p++) {
+                    proj[p] = __builtin_inf();
+                    if (p < npts) {
+                        ox[p] = px[p] - px[i]; oy[p] = py[p] - py[i];
+                        const double pl = sp_dot2(ox[p], oy[p], ux, uy, s.mm_mode);
+                        const double ex = ox[p] - pl * ux, ey = oy[p] - pl * uy;
+                        const double d = sqrt(ex * ex + ey * ey);
+                        if (d <= s.p0) { proj[p] = pl; n_in++; }            // (NaN: coincident points -> no inliers)
+                    }
+                }
+                if (n_in <= best) continue;
+                // np.sort of the inliers' projections, then the longest run of neighbours at most max_separation apart
+                for (int a = 1; a < npts; a++) {
+                    const double v = proj[a]; int b = a - 1;
+                    while (b >= 0 && proj[b] > v) { proj[b + 1] = proj[b]; b--; }
+                    proj[b + 1] = v;
+                }
+                int run = 0, longest = 0;
+                for (int k = 0; k + 1 < n_in; k++) {
+                    run = fabs(proj[k + 1] - proj[k]) <= s.p1 ? run + 1 : 0;
+                    longest = longest > run ? longest : run;
+                }
+                if (longest + 1 > best) best = longest + 1;
+            }
+        const int max_len = npts, min_len = (npts - 2) > 2 ? (npts - 2) : 2;
+        const int num = best - min_len > 0 ? best - min_len : 0;
+        score = (double)num / (double)(max_len - min_len);
+    } else {
+        // centroid of every class = sum of its members in block order / their number; a block is correct when it is closer to
+        // its own centroid than to the nearest other one by the margin (a squared distance: reference quirk, cluster.py:203-206)
+        double sx[SP_MAX_CLASSES], sy[SP_MAX_CLASSES], cnt[SP_MAX_CLASSES];
+        int cls[SP_MAX_BLOCKS];
+#pragma unroll
+        for (int c = 0; c < SP_MAX_CLASSES; c++) { sx[c] = sy[c] = cnt[c] = 0.0; }
+        for (int k = 0; k < s.n; k++) {
+            cls[k] = s.cls_env ? (int)s.cls_env[env * s.n + k] : s.cls_default[k];
+            if (!on[k]) continue;
+            for (int c = 0; c < s.n_classes; c++) if (c == cls[k]) { sx[c] += px[k]; sy[c] += py[k]; cnt[c] += 1.0; }
+        }
+        for (int c = 0; c < s.n_classes; c++) { sx[c] = sx[c] / cnt[c]; sy[c] = sy[c] / cnt[c]; }
+        int n_correct = 0;
+        for (int k = 0; k < s.n; k++) {
+            double true_sse = 0.0, bad = __builtin_inf();
+            bool bad_nan = false;
+            for (int c = 0; c < s.n_classes; c++) {
+                const double dx = px[k] - sx[c], dy = py[k] - sy[c];
+                const double sse = dx * dx + dy * dy;
+                if (c == cls[k]) true_sse = sse;
+                else if (sse != sse) bad_nan = true;         // np.min propagates the NaN of a class without members
+                else bad = sse < bad ? sse : bad;
+            }
+            const double margin = 2.0 * true_sse;
+            const bool ok = !bad_nan && sqrt(true_sse) < sqrt(bad) - margin;
+            n_correct += (ok && on[k]) ? 1 : 0;
+        }
+        const double frac = (double)n_correct / (double)(n_on > 1 ? n_on : 1);
+        score = fmax(frac - 0.75, 0.0) / (1.0 - 0.75);
+    }
+    out[env] = score;
+}
+
 // per-env entity tables: row e of env env_idx[k] <- src[k][e]
 __global__ void k_scatter_ent_rows(int8_t *type_tab, uint8_t *present_tab, const int8_t *src_type, const uint8_t *src_present,
                                    const int32_t *env_idx, int n_entities, long n_envs) {

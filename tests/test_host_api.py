@@ -361,3 +361,29 @@ def test_bench_window_plan_gives_every_window_its_share_of_episode_ends():
                 end_step = ep - 1 - ahead                                 # step (since the clocks were set) at which the others finish
                 assert first <= end_step <= last                          # inside the window
                 assert end_step >= start                                  # not during the warm-up
+
+
+def test_numpy_dot_modes_probe_is_self_consistent():
+    """_scoring.numpy_dot_modes(): which rounding this numpy's ddot / small matmul take (handed to mgx_engine_score_points).  The mode it
+    reports must reproduce the live primitives on rows it has not seen, and the three candidates must really differ somewhere."""
+    from fractions import Fraction
+    from magical_amd.benchmarks._scoring import numpy_dot_modes
+    modes = numpy_dot_modes()
+    assert modes is not None, 'this numpy rounds a 2-element dot product in a way the device kernel does not know: host scoring would be used'
+    dot_mode, mm_mode = modes
+    rs = np.random.RandomState(77)
+    a, b = rs.uniform(-3, 3, size=(600, 2)), rs.uniform(-3, 3, size=(600, 2))
+
+    def cand(mode, ax, ay, bx, by):
+        if mode == 0:
+            return ax * bx + ay * by
+        if mode == 1:
+            return float(Fraction(ax * bx) + Fraction(ay) * Fraction(by))
+        return float(Fraction(ax) * Fraction(bx) + Fraction(ay * by))
+    assert [cand(dot_mode, r[0], r[1], r[0], r[1]) for r in a] == [float(np.dot(r, r)) for r in a]
+    for n in (3, 4):        # the [n, 2] @ [2, 1] products of make_line.py:47 (a [1, 2] @ [2, 1] product takes another kernel)
+        rows = (600 // n) * n
+        got = np.concatenate([np.squeeze(a[i:i + n] @ b[i // n][:, None], axis=1) for i in range(0, rows, n)])
+        assert [cand(mm_mode, a[i, 0], a[i, 1], b[i // n, 0], b[i // n, 1]) for i in range(rows)] == got.tolist(), n
+    differ = sum(len({cand(m, x[0], x[1], y[0], y[1]) for m in range(3)}) > 1 for x, y in zip(a, b))
+    assert differ > 10

@@ -303,10 +303,18 @@ def _set_xy(env, bodies, ent, xy):
     bodies[:, ent.body, 0], bodies[:, ent.body, 1] = xy[:, 0], xy[:, 1]
 
 
-def _score(env, bodies):
+def _score(env, bodies, device=True):
+    """Host score of the poses written into the device state; where the task's score also exists on the device
+    (mgx_engine_score_points: MoveToCorner, MakeLine, Cluster*) the kernel's result must equal it bit for bit -- so every
+    point-task case of the fixture pins the device kernel on the reference's own output as well."""
     env.set_bodies(bodies)
     env._scoring_envs = np.arange(env.n_envs)
-    return env.score_on_end_of_traj(env.get_poses())
+    host = env.score_on_end_of_traj(env.get_poses())
+    if device and env._device_point_scores():
+        env._enqueue_point_scores(None)
+        dev = env._score_dev.cpu().numpy()
+        assert dev.tolist() == np.asarray(host, dtype=np.float64).tolist(), ('device score differs from the host score', int((dev != host).sum()))
+    return host
 
 
 @pytest.mark.gpu
@@ -425,9 +433,39 @@ def test_gpu_cluster_score_with_random_memberships():
         pos = arr(c['pos'])
         for i in range(n):
             b[k, ents[i].body, :2] = pos[i]
-    got = _score(env, b)
+    got = _score(env, b, device=False)       # (this test edits the HOST's presence table only: the device has its own, below)
     assert got.tolist() == [unhex(c['score']) for c in cases]
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['MoveToCorner-Demo-v0', 'MoveToCorner-TestAll-v0', 'MakeLine-Demo-v0', 'MakeLine-TestCountPlus-v0', 'MakeLine-TestAll-v0',
+                                  'ClusterColour-Demo-v0', 'ClusterColour-TestColour-v0', 'ClusterColour-TestAll-v0', 'ClusterShape-TestCountPlus-v0',
+                                  'ClusterShape-TestAll-LoRes4E-v0'])
+def test_gpu_device_point_scores_equal_the_host_scores_over_rollouts(name):
+    """info['eval_score'] of the point tasks comes off the device whole (mgx_engine_score_points, no pose rows downloaded): over
+    rollouts of Demo and Test* variants (per-env worlds: absent blocks, redrawn classes) it equals, bit for bit, the host's
+    score_on_end_of_traj() -- the restatement pinned on the reference's method bodies above -- on the same final poses, across
+    two auto-resets; a numpy whose BLAS rounds differently would make the env fall back to the host path, which is asserted not
+    to be the case here."""
+    from magical_amd.benchmarks._scoring import numpy_dot_modes
+    assert numpy_dot_modes() is not None
+    n, ep = 192, 14
+    dev = _make(name, n, max_episode_steps=ep)
+    host = _make(name, n, max_episode_steps=ep, device_scores=False)
+    assert dev._device_point_scores() and not host._device_point_scores()
+    dev.seed(6); host.seed(6); dev.reset(); host.reset()
+    rs = np.random.RandomState(8)
+    ends = 0
+    for s in range(2 * ep):
+        a = np.where(rs.rand(n) < 0.7, 1, rs.randint(0, 18, size=n)).astype(np.int32)       # mostly forward: blocks get shoved around
+        _, _, dd, di = dev.step(a)
+        _, _, dh, hi = host.step(a)
+        assert np.array_equal(dd, dh)
+        assert di['eval_score'].tolist() == hi['eval_score'].tolist(), (name, s, int((di['eval_score'] != hi['eval_score']).sum()))
+        ends += int(dd.any())
+    assert ends == 2
+    dev.close(); host.close()
 
 
 @pytest.mark.gpu
