@@ -183,6 +183,9 @@ __device__ __forceinline__ int masked_item_index_uniform(const Raster &rs, uint6
     return found;
 }
 
+// v_min_f32 as it is: fminf first canonicalises an operand the compiler cannot prove quiet (NaNs cannot arise where this is used:
+// finite coefficients, finite coordinates)
+__device__ __forceinline__ float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // one Item per lane; get(i) broadcasts lane i's record to the whole wave as scalar operands
 struct RegItems {
     Item my;
@@ -216,9 +219,11 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
         float lo = st.lo;
         if (kind == IT_EDGE) {
             for (int j = i; j < i + run; j++) {
-                const float e = TILE ? (bc(src.my.a, j) * xc + (bc(src.my.b, j) * yc + bc(src.my.c, j))) * bc(src.my.g3, j)
-                                     : bc(src.my.g0, j) * xc + (bc(src.my.g1, j) * yc + bc(src.my.g2, j));
-                lo = r_min(lo, e);
+                // (explicit fma and the raw v_min: 7 instead of 10 instructions per edge -- the compiler's form multiplied in pairs and
+                // canonicalised the running minimum each turn)
+                const float e = TILE ? __builtin_fmaf(bc(src.my.a, j), xc, __builtin_fmaf(bc(src.my.b, j), yc, bc(src.my.c, j))) * bc(src.my.g3, j)
+                                     : __builtin_fmaf(bc(src.my.g0, j), xc, __builtin_fmaf(bc(src.my.g1, j), yc, bc(src.my.g2, j)));
+                lo = raw_min(lo, e);
             }
         } else if (kind == IT_NGON) {
             const float qx = r_abs(xc - bc(src.my.a, i)), qy = r_abs(yc - bc(src.my.b, i));
@@ -269,6 +274,11 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
 #define PROBE(...) __VA_ARGS__
 #else
 #define PROBE(...)
+#endif
+#ifdef MGX_RASTER_MARKERS   // development aid: names in the assembly (hipcc -S) to find a phase's instructions by
+#define RMARK(name) asm volatile("; MGX_MARK " #name);
+#else
+#define RMARK(name)
 #endif
 #ifdef MGX_RASTER_PROBE   // development build: also allows truncating the kernel after phase i (tools/raster_phase_probe.py)
 #define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + (i)] = wall_clock64() - clk0; if ((i) > 0 && t.dbg_stop == (i)) return;
