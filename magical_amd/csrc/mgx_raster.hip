@@ -275,6 +275,11 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
 #else
 #define PROBE(...)
 #endif
+#ifdef MGX_Q_NO_STORE      // development probe: what the byte patches of phases Q / E cost (the frame is wrong without them)
+#define Q_STORE(x) do { if (c == 0x7FFFFFFF) { x; } } while (0)
+#else
+#define Q_STORE(x) x
+#endif
 #ifdef MGX_RASTER_MARKERS   // development aid: names in the assembly (hipcc -S) to find a phase's instructions by
 #define RMARK(name) asm volatile("; MGX_MARK " #name);
 #else

@@ -1,5 +1,5 @@
-"""Phase T of k_raster, wave 0 of every workgroup (MGX_RASTER_PROBE build): mixed tiles walked, items classified, cycles in the
-gather and in the classification (development tool)."""
+"""Phase clocks of a rasteriser workgroup (the shipped build records them when asked): wall-clock ticks (100 MHz) from the workgroup's start
+to the end of phases S, C, T and Q + E, all workgroups of one launch at full occupancy (development tool)."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -19,10 +19,10 @@ env._lib.mgx_engine_debug_raster_clocks(env._engine, C.c_void_p(clk.data_ptr()))
 env.render_frames(stack, view='ego', layout='stack4'); torch.cuda.synchronize()
 env._lib.mgx_engine_debug_raster_clocks(env._engine, C.c_void_p(0))
 c = clk.cpu().numpy().astype(np.float64)
-q = lambda a: ' '.join('%s %.0f' % (n, np.percentile(a, p)) for n, p in (('p10', 10), ('p50', 50), ('p90', 90), ('max', 100)))
-print(task, 'wave 0 of each workgroup, phase T:')
-print('  mixed tiles walked (of 36):', q(c[:, 9]))
-print('  items classified          :', q(c[:, 10]), ' per mixed tile %.1f' % (c[:, 10].sum() / max(c[:, 9].sum(), 1)))
-print('  cycles (s_memtime, 100 MHz): gather', q(c[:, 6]), '| classify', q(c[:, 7]), '| phase T', q(c[:, 8]))
-print('  phases Q / E (last round): Q cycles per wave', q(c[:, 11:15].reshape(-1)), '| E cycles', q(c[:, 15]), '| queued pixels', q(c[:, 5]))
-print('  CLK: S %.0f  C %.0f  T %.0f  Q+E %.0f (wall clock ticks, p50, cumulative)' % tuple(np.percentile(c[:, k], 50) for k in (1, 2, 3, 4)))
+names = (('S', 1), ('C', 2), ('T', 3), ('Q+E', 4))
+prev = 0
+for n, k in names:
+    v = np.percentile(c[:, k], 50)
+    print('%-4s ends at p50 %6.1f us  (+%5.1f)   p90 %6.1f' % (n, v / 100, (v - prev) / 100, np.percentile(c[:, k], 90) / 100))
+    prev = v
+print('queued pixels p50 %d p99 %d' % (np.percentile(c[:, 5], 50), np.percentile(c[:, 5], 99)))
