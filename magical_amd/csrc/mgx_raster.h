@@ -82,7 +82,8 @@ struct Raster {
     MGX_HD int prim_rgb(int k) const { return i[ro.prgb + k]; }       // after raster_setup_prims
     MGX_HD int prim_rgb_template(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 4]; }
     MGX_HD int prim_stipple(int k) const { return ti[to.prim_i + k * PRIM_IWORDS + 5] & 0xFFFF; }
-    MGX_HD int prim_goal(int k) const { return (ti[to.prim_i + k * PRIM_IWORDS + 5] >> 16) - 1; }   // goal region ordinal, -1: none
+    MGX_HD int prim_goal(int k) const { return ((ti[to.prim_i + k * PRIM_IWORDS + 5] >> 16) & 0x1F) - 1; }   // goal region ordinal, -1: none
+    MGX_HD int prim_item_start(int k) const { return (int)((uint32_t)ti[to.prim_i + k * PRIM_IWORDS + 5] >> 21); }   // first classification item (front-to-back list)
     MGX_HD uint32_t prim_ends(int k) const { return (uint32_t)ti[to.prim_i + k * PRIM_IWORDS + 6]; }    // bit i: vertex i ends a convex part
     // tq layout: [n_prims * PRIM_RWORDS][pvx n_pverts][pvy n_pverts]
     MGX_HD double prim_r(int k, int j) const { return tq[k * PRIM_RWORDS + j]; }
@@ -171,9 +172,8 @@ MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_
             const int xw = rs.prim_xf(k), role = ((xw >> 24) & 3) - 1, ent = ((xw >> 26) & 0x3F) - 1;
             RI(prgb, k) = (env_col && ent >= 0 && role >= 0) ? palette[4 * role + env_col[(long)ent * stride + env]] : rs.prim_rgb_template(k);
         }
-        // the prim's slice of the item list: front (top) prims first
-        int start = 0;
-        for (int kk = h.n_prims - 1; kk > k; kk--) start += prim_item_count(rs, kk);
+        // the prim's slice of the item list: front (top) prims first (the world builder did the sum)
+        const int start = rs.prim_item_start(k);
         RI(pitem, k) = start | (prim_item_count(rs, k) << 16);
         const int kind = rs.prim_kind(k);
         if (kind == PR_LINELOOP) RD(prad, k) = rs.prim_r(k, 4);
@@ -196,7 +196,7 @@ MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_
         const double pcx = cam[0] * wx + cam[1] * wy + cam[4], pcy = cam[2] * wx + cam[3] * wy + cam[5];
         RD(pcx, k) = pcx; RD(pcy, k) = pcy;
         double sc = (double)NATIVE_RES / 2.04;
-        double rad = rs.prim_r(k, 5) * sc, apo = rad * cos(3.14159265358979323846 / nv);
+        double rad = rs.prim_r(k, 5) * sc, apo = rad * rs.prim_r(k, 4);       // (prim_r 4 of an n-gon: cos(pi / nv), from the world builder)
         RD(prad, k) = rad;
         RD(papo, k) = apo;
         double phi = 0.0;
@@ -430,7 +430,8 @@ MGX_HD int masked_item_index(const Raster &rs, uint64_t mask, int slot, int &n_t
 // (n-gons report -2 / 0 / +2 on the same scale; for line loops `lo` is the max touch margin: touched when lo >= 0).
 struct ClassState {
     uint64_t mixed; int base; int decided; float lo;
-    MGX_HD void init(int bg) { mixed = 0; base = bg; decided = 0; lo = 1e30f; }
+    int line;                        // some primitive of `mixed` is a line loop (the pixel queue keeps those apart, mgx_raster_body.inc)
+    MGX_HD void init(int bg) { mixed = 0; base = bg; decided = 0; lo = 1e30f; line = 0; }
 };
 constexpr float BIG_F = 1e30f;
 // Consume one item for the sample block centred at (xc, yc): TILE = whole 16x4-pixel tile (half extents TILE_HX/HY),
@@ -464,7 +465,7 @@ template <bool TILE> MGX_HD void classify_item(const Raster &rs, const Item &I, 
     if (I.meta & IT_LAST) {
         const int k = I.meta >> IT_K_SHIFT;
         if (!st.decided) {
-            if (kind == IT_SEG) { if (st.lo >= 0.0f) st.mixed |= 1ull << k; }
+            if (kind == IT_SEG) { if (st.lo >= 0.0f) { st.mixed |= 1ull << k; st.line = 1; } }
             else if (!(st.lo < -1.0f)) {
                 if (st.lo > 1.0f) { st.base = rs.prim_rgb(k); st.decided = 1; }     // topmost covering prim hides the rest
                 else st.mixed |= 1ull << k;

@@ -253,6 +253,7 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
             const bool mix = open && touch && !all, cover = open && touch && all;
             const uint64_t bit = 1ull << k;
             st.mixed |= mix ? bit : 0ull;
+            st.line |= (mix && kind == IT_SEG) ? 1 : 0;
             st.base = cover ? rgb : st.base;
             st.decided |= cover ? 1 : 0;
             lo = BIG_F;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
             *slot = (int32_t)got;
         }
         __syncthreads();
-        env = *slot;
+        env = __builtin_amdgcn_readfirstlane(*slot);      // (the same in every lane: keeps the env's frame pointer and row offsets on the scalar unit)
         if (env < 0) return;
         __syncthreads();           // (the slot is reused as a counter below)
     }

@@ -41,11 +41,11 @@ constexpr int CAP_PVERTS = 1024;
 
 constexpr int N_PHYS_VARS = 5;    // robot_pos, robot_rot, finger, shape_trans, shape_rot joint max forces (phys_vars.py)
 constexpr int JOINT_PARAMS = 10;   // ax ay bx by p0 p1 p2 bias_rate max_bias max_impulse
-constexpr int PRIM_IWORDS = 7;     // kind, nverts, voff | line-vertex offset << 16, xform|body<<8|(eye_body+1)<<16|(role+1)<<24|(entity+1)<<26, rgb(packed), stipple, part ends
+constexpr int PRIM_IWORDS = 7;     // kind, nverts, voff | line-vertex offset << 16, xform|body<<8|(eye_body+1)<<16|(role+1)<<24|(entity+1)<<26, rgb(packed), stipple | (goal+1) << 16 | first classification item << 21, part ends
 // A PR_POLY primitive is a union of convex parts drawn in one colour (a star: five triangles + a pentagon, entities.py:
 // 723-734): its vertices are the parts' vertices back to back and bit i of the `part ends` word marks vertex i as the
 // last one of its part (a plain convex polygon has the single bit nverts - 1) -- hence at most 32 vertices per primitive.
-constexpr int PRIM_RWORDS = 6;     // eye_base(2) eye_pre(2) line_halfwidth radius
+constexpr int PRIM_RWORDS = 6;     // eye_base(2) eye_pre(2) line_halfwidth (n-gons: cos(pi / nverts)) radius
 
 struct TmplHeader {
     int32_t n_bodies, n_shapes, n_verts, n_joints, n_pairs, n_prims, n_pverts;

@@ -565,6 +565,7 @@ int World::finalize(int max_steps, std::string &err) {
     for (auto &s : shapes) nverts += (s.kind == SH_CIRCLE) ? 1 : (int)s.verts.size();
     for (auto &p : prims) npv += (int)p.verts.size();
     for (auto &p : prims) if (p.verts.size() > 32) { err = "primitive with more than 32 vertices"; return -2; }
+    for (auto &p : prims) if (p.goal + 1 > 31) { err = "more than 30 goal regions"; return -2; }      // (5-bit field of the primitive record)
     if ((int)bodies.size() > CAP_BODIES || (int)shapes.size() > CAP_SHAPES || nverts > CAP_VERTS ||
         (int)joints.size() > CAP_JOINTS || (int)pairs.size() > CAP_PAIRS || (int)prims.size() > CAP_PRIMS ||
         npv > CAP_PVERTS) {
@@ -697,6 +698,11 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
         if (comp < 3) iw[o.body_prow + 3 * b + comp] = row;
     }
     int pvoff = 0, lvoff = 0;
+    // the rasteriser's classification items (one per polygon edge / line segment / n-gon) are listed FRONT TO BACK: primitive k's
+    // first item comes after those of every primitive drawn later
+    std::vector<int> item_start(h.n_prims + 1, 0);
+    for (int k = h.n_prims - 1; k >= 0; k--)
+        item_start[k] = item_start[k + 1] + (k + 1 < h.n_prims ? (prims[k + 1].kind == PR_NGON ? 1 : (int)prims[k + 1].verts.size()) : 0);
     for (int k = 0; k < h.n_prims; k++) {
         const PrimDef &P = prims[k];
         int32_t *pi = &iw[o.prim_i + k * PRIM_IWORDS];
@@ -706,7 +712,9 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
         if (P.kind == PR_LINELOOP) lvoff += (int)P.verts.size();
         pi[3] = P.xform | (P.body << 8) | ((P.eye_body + 1) << 16) | ((P.role + 1) << 24) | (int32_t)((uint32_t)(P.ent + 1) << 26);
         pi[4] = P.rgb[0] | (P.rgb[1] << 8) | (P.rgb[2] << 16);
-        pi[5] = P.stipple | ((P.goal + 1) << 16);      // low 16 bits: line stipple; high: 1 + goal ordinal
+        // low 16 bits: line stipple; 5 bits: 1 + goal ordinal; 11 bits: first classification item (< CAP_PVERTS + CAP_PRIMS)
+        static_assert(CAP_PVERTS + CAP_PRIMS <= 2048, "item index field");
+        pi[5] = P.stipple | ((P.goal + 1) << 16) | (int32_t)((uint32_t)item_start[k] << 21);
         {
             uint32_t ends = 0; int at = 0;
             for (int n : P.parts) { at += n; ends |= 1u << (at - 1); }
@@ -714,7 +722,7 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
             pi[6] = (int32_t)ends;
         }
         pr[0] = P.eye_base[0]; pr[1] = P.eye_base[1]; pr[2] = P.eye_pre[0]; pr[3] = P.eye_pre[1];
-        pr[4] = 0.5 * (P.line_width + 1.0);
+        pr[4] = P.kind == PR_NGON ? std::cos(3.14159265358979323846 / nv) : 0.5 * (P.line_width + 1.0);   // apothem / circumradius; line half width
         pr[5] = P.radius;
         for (size_t i = 0; i < P.verts.size(); i++) { rw[o.pvx + pvoff + i] = P.verts[i].x; rw[o.pvy + pvoff + i] = P.verts[i].y; }
         for (size_t i = 0; i < P.verts.size(); i++) iw[o.pv_prim + pvoff + i] = k;

@@ -4,7 +4,7 @@ cd /tmp; export TMPDIR=/tmp
 C="$1"; shift
 for kv in "$@"; do export "$kv"; done
 tag=$(echo "$*" | tr -c 'A-Za-z0-9\n' '_'); rm -rf /tmp/pq_$tag
-MGX_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $C -f csv -d /tmp/pq_$tag -o run -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-secondary --steps 60 > /tmp/pq_$tag.log 2>&1
+MGX_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $C -f csv -d /tmp/pq_$tag -o run -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-secondary --steps 60 $BENCH_ARGS > /tmp/pq_$tag.log 2>&1
 python - <<PY
 import csv, glob, collections, statistics
 fs = glob.glob('/tmp/pq_$tag/**/*counter_collection.csv', recursive=True)

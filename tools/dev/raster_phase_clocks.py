@@ -19,10 +19,10 @@ env._lib.mgx_engine_debug_raster_clocks(env._engine, C.c_void_p(clk.data_ptr()))
 env.render_frames(stack, view='ego', layout='stack4'); torch.cuda.synchronize()
 env._lib.mgx_engine_debug_raster_clocks(env._engine, C.c_void_p(0))
 c = clk.cpu().numpy().astype(np.float64)
-names = (('S', 1), ('C', 2), ('T', 3), ('Q+E', 4))
+names = (('stage', 0), ('S.bodies', 12), ('S.prims', 13), ('S', 1), ('C', 2), ('T', 3), ('Q+E', 4)) if c[:, 12].any() else (('stage', 0), ('S', 1), ('C', 2), ('T', 3), ('Q+E', 4))
 prev = 0
 for n, k in names:
     v = np.percentile(c[:, k], 50)
-    print('%-4s ends at p50 %6.1f us  (+%5.1f)   p90 %6.1f' % (n, v / 100, (v - prev) / 100, np.percentile(c[:, k], 90) / 100))
+    print('%-9s ends at p50 %6.1f us  (+%5.1f)   p90 %6.1f' % (n, v / 100, (v - prev) / 100, np.percentile(c[:, k], 90) / 100))
     prev = v
 print('queued pixels p50 %d p99 %d' % (np.percentile(c[:, 5], 50), np.percentile(c[:, 5], 99)))
