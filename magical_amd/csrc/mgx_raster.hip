@@ -270,7 +270,15 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
                                                 long env_stride, int view, const uint8_t *__restrict__ fill_mask, int n_envs, RasterHandoff ho) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
+    // phase clocks of a workgroup (tools/dev/raster_phase_clocks.py, fused_timeline.py): in -DMGX_RASTER_CLOCKS / -DMGX_RASTER_PROBE builds only
+    // -- the start time and the table pointer are four scalar registers held from the first instruction to the last, in a kernel that
+    // spills seventy of them
+#if defined(MGX_RASTER_PROBE) && !defined(MGX_RASTER_CLOCKS)
+#define MGX_RASTER_CLOCKS 1
+#endif
+#ifdef MGX_RASTER_CLOCKS
     unsigned long long clk0 = wall_clock64();
+#endif
 #ifdef MGX_RASTER_PROBE
 #define PROBE(...) __VA_ARGS__
 #else
@@ -286,13 +294,17 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
 #else
 #define RMARK(name)
 #endif
-#ifdef MGX_RASTER_PROBE   // development build: also allows truncating the kernel after phase i (tools/raster_phase_probe.py)
+#if defined(MGX_RASTER_PROBE)   // development build: also allows truncating the kernel after phase i (tools/raster_phase_probe.py)
 #define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + (i)] = wall_clock64() - clk0; if ((i) > 0 && t.dbg_stop == (i)) return;
-#else
+#elif defined(MGX_RASTER_CLOCKS)
 #define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + (i)] = wall_clock64() - clk0;
+#else
+#define CLK(i)
 #endif
     long env = blockIdx.x;
+#ifdef MGX_RASTER_CLOCKS
     if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + 9] = clk0;        // (absolute: tools/dev/fused_timeline.py)
+#endif
     // the shared draw list does not depend on the env: stage it before waiting for the hand-off
     if (!t.tmpl_stride_words) { const int n = raster_staged_words(t, t.words); for (int i = tid; i < n; i += 256) lds[i] = t.words[i]; }
     if (ho.mode) {
@@ -338,12 +350,7 @@ __global__ __launch_bounds__(256, 3) void k_raster_deferred(RasterDev t, const P
                                                    long env_stride, int view, int n_envs, RasterHandoff ho) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
-    unsigned long long clk0 = wall_clock64();
-#ifdef MGX_RASTER_PROBE
-#define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + (i)] = wall_clock64() - clk0; if ((i) > 0 && t.dbg_stop == (i)) return;
-#else
-#define CLK(i) if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + (i)] = wall_clock64() - clk0;
-#endif
+#define CLK(i)
     if (ho.deferred[blockIdx.x] != ho.epoch) return;                        // (workgroup-uniform)
     const long env = (long)(ho.queue[blockIdx.x] & 0xFFFFFFFFull);         // written by a kernel that has completed
     const uint8_t *fill_mask = nullptr;

@@ -1,5 +1,9 @@
-"""Phase clocks of a rasteriser workgroup (the shipped build records them when asked): wall-clock ticks (100 MHz) from the workgroup's start
-to the end of phases S, C, T and Q + E, all workgroups of one launch at full occupancy (development tool)."""
+"""Phase clocks of a rasteriser workgroup: wall-clock ticks (100 MHz) from the workgroup's start
+to the end of phases S, C, T and Q + E, all workgroups of one launch at full occupancy (development tool).
+Needs a -DMGX_RASTER_CLOCKS build of the library (the shipped one carries no phase clocks):
+  python -c "from magical_amd import _native as n; n.build(force=True, defines=['MGX_RASTER_CLOCKS'], out=n.LIB_PATH.replace('.so', '_clocks.so'))"
+  MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so python <this tool>
+"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

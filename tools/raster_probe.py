@@ -1,4 +1,8 @@
-"""GPU probe: k_raster launch time vs state / layout / view (development tool)."""
+"""GPU probe: k_raster launch time vs state / layout / view (development tool).
+Needs a -DMGX_RASTER_CLOCKS build of the library (the shipped one carries no phase clocks):
+  python -c "from magical_amd import _native as n; n.build(force=True, defines=['MGX_RASTER_CLOCKS'], out=n.LIB_PATH.replace('.so', '_clocks.so'))"
+  MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so python <this tool>
+"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, ctypes as C
