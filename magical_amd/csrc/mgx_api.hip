@@ -2,6 +2,7 @@
 // kernel launches.  Device state blobs and output tensors are owned by the caller (PyTorch);
 // the engine owns only its small constant template buffers and timing events.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <array>
 #include <mutex>
@@ -779,11 +780,13 @@ static int raster_capacity_ok(const mgx_engine *e) {
 }
 template <typename P>
 static int launch_raster(mgx_engine *e, const void *sp, uint8_t *out, int64_t env_stride, int view, int layout, const uint8_t *fill, hipStream_t st,
-                         const RasterHandoff &ho = RasterHandoff{}) {
+                         const RasterHandoff &ho = RasterHandoff{}, hipEvent_t done = nullptr) {
     size_t lds = e->lds_raster;
     auto go = [&](auto kern) -> int {
         if (int rc = ensure_lds((const void *)kern, lds, e->device)) return rc;
-        hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, fill, e->n_envs, ho);
+        // done: an event that completes with the kernel (its own completion signal: no marker packet behind it for the join to wait for)
+        if (done) hipExtLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, nullptr, done, 0, e->rdev, (const P *)sp, out, (long)env_stride, view, fill, e->n_envs, ho);
+        else hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, fill, e->n_envs, ho);
         return MGX_OK;
     };
     auto by_layout = [&](auto waves) -> int {
@@ -858,7 +861,7 @@ int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t 
     hipStream_t st = (hipStream_t)stream;
     if (!e->st2) {
         HIP_OK(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
-        HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&e->ev_join, getenv("MGX_JOIN_MARKER") ? hipEventDisableTiming : hipEventDefault));
         HIP_OK(hipMalloc(&e->d_queue, (size_t)e->n_envs * 8)); HIP_OK(hipMalloc(&e->d_deferred, (size_t)e->n_envs * 4)); HIP_OK(hipMalloc(&e->d_hand, 16));
         HIP_OK(hipMemset(e->d_queue, 0, (size_t)e->n_envs * 8)); HIP_OK(hipMemset(e->d_deferred, 0, (size_t)e->n_envs * 4)); HIP_OK(hipMemset(e->d_hand, 0, 16));
         HIP_OK(hipDeviceSynchronize());
@@ -885,14 +888,17 @@ int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t 
     if (rc) return recover(rc);
     rc = timing_begin(e, 1, e->st2);
     if (rc) return recover(rc);
-    rc = e->dtype == MGX_F32_PURE ? launch_raster<float>(e, state_p, out, env_stride, view, layout, nullptr, e->st2, rh)
-                                  : launch_raster<double>(e, state_p, out, env_stride, view, layout, nullptr, e->st2, rh);
+    static const bool join_on_kernel = getenv("MGX_JOIN_MARKER") == nullptr;      // (the join event completes with the rasteriser itself: no marker packet
+                                                                               // behind it; raster end -> next launch on the caller's stream 13 -> 11 us)
+    const bool jk = join_on_kernel && !timing_this_launch(e, 1);
+    rc = e->dtype == MGX_F32_PURE ? launch_raster<float>(e, state_p, out, env_stride, view, layout, nullptr, e->st2, rh, jk ? e->ev_join : nullptr)
+                                  : launch_raster<double>(e, state_p, out, env_stride, view, layout, nullptr, e->st2, rh, jk ? e->ev_join : nullptr);
     if (rc) return recover(rc);
     e->hand_tail += (unsigned)e->n_envs; e->hand_started += (unsigned)step_blocks(e);
     rc = timing_end(e, 1, e->st2);
     if (rc) return rc;
     // ... and the caller's stream waits for it: whatever comes next on `stream` sees the finished observation
-    HIP_OK(hipEventRecord(e->ev_join, e->st2));
+    if (!jk) HIP_OK(hipEventRecord(e->ev_join, e->st2));
     HIP_OK(hipStreamWaitEvent(st, e->ev_join, 0));
     // clean-up: the envs whose consumer gave up (producers not all running yet, or a wait that ran out) -- normally none
     rh.mode = 2;
