@@ -338,7 +338,12 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
         if (env < 0) return;
         __syncthreads();           // (the slot is reused as a counter below)
     }
+#ifdef MGX_TWO_PASS_ALWAYS
+    constexpr bool TWO_PASS_POLY = true;
+#else
     constexpr bool TWO_PASS_POLY = WAVES < 5;
+#endif
+    constexpr bool SCALAR_WAVE = WAVES < 5;
 #include "mgx_raster_body.inc"
 #undef CLK
 }
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(256, 3) void k_raster_deferred(RasterDev t, const P
     if ((todo[0] | todo[1] | todo[2] | todo[3]) == 0) return;                 // (workgroup-uniform)
     const uint8_t *fill_mask = nullptr;
     if (!t.tmpl_stride_words) { const int n = raster_staged_words(t, t.words); for (int i = tid; i < n; i += 256) lds[i] = t.words[i]; }
-    constexpr bool TWO_PASS_POLY = true;
+    constexpr bool TWO_PASS_POLY = true, SCALAR_WAVE = true;
     for (int w = 0; w < 4; w++) {
         const unsigned long long mw = todo[w];
         unsigned long long left = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(mw >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)mw);
