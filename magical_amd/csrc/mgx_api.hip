@@ -806,7 +806,7 @@ static int launch_raster_deferred(mgx_engine *e, const void *sp, uint8_t *out, i
     size_t lds = e->lds_raster;
     auto go = [&](auto kern) -> int {
         if (int rc = ensure_lds((const void *)kern, lds, e->device)) return rc;
-        hipLaunchKernelGGL(kern, dim3((e->n_envs + 255) / 256), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, e->n_envs, ho);
+        hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, e->n_envs, ho);
         return MGX_OK;
     };
     int rc = layout == MGX_OBS_FRAME ? go(k_raster_deferred<P, 0>) : layout == MGX_OBS_STACK4 ? go(k_raster_deferred<P, 1>)

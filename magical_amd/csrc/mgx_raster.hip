@@ -348,39 +348,23 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
 #undef CLK
 }
 
-// the clean-up launch of mgx_engine_step_render: the envs whose consumer gave up (normally none).  One workgroup looks at 256 queue
-// entries, one per thread, and rasterises the ones left to it one after the other -- 16 workgroups at 4096 envs, a 2 us launch when
-// there is nothing to do (a workgroup per entry, as before: 5 us per env-step); a kernel of its own, so that the launch statistics
-// of k_raster are those of real work (one occupancy variant serves every world)
+// the clean-up launch of mgx_engine_step_render: workgroup b rasterises queue[b]'s env iff consumer b gave up (normally none: 4.4 us,
+// the floor of a launch); a kernel of its own, so that the launch statistics of k_raster are those of real work (one occupancy
+// variant serves every world).  One workgroup per entry: where several engines share the GPU (the task fleet of BASELINE.json's
+// configs[4]) consumers give up by the hundred, and a launch of 16 workgroups that each walk 256 entries -- tried: no faster when
+// there is nothing to do -- rasterised them one after the other (8 x 1024 envs on one GPU: 3.59 -> 2.74 M env-steps/s)
 template <typename P, int LAYOUT>
 __global__ __launch_bounds__(256, 3) void k_raster_deferred(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
                                                    long env_stride, int view, int n_envs, RasterHandoff ho) {
     extern __shared__ __align__(16) uint32_t lds[];
-    __shared__ unsigned long long todo[4];
     const int tid = threadIdx.x;
 #define CLK(i)
-    const long b0 = (long)blockIdx.x * 256;
-    const bool mine = b0 + tid < n_envs && ho.deferred[b0 + tid] == ho.epoch;
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
-    if ((tid & 63) == 0) todo[tid >> 6] = m;
-    __syncthreads();
-    if ((todo[0] | todo[1] | todo[2] | todo[3]) == 0) return;                 // (workgroup-uniform)
+    if (ho.deferred[blockIdx.x] != ho.epoch) return;                        // (workgroup-uniform)
+    const long env = (long)(ho.queue[blockIdx.x] & 0xFFFFFFFFull);         // written by a kernel that has completed
     const uint8_t *fill_mask = nullptr;
     if (!t.tmpl_stride_words) { const int n = raster_staged_words(t, t.words); for (int i = tid; i < n; i += 256) lds[i] = t.words[i]; }
     constexpr bool TWO_PASS_POLY = true, SCALAR_WAVE = true;
-    for (int w = 0; w < 4; w++) {
-        const unsigned long long mw = todo[w];
-        unsigned long long left = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(mw >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)mw);
-        while (left) {
-            const int j = __builtin_ctzll(left);
-            left &= left - 1;
-            const long env = (long)(ho.queue[b0 + 64 * w + j] & 0xFFFFFFFFull);      // written by a kernel that has completed
-            {
 #include "mgx_raster_body.inc"
-            }
-            __syncthreads();
-        }
-    }
 #undef CLK
 }
 
