@@ -286,13 +286,19 @@ int mgx_world_randomise_all_poses(const mgx_world *w, double *poses, const int *
 
 // pm_randomise_all_poses for m envs, env k in the world world_of(k): envs are independent (own stream, own poses), so
 // they are spread over a few host threads
+static int host_threads() {
+    // world building and placement at a reset: as many threads as the host has cores, within [1, MGX_HOST_THREADS (default 32: ClusterColour-TestAll
+    // resets 41-62 ms at 16 threads, 31-48 at 32, no better at 64, worse at 128 -- the allocator)]
+    static const int cap = [] { const char *v = getenv("MGX_HOST_THREADS"); const int c = v ? atoi(v) : 32; return c < 1 ? 1 : (c > 256 ? 256 : c); }();
+    const int hw = (int)std::thread::hardware_concurrency();
+    return hw < 1 ? 1 : (hw > cap ? cap : hw);
+}
 template <typename WorldOf>
 static int randomise_batch(WorldOf world_of, int ne, int m, double *poses, const int *ents, int n, const uint8_t *ignore,
                            const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
                            const double *pos_limits, const double *rot_limits, int limits_per_env,
                            const uint64_t *mt_state_addr, const double *ent_hw) {
-    int n_threads = (int)std::thread::hardware_concurrency();
-    n_threads = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
+    int n_threads = host_threads();
     if (m < 64) n_threads = 1;
     std::vector<long> rej(n_threads, 0);
     std::vector<int> bad(n_threads, 0);
@@ -1104,8 +1110,7 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     }
     tm[ti++] = now();
     // build what is missing and serialise everything, a few host threads wide
-    int n_threads = (int)std::thread::hardware_concurrency();
-    n_threads = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
+    int n_threads = host_threads();
     if (uniq.size() < 8) n_threads = 1;
     auto work = [&](int t) {
         for (size_t u = t; u < uniq.size(); u += n_threads) {
