@@ -7,6 +7,9 @@ name = sys.argv[1] if len(sys.argv) > 1 else 'MatchRegions-TestCountPlus-LoRes4E
 N = 4096
 env = magical_amd.make(name, n_envs=N, device='cuda:0')
 env.seed(3); env.reset(); torch.cuda.synchronize()
+for _ in range(3):          # steady state: the first resets of a process also warm the allocator and the staging buffers up
+    for _ in range(10): env.step(torch.zeros(N, dtype=torch.int32, device='cuda:0'))
+    env.reset(); torch.cuda.synchronize()
 idx = np.arange(N)
 # time the native calls of the reset separately (cProfile does not see inside ctypes)
 native_ms = {}
