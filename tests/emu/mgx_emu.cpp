@@ -8,6 +8,9 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../magical_amd/csrc/mgx_raster.h"
@@ -97,6 +100,14 @@ static void emu_raster(const World &w, const P *sp, int n_envs, int env, int vie
     for (int lane = 0; lane < nl; lane++) raster_setup_bodies<P>(rs, sp, (long)n_envs, (long)env, lane, nl);
     for (int lane = 0; lane < nl; lane++) raster_setup_prims(rs, lane, nl);
     for (int lane = 0; lane < nl; lane++) raster_setup_edges(rs, lane, nl);
+    // what the set-up takes from the world builder instead of computing it per lane (round 3): a primitive's first slot in the
+    // front-to-back item list = the item counts of the primitives drawn after it, and an n-gon's cos(pi / n)
+    for (int k = 0, after = 0; k < h.n_prims; k++) {
+        after = 0;
+        for (int kk = h.n_prims - 1; kk > k; kk--) after += prim_item_count(rs, kk);
+        if (rs.prim_item_start(k) != after) { std::fprintf(stderr, "emu: item start of primitive %d is %d, expected %d\n", k, rs.prim_item_start(k), after); std::abort(); }
+        if (rs.prim_kind(k) == PR_NGON && rs.prim_r(k, 4) != std::cos(3.14159265358979323846 / rs.prim_nv(k))) { std::fprintf(stderr, "emu: n-gon %d carries no cos(pi / n)\n", k); std::abort(); }
+    }
     const int bg = 231 | (231 << 8) | (234 << 16);
     const uint64_t all = h.n_prims >= 64 ? ~0ull : ((1ull << h.n_prims) - 1ull);
     if (native) {
