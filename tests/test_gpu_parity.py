@@ -1489,3 +1489,38 @@ def test_batched_draws_equal_the_per_env_loop(env_name, n):
         assert da.all() and np.array_equal(ia['eval_score'], ib['eval_score'])
     assert all(x.randint(1 << 30) == y.randint(1 << 30) for x, y in zip(a.rngs, b.rngs))
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_fused_step_schedules_are_interchangeable():
+    """The switches that change HOW the fused env-step is issued (the join on the rasteriser's own completion signal / on a marker
+    event behind it; the two kernels one after the other) change nothing about what it computes: one short rollout with a partial
+    episode end inside, each schedule in a process of its own (the switches are read once per process), same observation and state
+    digests."""
+    import subprocess, sys, os, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import sys, hashlib, json; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch, magical_amd\n"
+        "n = 300\n"
+        "env = magical_amd.make('MoveToCorner-Demo-LoRes4E-v0', n_envs=n, device='cuda:0', max_episode_steps=9)\n"
+        "env.seed(5); env.reset()\n"
+        "clocks = np.zeros(n, dtype=np.int64); clocks[::3] = 4\n"
+        "env.set_episode_steps(clocks)\n"
+        "tape = np.random.RandomState(11).randint(0, 18, size=(14, n)).astype(np.int32)\n"
+        "h = hashlib.sha256()\n"
+        "for s in range(14):\n"
+        "    obs, rew, done, info = env.step(tape[s])\n"
+        "    h.update(obs.cpu().numpy().tobytes()); h.update(np.asarray(done).tobytes()); h.update(np.asarray(info['eval_score']).tobytes())\n"
+        "h.update(env.get_bodies().tobytes())\n"
+        "print(json.dumps({'digest': h.hexdigest(), 'stats': list(env.handoff_stats())}))\n" % root)
+    out = {}
+    for name, var in (('completion signal', None), ('marker event', 'MGX_JOIN_MARKER'), ('one after the other', 'MGX_NO_OVERLAP')):
+        envv = {k: v for k, v in os.environ.items() if k not in ('MGX_JOIN_MARKER', 'MGX_NO_OVERLAP')}
+        if var:
+            envv[var] = '1'
+        r = subprocess.run([sys.executable, '-c', prog], capture_output=True, text=True, env=envv, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out[name]['stats'][1] == 0, (name, out[name])          # no hand-off wait ran out
+    assert out['completion signal']['digest'] == out['marker event']['digest'] == out['one after the other']['digest'], out
