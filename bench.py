@@ -65,11 +65,17 @@ def kernel_resources():
     return _RESOURCES
 
 
-def scratch_bytes(kernel, n_envs, lanes_per_env):
+def scratch_bytes(kernel, n_envs, lanes_per_env, dtype='f32', raster_lds=None, layout=1):
     """Static scratch footprint of one launch: private segment bytes per lane x lanes launched (step: n_envs x lanes_per_env;
-    raster: 256 per env), for the instantiation the default workload uses; None if the code object cannot be read."""
+    raster: 256 per env) of the instantiation this workload runs -- k_step<R,P,L> / k_step_wide (all-fp64) / k_step_env (one env per
+    wavefront); k_raster<P,LAYOUT,WAVES> with WAVES from the LDS footprint as the host picks it; None if the code object cannot be read."""
     res = kernel_resources()
-    want = ('k_stepIfdLi%d' % lanes_per_env) if kernel == 'k_step' else 'k_rasterIdLi1ELi5'
+    rp = {'f32': 'fd', 'f64': 'dd', 'f32_pure': 'ff'}.get(dtype, 'fd')
+    if kernel == 'k_step':
+        want = ('k_step_envI%sE' % rp) if lanes_per_env == 64 else (('k_step_wideI%sLi%dE' if dtype == 'f64' else 'k_stepI%sLi%dE') % (rp, lanes_per_env))
+    else:
+        fit = 5 if not raster_lds else max(3, min(5, (160 * 1024) // ((int(raster_lds) + 511) // 512 * 512)))
+        want = 'k_rasterI%sLi%dELi%dE' % (rp[1], layout, fit)
     for name, r in res.items():
         if want in name and 'deferred' not in name:
             return r['scratch_bytes_per_lane'] * (n_envs * lanes_per_env if kernel == 'k_step' else n_envs * 256)
@@ -282,8 +288,11 @@ def measure(args, rank, world, device):
             score_host[done] = info['eval_score'][done]
     last_score.copy_(torch.as_tensor(score_host))
     # end-of-rollout gather over xGMI (RCCL): per-env scores of every rank; observations never leave their GPU
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
     all_scores = gather_rollout_results(last_score, n * world)
     barrier()
+    gather_ms = (time.perf_counter() - tg) * 1e3
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -350,6 +359,13 @@ def measure(args, rank, world, device):
                     break
                 except Exception:
                     continue
+        def scratch_of(kname):
+            try:
+                from magical_amd import _native
+                lds_r = _native.lib().mgx_engine_lds_bytes(env._engine, 1)
+            except Exception:
+                lds_r = None
+            return scratch_bytes(kname, n, env.lanes_per_env, args.dtype, lds_r, 1 if '-LoRes4' in args.task else 0)
         def alu_fields(kname):
             d = ((alu or {}).get(kname) or {}).get('derived') or {}
             return {k: d.get(k) for k in ('valu_util', 'valu_busy', 'occupancy_waves_per_simd', 'wait_share', 'issue_stall_share', 'active_share',
@@ -391,9 +407,12 @@ def measure(args, rank, world, device):
                        'roofline_bytes_row': 'SURVEY.md 8(d) headline row: state + ONE new 96x96x3 frame per env-step (ring of planar frames)' if ring else
                                              'SURVEY.md 8(d) parenthetical row: [96,96,12] stack re-materialised each step (9 B read + 12 B '
                                              'written per pixel + pose rows); frac_new_frame_row uses the 28.3 KB headline row'},
+            'collective': {'backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')) if dist.is_initialized() else None,
+                           'world_size': world, 'in_timed_region': f'all_gather of the shard sizes + all_gather of the per-env scores f64[{n}] per rank, once, at the end of the rollout',
+                           'ms': gather_ms} if dist.is_initialized() else {'backend': None, 'note': 'no process group: single process, gather skipped'},
             'roofline': {'bound': bound_of(dom), 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         **alu_fields(dom), 'alu_source': alu_src, 'scratch_bytes': scratch_bytes(dom, n, env.lanes_per_env),
+                         **alu_fields(dom), 'alu_source': alu_src, 'scratch_bytes': scratch_of(dom),
                          'frac_new_frame_row': (ring_bytes / (kernels[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom == 'k_raster' else None,
                          'launch_mode': ('fused: k_raster runs concurrently with k_step and consumes envs as they finish, so its launch duration '
                                          'includes hand-off waits' if alone_ms else 'one kernel after the other'),
@@ -403,7 +422,7 @@ def measure(args, rank, world, device):
                          'avg_launch_ms': kernels[dom][0], 'algorithmic_bytes_per_launch': kernels[dom][1],
                          'other_kernels': {k: {'avg_launch_ms': v[0], 'algorithmic_bytes_per_launch': v[1],
                                                'achieved_GBs': v[1] / (v[0] * 1e-3) / 1e9, 'bound': bound_of(k), **alu_fields(k),
-                                               'scratch_bytes': scratch_bytes(k, n, env.lanes_per_env)} for k, v in kernels.items() if k != dom}},
+                                               'scratch_bytes': scratch_of(k)} for k, v in kernels.items() if k != dom}},
         }
     env.close()
     return out if rank == 0 else None
@@ -419,12 +438,14 @@ def main():
     ap.add_argument('--lanes', type=int, default=0)
     ap.add_argument('--dtype', default='f32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-secondary', action='store_true', help='default line only: skip the two short secondary lines (all-fp64 build, ClusterColour)')
+    ap.add_argument('--no-secondary', action='store_true', help='default line only: skip the short secondary lines (all-fp64 build, ClusterColour, state-only, config 5 at rank size)')
     ap.add_argument('--obs-ring', type=int, default=0, help='with a -LoResCHW4E- task: frames kept as planes in a ring of this many frames '
                     '(MGX_OBS_PLANAR; the channels-first stack is a window of the ring), priced on the 28.3 KB row of SURVEY.md 8(d)')
     ap.add_argument('--config5', action='store_true', help='BASELINE.json configs[4]: all 8 tasks x Demo-LoRes4E, --envs5 envs per task sharded over '
                                                            'the GPUs, one engine + HIP stream per task on every GPU, one RCCL gather at the end')
     ap.add_argument('--envs5', type=int, default=8192, help='envs per task over the whole job (config 5)')
+    ap.add_argument('--no-collective', action='store_true', help='--gpus 1: do not form the one-rank RCCL group (the end-of-rollout gather is then skipped)')
+    ap.add_argument('--force-collective', action='store_true', help='--gpus 1: fail instead of carrying on without the gather if the one-rank RCCL group cannot be formed')
     args = ap.parse_args()
     if args.config5:
         return main_config5(args)
@@ -432,12 +453,23 @@ def main():
     import torch
     import torch.distributed as dist
     from magical_amd.distributed import gather_rollout_results, init_from_env
-    rank, world, local_rank = init_from_env(backend='nccl')      # "nccl" == RCCL on ROCm
+    # "nccl" == RCCL on ROCm.  One GPU: a process group of ONE rank, so that the line's timed region holds the same RCCL all_gather
+    # as the N-GPU lines (the collective runs on the one GPU; without a group the gather would be skipped)
+    collective_error = None
+    try:
+        rank, world, local_rank = init_from_env(backend='nccl', single_process_group=not args.no_collective)
+    except Exception as ex:
+        if args.force_collective or int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            raise
+        collective_error = f'{type(ex).__name__}: {ex}'
+        rank, world, local_rank = 0, 1, 0
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
 
     out = measure(args, rank, world, device)
+    if rank == 0 and collective_error:
+        out['collective'] = {'backend': None, 'error': collective_error}
     if rank == 0:
         # Driver-executed, outside the headline's timed region: the reference-precision build and BASELINE.json configs[3]
         # (ClusterColour, many contacts) on short windows with the same window plan -- so that these lines are not builder-run only
@@ -445,7 +477,8 @@ def main():
         if default_line and not args.no_secondary:
             import copy
             sec = {}
-            for key, over in (('f64', {'dtype': 'f64'}), ('clustercolour', {'task': 'ClusterColour-Demo-LoRes4E-v0'})):
+            for key, over in (('f64', {'dtype': 'f64'}), ('clustercolour', {'task': 'ClusterColour-Demo-LoRes4E-v0'}),
+                              ('state_only', {'task': 'MoveToCorner-Demo-v0'})):       # BASELINE.json configs[2] (reference precision), [3], [1]
                 a2 = copy.copy(args)
                 a2.steps, a2.warmup = 40, 5
                 for k, v in over.items():
@@ -457,6 +490,16 @@ def main():
                                 'episodes_finished': o2['config']['episodes_finished'], 'roofline': o2['roofline']}
                 except Exception as ex:          # the headline must not be lost to a secondary line
                     sec[key] = {'error': f'{type(ex).__name__}: {ex}'}
+            # BASELINE.json configs[4] at rank size: the 8 Demo tasks x 1024 envs as 8 engines on 8 HIP streams of this one GPU (what each
+            # of the 8 ranks of the 8192-env job runs), one short window, the score table through the same gather
+            try:
+                sc5, eps5, el5 = run_config5(1024, 20, 5, 0, 1, device, 'f32')
+                sec['config5_rank_size_env_steps_per_s'] = len(CONFIG5_TASKS) * 1024 * 20 / el5
+                sec['config5_rank_size'] = {'tasks': CONFIG5_TASKS, 'envs_per_task': 1024, 'steps': 20, 'warmup': 5, 'ms_per_step': el5 / 20 * 1e3,
+                                            'episodes_finished': eps5, 'mean_eval_score': float(sc5.mean().item()),
+                                            'note': 'a step = one env-step of each of the 8 tasks (8192 env-steps); one rank\'s share of configs[4]'}
+            except Exception as ex:
+                sec['config5_rank_size'] = {'error': f'{type(ex).__name__}: {ex}'}
             out['secondary'] = sec
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

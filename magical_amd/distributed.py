@@ -14,28 +14,38 @@ def env_shard(n_total, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, single_process_group=False):
     """Join the torch.distributed group described by RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
-    (rank, world_size, local_rank); a no-op for single-process runs."""
+    (rank, world_size, local_rank).  A single-process run joins no group -- unless `single_process_group`: then a group of ONE
+    rank is formed on 127.0.0.1 (a free port unless MASTER_PORT is set), so that the end-of-rollout gather really goes through the
+    backend (RCCL on a GPU box) on the one GPU there is."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_process_group) and not dist.is_initialized():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this driver
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if 'MASTER_PORT' not in os.environ:
+                import socket
+                with socket.socket() as s:
+                    s.bind(('127.0.0.1', 0))
+                    os.environ['MASTER_PORT'] = str(s.getsockname()[1])
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
 
 def gather_rollout_results(local, n_total=None):
     """All-gather a per-env result tensor [n_local, ...] along dim 0 in rank order -> [n_total, ...] on every
-    rank.  Shards may differ in length by one (env_shard), so this pads to the longest shard."""
+    rank.  Shards may differ in length by one (env_shard), so this pads to the longest shard.  Without a process group the
+    local tensor is the result; in a group of one rank (init_from_env(single_process_group=True)) the collective still runs."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size()
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
