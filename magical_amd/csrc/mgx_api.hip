@@ -474,7 +474,7 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     const int qcap_lds = (!e->env_worlds && n_goals_w == 0 && n_blocks_w <= 1 && !getenv("MGX_QCAP_FULL")) ? QCAP_SMALL : QCAP;
     e->rdev.qcap_lds = qcap_lds;
     if (e->rdev.qcap <= 0 || e->rdev.qcap > qcap_lds) e->rdev.qcap = qcap_lds;
-    const int extra = N_TILES * 3 + qcap_lds * 4 + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2 + (MGX_Q16 ? ESCAP / 2 : 0);
+    const int extra = N_TILES * 3 + qcap_lds * 4 + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2;
     // As many rasteriser workgroups per CU as LDS allows (allocations round up to 512 B), between 3 and 5; a step is worth 13-15 % of
     // the launch.  Two economies are taken only where they buy such a step, the cheaper one first:
     //  - the draw list's fp64 part (local vertices, radii: read once per frame, by the set-up) stays in HBM instead of being staged
@@ -693,7 +693,7 @@ int mgx_engine_create(const mgx_world *w, int n_envs, int device, int dtype, int
     e->tdev.words = e->d_step; e->tdev.n_words = (int)b.step.size(); e->tdev.tmpl_stride_words = 0;
     e->tdev.off_r = b.step_off_r; e->tdev.off_p = b.step_off_p; e->tdev.env_off_r = b.step_env_off_r; e->tdev.env_off_i = b.step_env_off_i;
     e->rdev.words = e->d_raster; e->rdev.n_words = (int)b.raster.size(); e->rdev.tmpl_stride_words = 0;
-    e->rdev.bg_rgb = BG_RGB; e->rdev.qcap = e->rdev.qcap_lds; e->rdev.ecap = ECAP; e->rdev.escap = ESCAP; e->rdev.palette = e->d_palette;
+    e->rdev.bg_rgb = BG_RGB; e->rdev.qcap = e->rdev.qcap_lds; e->rdev.ecap = ECAP; e->rdev.palette = e->d_palette;
     rc = build_score_tables(e);
     if (rc) { mgx_engine_destroy(e); return rc; }
     *out = e;
@@ -939,14 +939,7 @@ int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_
     return MGX_OK;
 }
 int mgx_engine_debug_raster_waves(mgx_engine *e, int n) { if (e && n >= 3 && n <= 5) e->raster_waves = n; return MGX_OK; }
-int mgx_engine_debug_raster_ecap(mgx_engine *e, int n) {
-    if (!e) return MGX_OK;
-    e->rdev.ecap = n < 1 ? 1 : (n > ECAP ? ECAP : n);
-    // the sample list shrinks with the records, but always holds one pixel's sixteen samples: a round then completes at least one pixel
-    const int ns = 2 * e->rdev.ecap;
-    e->rdev.escap = ns < 16 ? 16 : (ns > ESCAP ? ESCAP : ns);
-    return MGX_OK;
-}
+int mgx_engine_debug_raster_ecap(mgx_engine *e, int n) { if (e) e->rdev.ecap = n < 1 ? 1 : (n > ECAP ? ECAP : n); return MGX_OK; }
 int mgx_engine_debug_raster_qcap(mgx_engine *e, int n) { if (e) e->rdev.qcap = n < 1 ? 1 : (n > e->rdev.qcap_lds ? e->rdev.qcap_lds : n); return MGX_OK; }
 int mgx_engine_debug_raster_stop(mgx_engine *e, int phase) { if (e) e->rdev.dbg_stop = phase; return MGX_OK; }
 int mgx_engine_debug_raster_clocks(mgx_engine *e, void *buf) { if (e) e->rdev.dbg_clk = (unsigned long long *)buf; return MGX_OK; }

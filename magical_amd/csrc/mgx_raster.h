@@ -28,7 +28,6 @@ struct RasterOff {
                                         // the normalised edge function's coefficients; compact: the exact tests rebuild them (edge_coeffs)
     int vstride, compact;               // doubles per vertex record (6, compact 3)
     int elen, earc;                     // per LINE-LOOP vertex: segment length and arclength at the segment start
-    int la, lb, lc, ld;                 // ... and its carrier line a x + b y + c (distance) and arclength function b x - a y + d, for phase Q
     int pcx, pcy, prad, papo, pphi;     // per prim (n-gon centre/radius/apothem/phase; line half width in prad)
     int n_d;
     int prgb;                           // per prim colour of THIS env (the template's, or the env's own: TestColour variants)
@@ -41,7 +40,6 @@ struct RasterOff {
     static constexpr bool A_V = MGX_RAOS & 1, A_P = MGX_RAOS & 2, A_B = MGX_RAOS & 4;
     static constexpr int S_bx = A_B ? 5 : 1, S_by = S_bx, S_ba = S_bx, S_bc = S_bx, S_bs = S_bx;
     static constexpr int S_elen = 1, S_earc = 1;      // (the vertex records have a run-time stride: RDV)
-    static constexpr int S_la = 1, S_lb = 1, S_lc = 1, S_ld = 1;
     static constexpr int S_pcx = A_P ? 5 : 1, S_pcy = S_pcx, S_prad = S_pcx, S_papo = S_pcx, S_pphi = S_pcx;
     static constexpr int S_prgb = 1, S_items = 1, S_pitem = 1;
     // compact: three doubles per draw-list vertex less (2.6 KB of LDS in ClusterColour: a fourth workgroup per CU) for a dozen more
@@ -52,7 +50,6 @@ struct RasterOff {
         { const int d = A_B ? 1 : h.n_bodies; bx = o; by = o + d; ba = o + 2 * d; bc = o + 3 * d; bs = o + 4 * d; o += 5 * h.n_bodies; }
         svx = o; svy = o + 1; einv = o + 2; ea = o + 3; eb = o + 4; ec = o + 5; o += vstride * h.n_pverts;
         elen = o; o += h.n_lverts; earc = o; o += h.n_lverts;
-        la = o; o += h.n_lverts; lb = o; o += h.n_lverts; lc = o; o += h.n_lverts; ld = o; o += h.n_lverts;
         { const int d = A_P ? 1 : h.n_prims; pcx = o; pcy = o + d; prad = o + 2 * d; papo = o + 3 * d; pphi = o + 4 * d; o += 5 * h.n_prims; }
         n_d = o;
         o = 0;
@@ -295,7 +292,6 @@ MGX_HD void raster_setup_edges(Raster &rs, int lane, int nl) {
             }
             const int lv = rs.prim_lvoff(k) + i;
             RD(elen, lv) = len; RD(earc, lv) = arc;
-            RD(la, lv) = ea; RD(lb, lv) = eb; RD(lc, lv) = ec; RD(ld, lv) = ea * ay - eb * ax;
             it->g0 = (float)ax; it->g1 = (float)ay; it->g2 = (float)len; it->g3 = (float)RD(prad, k);
         } else {
             // edge function divided by its conservative half-extent over a 4x4 sample block (g0..g2: the block is
@@ -801,124 +797,7 @@ MGX_HD uint64_t pixel_add_exact(const Raster &rs, int X, int Y, uint64_t mixed, 
     }
     return sums;
 }
-// ---------------------------------------------------------------- resolving an undecided pixel, one lane per SAMPLE (round 4)
-// A queued pixel belongs to a DPP row of 16 lanes and a lane to one sample of its 4x4 block: sample s sits i = s & 3 to the right of
-// and j = s >> 2 below the block's top-left sample; its 384-grid centre is a half-integer, exact in fp32.  The painter runs front to
-// back per sample: the first opaque primitive that holds the sample gives its colour; a line loop met on the way is blended over that
-// colour at the end.  Every decision carries the error bounds of the mask form above -- a sample within CLASS_EPS_F of a polygon edge,
-// within NGON_TOL_F of an n-gon edge, on an undecidable stipple bit, under two line loops at once or with a blended channel within
-// TAU of a rounding boundary is reported as uncertain and goes to the fp64 painter (pixel_add_exact), so the bytes are the all-fp64
-// painter's whatever the fast path flags.  The device walks the primitives of the wavefront's four pixels in one wave-uniform loop
-// (mgx_raster_body.inc); the pieces below are what a lane does for one primitive, shared with the host emulation (tests/emu).
-MGX_HD void sample_pos(int X, int Y, int s, float &fx, float &fy) {
-    fx = 4.0f * X + 0.5f + (float)(s & 3); fy = (float)NATIVE_RES - 0.5f - 4.0f * Y - (float)(s >> 2);
-}
-// item fields a, b, c (+ g0) as one 16-byte LDS read
-struct Item4 { float a, b, c, g0; };
-MGX_HD Item4 load_item4(const Raster &rs, int idx) { return *reinterpret_cast<const Item4 *>(&RI(items, 8 * idx)); }
-MGX_HD float edge_at(const Item4 &it, float fx, float fy) { return __builtin_fmaf(it.a, fx, __builtin_fmaf(it.b, fy, it.c)); }
-// verdict of a sample against an opaque primitive
-enum { SV_OUT = 0, SV_IN = 1, SV_AMB = 2 };
-// convex-part polygon: inside a part when inside every one of its edges, inside the polygon when inside a part
-MGX_HD int poly_sample(const Raster &rs, int i0, int nv, uint32_t ends, float fx, float fy) {
-    bool in_all = true, out = false, cov = false, ua = false;
-    for (int e = 0; e < nv; e++) {
-        const float v = edge_at(load_item4(rs, i0 + e), fx, fy);
-        in_all = in_all && v >= CLASS_EPS_F; out = out || v < -CLASS_EPS_F;
-        if ((ends >> e) & 1u) { cov = cov || in_all; ua = ua || (!in_all && !out); in_all = true; out = false; }
-    }
-    return cov ? SV_IN : (ua ? SV_AMB : SV_OUT);
-}
-// regular n-gon (the arithmetic of ngon_coverage16 for one sample); `want`: lanes whose verdict is needed (the rest skip the annulus)
-MGX_HD int ngon_sample(const Raster &rs, int k, int i0, int n, float fx, float fy, bool want) {
-    const Item4 it = load_item4(rs, i0);
-    const float qx = fx - it.a, qy = fy - it.b, d2 = qx * qx + qy * qy;
-    const float apo = it.c - CLASS_EPS_F, rad = it.g0 + CLASS_EPS_F, apo2 = apo > 0.0f ? apo * apo : -1.0f, rad2 = rad * rad;
-    if (d2 <= apo2) return SV_IN;
-    if (!(d2 <= rad2) || !want) return SV_OUT;
-    const float step = 6.283185307179586f / (float)n, phi = (float)RD(pphi, k);
-    float ss, cs, s, c;
-    r_sincos<float>(step, ss, cs);
-    const float kk = floorf((atan2f(qy, qx) - phi) / step);
-    r_sincos<float>(phi + (kk + 0.5f) * step, s, c);
-    const float d0 = qx * c + qy * s;                                      // this sector's edge
-    const float dp = qx * (c * cs - s * ss) + qy * (s * cs + c * ss);      // next sector
-    const float dm = qx * (c * cs + s * ss) + qy * (s * cs - c * ss);      // previous sector
-    const float d = r_max(d0, r_max(dp, dm)) - it.c;
-    if (r_abs(d) < NGON_TOL_F) return SV_AMB;
-    return d <= 0.0f ? SV_IN : SV_OUT;
-}
-// fp32 alpha of one sample for the segment at line-loop vertex lv: the carrier line and the arclength function are evaluated at the
-// sample in fp64 and rounded once (|error of alpha| < ALPHA_ERR_F: the terms are O(1) wherever alpha can be non-zero); `amb` is raised
-// when the stipple bit cannot be decided in fp32
-MGX_HD float seg_alpha_sample(const Raster &rs, int lv, float hw, int stipple, float fx, float fy, bool &amb) {
-    const double x = (double)fx, y = (double)fy;
-    const double A = RD(la, lv), B = RD(lb, lv), len = RD(elen, lv);
-    const double E = A * x + (B * y + RD(lc, lv)), S = B * x + (RD(ld, lv) - A * y);
-    const float e = (float)E, s = (float)S, sb = (float)(S - len), lenf = (float)len;
-    const float t = r_max(r_max(-s, sb), 0.0f);
-    float al = r_clamp01(hw - sqrtf(e * e + t * t));
-    if (stipple) {
-        const double arc = RD(earc, lv);
-        const float u0 = (float)(arc - 16.0 * rz_floor(arc * 0.0625));
-        const float u = u0 + r_clamp(s, 0.0f, lenf), fl = floorf(u);
-        if (al > 0.0f && (u - fl < STIPPLE_TOL_F || fl + 1.0f - u < STIPPLE_TOL_F)) amb = true;
-        if (!((stipple >> (((int)fl) & 15)) & 1)) al = 0.0f;
-    }
-    return al;
-}
-// line colour `lcol` with coverage a over the opaque colour `under`; `unc` when a channel is within TAU of a rounding boundary
-MGX_HD int blend_sample(int under, int lcol, float a, bool &unc) {
-    constexpr float TAU = 255.0f * ALPHA_ERR_F + 5e-4f;
-    const float lrf = (float)(lcol & 0xFF), lgf = (float)((lcol >> 8) & 0xFF), lbf = (float)((lcol >> 16) & 0xFF);
-    const float cr = (float)(under & 0xFF), cg = (float)((under >> 8) & 0xFF), cb = (float)((under >> 16) & 0xFF);
-    const float vr = cr + a * (lrf - cr) + 0.5f, vg = cg + a * (lgf - cg) + 0.5f, vb = cb + a * (lbf - cb) + 0.5f;
-    const float fr = floorf(vr), fg = floorf(vg), fb = floorf(vb);
-    const float dr = r_abs(vr - fr - 0.5f), dg = r_abs(vg - fg - 0.5f), db = r_abs(vb - fb - 0.5f);
-    if (r_max(r_max(dr, dg), db) > 0.5f - TAU) unc = true;
-    return (int)fr | ((int)fg << 8) | ((int)fb << 16);
-}
-// one sample, every primitive of `mixed` in turn (the host emulation's form of phase Q; the device's is the wave-uniform loop)
-MGX_HD int sample_resolve_fast(const Raster &rs, int X, int Y, int sidx, uint64_t mixed, int base, bool &unc) {
-    float fx, fy;
-    sample_pos(X, Y, sidx, fx, fy);
-    float pa = 0.0f; int pcol = 0, under = base;
-    unc = false;
-    for (uint64_t m = mixed; m;) {
-        const int k = 63 - __builtin_clzll(m);
-        m &= ~(1ull << k);
-        const int kind = rs.prim_kind(k), nv = rs.prim_nv(k), i0 = RI(pitem, k) & 0xFFFF;
-        if (kind == PR_LINELOOP) {
-            const float hw = (float)RD(prad, k);
-            float al = 0.0f; bool amb = false;
-            for (int e = 0; e < nv; e++)
-                if (r_abs(edge_at(load_item4(rs, i0 + e), fx, fy)) <= hw + CLASS_EPS_F)
-                    al = r_max(al, seg_alpha_sample(rs, rs.prim_lvoff(k) + e, hw, rs.prim_stipple(k), fx, fy, amb));
-            if (amb || (al > 0.0f && pa > 0.0f)) { unc = true; return 0; }      // (two line loops over one sample: the exact painter's)
-            if (al > 0.0f) { pa = al; pcol = rs.prim_rgb(k); }
-        } else {
-            const int v = kind == PR_POLY ? poly_sample(rs, i0, nv, rs.prim_ends(k) | (1u << (nv - 1)), fx, fy) : ngon_sample(rs, k, i0, nv, fx, fy, true);
-            if (v == SV_AMB) { unc = true; return 0; }
-            if (v == SV_IN) { under = rs.prim_rgb(k); break; }
-        }
-    }
-    return pa > 0.0f ? blend_sample(under, pcol, pa, unc) : under;
-}
 MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int base) {
-    uint64_t sums = 0;
-    uint32_t uncertain = 0;
-    for (int s = 0; s < 16; s++) {
-        bool unc;
-        const int c = sample_resolve_fast(rs, X, Y, s, mixed, base, unc);
-        if (unc) uncertain |= 1u << s;
-        else sums += (uint64_t)(c & 0xFF) | ((uint64_t)((c >> 8) & 0xFF) << 12) | ((uint64_t)((c >> 16) & 0xFF) << 24);
-    }
-    MGX_RSTAT(0, 1); MGX_RSTAT(6, uncertain ? 1 : 0); MGX_RSTAT(7, __builtin_popcount(uncertain));
-    if (uncertain) sums = pixel_add_exact(rs, X, Y, mixed, base, sums, uncertain);
-    return pixel_finish(sums);
-}
-// the round-3 form (one lane per pixel, 16-bit coverage masks): kept for A/B builds (-DMGX_Q16=0)
-MGX_HD int pixel_resolve_masks(const Raster &rs, int X, int Y, uint64_t mixed, int base) {
     uint32_t unc;
     uint64_t sums = pixel_resolve_fast(rs, X, Y, mixed, base, unc);
     if (unc) sums = pixel_add_exact(rs, X, Y, mixed, base, sums, unc);

@@ -35,7 +35,6 @@ struct RasterDev {
     int qcap;                      // queue entries in use (<= qcap_lds; tests shrink it to exercise the overflow rounds)
     int qcap_lds;                  // queue entries the LDS layout holds (<= QCAP; the host's choice by world, configure_launch)
     int ecap;                      // phase E records in use (<= ECAP; likewise)
-    int escap;                     // phase E sample-list slots in use (<= ESCAP; likewise)
 };
 
 // Consumer side of the step -> raster hand-off (mgx_engine_step_render; producer: StepHandoff in mgx_step.hip).
@@ -71,10 +70,6 @@ constexpr int QCAP_SMALL = 640;   // ... of the worlds without a goal region and
                                   // at the median, 550 at p99.9, 660 at most over 2 x 10^5 frames, tools/dev/nq_stats.py): 6 KB less LDS
 constexpr int OVF_WORDS = LORES * LORES / 32;
 constexpr int ECAP = 256;      // phase E records per round (uncertain pixels beyond that wait in the bitmap like queue overflow)
-constexpr int ESCAP = 512;     // ... and uncertain samples per round (u16 each)
-#ifndef MGX_Q16
-#define MGX_Q16 1              // phase Q: a DPP row per queued pixel, a lane per sample (0: the round-3 form, a lane per pixel -- A/B builds)
-#endif
 // k_raster is instantiated for 3, 4 and 5 workgroups per CU (= waves per SIMD: VGPR caps 168 / 128 / 96); the host picks
 // the one the world's LDS footprint allows, so that LDS-bound worlds are not squeezed into fewer registers for nothing
 #ifndef MGX_RASTER_WAVES
@@ -161,23 +156,6 @@ template <int LAYOUT> __device__ __forceinline__ void store_patch(uint8_t *frame
     const int first = LAYOUT == LAY_SLOT0 ? 0 : (fill ? (LAYOUT == LAY_STACK4 ? 0 : 3) : 9);   // after a reset every frame of the stack
     const int last = LAYOUT == LAY_SLOT0 ? 3 : 12;
     for (int k = first; k < last; k += 3) { px[k] = r; px[k + 1] = g; px[k + 2] = b; }
-}
-// phase Q, one lane per byte: lane s of the pixel's DPP row writes byte s of what store_patch / store_frame_px / store_planar_px write
-template <int LAYOUT> __device__ __forceinline__ void store_px_lane(uint8_t *frame, int X, int Y, int c, bool fill, int s) {
-    const int ch = s % 3, v = (c >> (8 * ch)) & 0xFF;
-    if (LAYOUT == LAY_FRAME) { if (s < 3) frame[(Y * LORES + X) * 3 + s] = (uint8_t)v; return; }
-    if (LAYOUT == LAY_PLANAR) { if (s < 3) frame[s * LORES * LORES + Y * LORES + X] = (uint8_t)v; return; }
-    const int first = LAYOUT == LAY_SLOT0 ? 0 : (fill ? (LAYOUT == LAY_STACK4 ? 0 : 3) : 9);
-    const int last = LAYOUT == LAY_SLOT0 ? 3 : 12;
-    if (first + s < last) frame[(uint32_t)((Y * LORES + X) * 12 + first + s)] = (uint8_t)v;
-}
-// sum over the 16 lanes of a DPP row, in every lane (quad swaps, then the mirrored half row and the mirrored row)
-__device__ __forceinline__ int row_sum16(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);     // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);     // row_mirror
-    return v;
 }
 __device__ __forceinline__ void store_planar_px(uint8_t *frame, int X, int Y, int c) {
     uint8_t *q = frame + (Y * LORES + X);          // a tile row = 16 consecutive bytes per plane
