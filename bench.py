@@ -195,7 +195,7 @@ def main_config5(args):
     import torch
     import torch.distributed as dist
     from magical_amd.distributed import env_shard, init_from_env
-    rank, world, local_rank = init_from_env(backend='nccl')
+    rank, world, local_rank = init_from_env(backend='nccl', single_process_group=not args.no_collective)      # (one GPU: a group of one rank, the gather still runs)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
@@ -216,8 +216,8 @@ def main_config5(args):
                           'envs_per_task_per_gpu': n, 'episodes_finished': n_eps * world, 'mean_eval_score': float(all_scores.mean().item())},
                'roofline': None, 'note': 'a step = one env-step of each of the 8 tasks; kernels of different engines overlap, so per-kernel '
                                          'roofline figures are those of the single-task lines (python bench.py --task ...)'}
-        print(json.dumps(out))
-    if world > 1:
+        args.emit(json.dumps(out))
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -408,7 +408,7 @@ def measure(args, rank, world, device):
                                              'SURVEY.md 8(d) parenthetical row: [96,96,12] stack re-materialised each step (9 B read + 12 B '
                                              'written per pixel + pose rows); frac_new_frame_row uses the 28.3 KB headline row'},
             'collective': {'backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')) if dist.is_initialized() else None,
-                           'world_size': world, 'in_timed_region': f'all_gather of the shard sizes + all_gather of the per-env scores f64[{n}] per rank, once, at the end of the rollout',
+                           'world_size': world, 'in_timed_region': f'one all_gather of the per-env scores f64[{n}] per rank at the end of the rollout',
                            'ms': gather_ms} if dist.is_initialized() else {'backend': None, 'note': 'no process group: single process, gather skipped'},
             'roofline': {'bound': bound_of(dom), 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
@@ -447,6 +447,15 @@ def main():
     ap.add_argument('--no-collective', action='store_true', help='--gpus 1: do not form the one-rank RCCL group (the end-of-rollout gather is then skipped)')
     ap.add_argument('--force-collective', action='store_true', help='--gpus 1: fail instead of carrying on without the gather if the one-rank RCCL group cannot be formed')
     args = ap.parse_args()
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL's version banner sits in a C stdio buffer
+    # until exit): file descriptor 1 is pointed at stderr for the run and the line goes out on a duplicate of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(real_stdout, (line + '\n').encode())
+    args.emit = emit
     if args.config5:
         return main_config5(args)
 
@@ -503,8 +512,8 @@ def main():
             out['secondary'] = sec
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
-    if world > 1:
+        args.emit(json.dumps(out))
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -48,19 +48,26 @@ def gather_rollout_results(local, n_total=None):
     if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size()
-    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local)
-    sizes = [int(s.item()) for s in sizes]
+    if n_total is not None:
+        # the job's env count is known: every rank's shard length follows from env_shard, nothing to exchange or wait for
+        sizes = [hi - lo for lo, hi in (env_shard(n_total, r, world) for r in range(world))]
+        assert local.shape[0] == sizes[dist.get_rank()], (local.shape[0], sizes, 'not the env_shard of n_total')
+    else:
+        n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        got = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(got, n_local)
+        sizes = [int(s.item()) for s in got]
     n_max = max(sizes)
+    if min(sizes) == n_max:
+        # equal shards: one collective straight into the result
+        out = torch.empty((world * n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
     padded = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     padded[:local.shape[0]] = local
     parts = [torch.zeros_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded)
-    out = torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
-    if n_total is not None:
-        assert out.shape[0] == n_total
-    return out
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
 
 
 class TaskFleet:

@@ -21,10 +21,13 @@ call sites, cited per method:
 (bias velocities, per-axis accumulated joint impulses) is reported as NaN, never invented.
 
     python -m oracle.pymunk_backend --probe                      # is pymunk importable here?  which version?
-    python -m oracle.pymunk_backend --capture out.json           # per-substep states, masses, star parts, scores of fixed tapes
+    python -m oracle.pymunk_backend --capture [out.json]         # per-substep states, masses, star parts, scores of fixed tapes
+                                                                 # (default: tests/golden/pymunk_capture.json, the fixture path)
 
 tests/test_pymunk_backend.py runs the comparison (C oracle vs pymunk, substep by substep) when pymunk is importable and skips
-LOUDLY otherwise; bench.py's cpu_baseline uses it (`kind: "pymunk"`) under the same condition.
+LOUDLY otherwise; bench.py's cpu_baseline uses it (`kind: "pymunk"`) under the same condition.  The capture FILE closes the loop for
+boxes without pymunk: ONE run of the --capture command anywhere pymunk 5.6 / 5.7 imports, committed as tests/golden/pymunk_capture.json,
+and tests/test_pymunk_capture.py holds both the C oracle (CPU) and the HIP engine (-m gpu) to the real engine's states.
 """
 import json
 import math
@@ -406,17 +409,37 @@ def capture_task(task, steps=20, backend='pymunk', seed=0):
             'mass': env.body_mass(), 'score': float(env.task.score_on_end_of_traj())}
 
 
-def capture_all(steps=20):
+CAPTURE_FIXTURE = 'tests/golden/pymunk_capture.json'       # where the consumer tests (tests/test_pymunk_capture.py) look for a capture
+
+
+def capture_all(steps=20, backend='pymunk'):
+    """The capture file's content.  backend 'pymunk': the real engine (what pins the oracle); 'c': the C oracle capturing itself --
+    only to exercise the consumer tests' plumbing where pymunk cannot be imported (such a file says so and pins nothing)."""
     from .tasks_ref import TASKS
-    ok, version = probe()
-    if not ok:
-        raise ImportError(version)
-    out = {'pymunk_version': str(version), 'mass_table': reference_mass_table(), 'star_parts': reference_star_parts(), 'tasks': {}}
+    if backend == 'pymunk':
+        ok, version = probe()
+        if not ok:
+            raise ImportError(version)
+        out = {'backend': 'pymunk', 'pymunk_version': str(version), 'mass_table': reference_mass_table(), 'star_parts': reference_star_parts(), 'tasks': {}}
+    else:
+        out = {'backend': 'c', 'pymunk_version': None, 'mass_table': None, 'star_parts': None, 'tasks': {}}
     for task in TASKS:
-        rec = capture_task(task, steps)
+        rec = capture_task(task, steps, backend=backend)
         out['tasks'][task] = {'tape': rec['tape'], 'score': rec['score'], 'mass': rec['mass'].tolist(),
                               'states_hex': [[[float(v).hex() for v in body] for body in st] for st in rec['states']]}
     return out
+
+
+def load_capture(path):
+    """A capture file back as arrays: {'backend', 'pymunk_version', 'mass_table', 'star_parts', 'tasks': {task: {'tape' int[T],
+    'score', 'mass' f64[n_bodies, 2], 'states' f64[10 T + 1, n_bodies, 6]}}} -- states after every substep, bit for bit (hex)."""
+    with open(path) as f:
+        cap = json.load(f)
+    for rec in cap['tasks'].values():
+        rec['states'] = np.array([[[float.fromhex(v) for v in body] for body in st] for st in rec.pop('states_hex')], dtype=np.float64)
+        rec['tape'] = np.array(rec['tape'], dtype=int)
+        rec['mass'] = np.array(rec['mass'], dtype=np.float64)
+    return cap
 
 
 def main(argv):
@@ -425,13 +448,15 @@ def main(argv):
         print(json.dumps({'pymunk_importable': ok, 'detail': str(info)}))
         return 0 if ok else 3
     if '--capture' in argv:
-        if not ok:
+        k = argv.index('--capture')
+        path = argv[k + 1] if k + 1 < len(argv) and not argv[k + 1].startswith('--') else CAPTURE_FIXTURE
+        backend = argv[argv.index('--backend') + 1] if '--backend' in argv else 'pymunk'
+        if backend == 'pymunk' and not ok:
             print(f'pymunk is not importable here ({info}): nothing captured', file=sys.stderr)
             return 3
-        path = argv[argv.index('--capture') + 1]
         with open(path, 'w') as f:
-            json.dump(capture_all(), f)
-        print(f'wrote {path} (pymunk {info})')
+            json.dump(capture_all(backend=backend), f)
+        print(f'wrote {path} (' + (f'pymunk {info}' if backend == 'pymunk' else 'the C oracle capturing itself: pins nothing') + ')')
         return 0
     print(__doc__)
     return 2
