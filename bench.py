@@ -338,11 +338,11 @@ def measure(args, rank, world, device):
         traffic, traffic_src = None, None
         key = {TASK: 'mtc_lores4e', 'ClusterColour-Demo-LoRes4E-v0': 'cc_lores4e'}.get(args.task)
         if key and n == N_ENVS and args.dtype == 'f32':
-            for rnd in ('r03', 'r02', 'r01'):
+            for rnd in ('r04', 'r03', 'r02', 'r01'):
                 pmc = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_traffic_{key}.json')
                 try:
                     traffic = float(json.load(open(pmc))[dom]['hbm_traffic_bytes_per_launch'])
-                    traffic_src = f'profiles/{rnd}_pmc_traffic_{key}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, median per launch)'
+                    traffic_src = f'profiles/{rnd}_pmc_traffic_{key}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, median per launch; committed file of that round, not measured in this run)'
                     break
                 except Exception:
                     continue
@@ -351,11 +351,11 @@ def measure(args, rank, world, device):
         # peak, resident wavefronts per SIMD, share of wave-cycles parked on s_waitcnt / stalled at issue, scratch footprint
         alu, alu_src = None, None
         if key and n == N_ENVS and args.dtype == 'f32':
-            for rnd in ('r03',):
+            for rnd in ('r04', 'r03'):
                 pa = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_alu_{key}.json')
                 try:
                     alu = json.load(open(pa))
-                    alu_src = f'profiles/{rnd}_pmc_alu_{key}.json (rocprofv3 --pmc, three passes of eight SQ counters, kernels one after the other)'
+                    alu_src = f'profiles/{rnd}_pmc_alu_{key}.json (rocprofv3 --pmc, three passes of eight SQ counters, kernels one after the other; committed file of that round, not measured in this run)'
                     break
                 except Exception:
                     continue

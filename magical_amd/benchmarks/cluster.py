@@ -158,7 +158,8 @@ class BaseClusterEnv(BaseEnv, abc.ABC):
             on = present[:, k]
             sums[rows[on], cls[on, k]] += pos[on, k]
             counts[rows[on], cls[on, k]] += 1.0
-        centroids = sums / counts[:, :, None]
+        with np.errstate(divide='ignore', invalid='ignore'):
+            centroids = np.where(counts[:, :, None] > 0, sums / counts[:, :, None], 0.0)      # a class without members: (0, 0), cluster.py:173-175
         min_margin = 2.0
         n_correct = np.zeros(M, dtype=np.int64)
         for k in range(n_blocks):

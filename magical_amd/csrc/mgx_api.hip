@@ -94,6 +94,7 @@ struct mgx_engine {
     TmplDev tdev{};
     RasterDev rdev{};
     int raster_waves = 4;       // k_raster variant: workgroups per CU its register cap is set for (3, 4 or 5)
+    int qcap_debug = 0;         // > 0: queue entries in use as set by mgx_engine_debug_raster_qcap (tests); else the layout's capacity
     size_t lds_step = 0, lds_raster = 0;
     int rows_p = 0, rows_f = 0, rows_i = 0;
     // per-env worlds (tasks whose episodes differ in shape types / entity counts)
@@ -473,7 +474,8 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     for (const auto &en : e->w.entities) { n_goals_w += en.kind == 2; n_blocks_w += en.kind == 1; }
     const int qcap_lds = (!e->env_worlds && n_goals_w == 0 && n_blocks_w <= 1 && !getenv("MGX_QCAP_FULL")) ? QCAP_SMALL : QCAP;
     e->rdev.qcap_lds = qcap_lds;
-    if (e->rdev.qcap <= 0 || e->rdev.qcap > qcap_lds) e->rdev.qcap = qcap_lds;
+    // (the layout may grow when per-env worlds are enabled: the entries in use follow it, unless a test has set them)
+    e->rdev.qcap = e->qcap_debug > 0 && e->qcap_debug < qcap_lds ? e->qcap_debug : qcap_lds;
     const int extra = N_TILES * 3 + qcap_lds * 4 + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2;
     // As many rasteriser workgroups per CU as LDS allows (allocations round up to 512 B), between 3 and 5; a step is worth 13-15 % of
     // the launch.  Two economies are taken only where they buy such a step, the cheaper one first:
@@ -902,10 +904,17 @@ int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t 
     if (rc) return recover(rc);
     e->hand_tail += (unsigned)e->n_envs; e->hand_started += (unsigned)step_blocks(e);
     rc = timing_end(e, 1, e->st2);
+    // ... and the caller's stream waits for it: whatever comes next on `stream` sees the finished observation.  Both kernels are
+    // in flight from here on: a failure (of the timing events, of the join itself) must still join, or later work on `stream`
+    // could read an unfinished observation -- if the event path is what failed, the host waits for the raster stream instead
+    hipError_t jerr = hipSuccess;
+    if (!jk || rc) jerr = hipEventRecord(e->ev_join, e->st2);
+    if (jerr == hipSuccess) jerr = hipStreamWaitEvent(st, e->ev_join, 0);
+    if (jerr != hipSuccess) {
+        (void)hipStreamSynchronize(e->st2);
+        if (!rc) rc = fail(MGX_ERR_HIP, std::string("joining the raster stream: ") + hipGetErrorString(jerr));
+    }
     if (rc) return rc;
-    // ... and the caller's stream waits for it: whatever comes next on `stream` sees the finished observation
-    if (!jk) HIP_OK(hipEventRecord(e->ev_join, e->st2));
-    HIP_OK(hipStreamWaitEvent(st, e->ev_join, 0));
     // clean-up: the envs whose consumer gave up (producers not all running yet, or a wait that ran out) -- normally none
     rh.mode = 2;
     return e->dtype == MGX_F32_PURE ? launch_raster_deferred<float>(e, state_p, out, env_stride, view, layout, st, rh)
@@ -940,7 +949,7 @@ int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_
 }
 int mgx_engine_debug_raster_waves(mgx_engine *e, int n) { if (e && n >= 3 && n <= 5) e->raster_waves = n; return MGX_OK; }
 int mgx_engine_debug_raster_ecap(mgx_engine *e, int n) { if (e) e->rdev.ecap = n < 1 ? 1 : (n > ECAP ? ECAP : n); return MGX_OK; }
-int mgx_engine_debug_raster_qcap(mgx_engine *e, int n) { if (e) e->rdev.qcap = n < 1 ? 1 : (n > e->rdev.qcap_lds ? e->rdev.qcap_lds : n); return MGX_OK; }
+int mgx_engine_debug_raster_qcap(mgx_engine *e, int n) { if (e) { e->qcap_debug = n < 1 ? 1 : n; e->rdev.qcap = e->qcap_debug > e->rdev.qcap_lds ? e->rdev.qcap_lds : e->qcap_debug; } return MGX_OK; }
 int mgx_engine_debug_raster_stop(mgx_engine *e, int phase) { if (e) e->rdev.dbg_stop = phase; return MGX_OK; }
 int mgx_engine_debug_raster_clocks(mgx_engine *e, void *buf) { if (e) e->rdev.dbg_clk = (unsigned long long *)buf; return MGX_OK; }
 int mgx_engine_debug_step_clocks(mgx_engine *e, void *buf) { if (e) e->tdev.dbg_clk = (unsigned long long *)buf; return MGX_OK; }

@@ -145,30 +145,47 @@ __device__ inline double sp_dot2(double ax, double ay, double bx, double by, int
     return ax * bx + ay * by;
 }
 
+// The per-env tables (positions, presence, classes, projections) are indexed by loop variables: as local arrays they lived in scratch
+// memory (round 3: 5 120 spilled registers, 2.8 KB of private segment per lane); they are columns of LDS now, [k][lane], and the
+// inliers' projections are sorted by a fixed compare-exchange network over registers (static indices).
+#define SP_CE(a, b) { const double lo_ = fmin(v[a], v[b]), hi_ = fmax(v[a], v[b]); v[a] = lo_; v[b] = hi_; }
+// Batcher's odd-even merge sort of 16 values (63 compare-exchanges); +inf pads sort to the end
+__device__ __forceinline__ void sp_sort16(double (&v)[SP_MAX_BLOCKS]) {
+#pragma unroll
+    for (int p = 1; p < SP_MAX_BLOCKS; p <<= 1)
+#pragma unroll
+        for (int k = p; k >= 1; k >>= 1)
+#pragma unroll
+            for (int j = k % p; j + k < SP_MAX_BLOCKS; j += 2 * k)
+#pragma unroll
+                for (int i = 0; i < k; i++)
+                    if (i + j + k < SP_MAX_BLOCKS && (i + j) / (2 * p) == (i + j + k) / (2 * p)) SP_CE(i + j, i + j + k)
+}
+#undef SP_CE
+
 template <typename P>
 __global__ __launch_bounds__(64) void k_score_points(ScorePointsDev s, const P *__restrict__ sp, const uint8_t *__restrict__ mask,
                                                      double *__restrict__ out, int n_envs) {
 #pragma clang fp contract(off)
-    const long env = (long)blockIdx.x * 64 + threadIdx.x;
+    __shared__ double l_px[SP_MAX_BLOCKS][64], l_py[SP_MAX_BLOCKS][64], l_cx[SP_MAX_CLASSES][64], l_cy[SP_MAX_CLASSES][64], l_cn[SP_MAX_CLASSES][64];
+    __shared__ int8_t l_cls[SP_MAX_BLOCKS][64];
+    __shared__ uint8_t l_on[SP_MAX_BLOCKS][64];
+    const int t = threadIdx.x;
+    const long env = (long)blockIdx.x * 64 + t;
     if (env >= n_envs) return;
     const long N = n_envs;
     if (mask && !mask[env]) { out[env] = 0.0; return; }
-    double px[SP_MAX_BLOCKS], py[SP_MAX_BLOCKS];
-    bool on[SP_MAX_BLOCKS];
     int n_on = 0;
-#pragma unroll
-    for (int k = 0; k < SP_MAX_BLOCKS; k++) {
-        px[k] = py[k] = 0.0; on[k] = false;
-        if (k < s.n) {
-            px[k] = (double)sp[(long)s.row_x[k] * N + env]; py[k] = (double)sp[(long)s.row_y[k] * N + env];
-            on[k] = !s.ent_present_env || s.ent_present_env[(long)s.ent[k] * N + env] != 0;
-            n_on += on[k] ? 1 : 0;
-        }
+    for (int k = 0; k < s.n; k++) {
+        l_px[k][t] = (double)sp[(long)s.row_x[k] * N + env]; l_py[k][t] = (double)sp[(long)s.row_y[k] * N + env];
+        const bool on = !s.ent_present_env || s.ent_present_env[(long)s.ent[k] * N + env] != 0;
+        l_on[k][t] = on ? 1 : 0;
+        n_on += on ? 1 : 0;
     }
     double score = 0.0;
     if (s.task == SP_CORNER) {
         // dist = np.linalg.norm((-1, 1) - shape_pos); score = min(1, max(0, furthest - dist) / range)
-        const double dx = -1.0 - px[0], dy = 1.0 - py[0];
+        const double dx = -1.0 - l_px[0][t], dy = 1.0 - l_py[0][t];
         const double dist = sqrt(sp_dot2(dx, dy, dx, dy, s.dot_mode));
         score = fmin(1.0, fmax(0.0, s.p0 - dist) / s.p1);
     } else if (s.task == SP_LINE) {
@@ -177,33 +194,33 @@ __global__ __launch_bounds__(64) void k_score_points(ScorePointsDev s, const P *
         int best = npts < 1 ? npts : 1;
         for (int i = 0; i + 1 < npts; i++)
             for (int j = i + 1; j < npts; j++) {
-                double ox[SP_MAX_BLOCKS], oy[SP_MAX_BLOCKS], proj[SP_MAX_BLOCKS];
-                const double jx = px[j] - px[i], jy = py[j] - py[i];
+                const double pix = l_px[i][t], piy = l_py[i][t];
+                const double jx = l_px[j][t] - pix, jy = l_py[j][t] - piy;
                 const double nrm = sqrt(sp_dot2(jx, jy, jx, jy, s.dot_mode));
                 const double ux = jx / nrm, uy = jy / nrm;
+                double proj[SP_MAX_BLOCKS];
                 int n_in = 0;
 #pragma unroll
                 for (int p = 0; p < SP_MAX_BLOCKS; p++) {
                     proj[p] = __builtin_inf();
                     if (p < npts) {
-                        ox[p] = px[p] - px[i]; oy[p] = py[p] - py[i];
-                        const double pl = sp_dot2(ox[p], oy[p], ux, uy, s.mm_mode);
-                        const double ex = ox[p] - pl * ux, ey = oy[p] - pl * uy;
+                        const double ox = l_px[p][t] - pix, oy = l_py[p][t] - piy;
+                        const double pl = sp_dot2(ox, oy, ux, uy, s.mm_mode);
+                        const double ex = ox - pl * ux, ey = oy - pl * uy;
                         const double d = sqrt(ex * ex + ey * ey);
                         if (d <= s.p0) { proj[p] = pl; n_in++; }            // (NaN: coincident points -> no inliers)
                     }
                 }
                 if (n_in <= best) continue;
                 // np.sort of the inliers' projections, then the longest run of neighbours at most max_separation apart
-                for (int a = 1; a < npts; a++) {
-                    const double v = proj[a]; int b = a - 1;
-                    while (b >= 0 && proj[b] > v) { proj[b + 1] = proj[b]; b--; }
-                    proj[b + 1] = v;
-                }
+                sp_sort16(proj);
                 int run = 0, longest = 0;
-                for (int k = 0; k + 1 < n_in; k++) {
-                    run = fabs(proj[k + 1] - proj[k]) <= s.p1 ? run + 1 : 0;
-                    longest = longest > run ? longest : run;
+#pragma unroll
+                for (int k = 0; k + 1 < SP_MAX_BLOCKS; k++) {
+                    if (k + 1 < n_in) {
+                        run = fabs(proj[k + 1] - proj[k]) <= s.p1 ? run + 1 : 0;
+                        longest = longest > run ? longest : run;
+                    }
                 }
                 if (longest + 1 > best) best = longest + 1;
             }
@@ -211,32 +228,36 @@ __global__ __launch_bounds__(64) void k_score_points(ScorePointsDev s, const P *
         const int num = best - min_len > 0 ? best - min_len : 0;
         score = (double)num / (double)(max_len - min_len);
     } else {
-        // centroid of every class = sum of its members in block order / their number; a block is correct when it is closer to
-        // its own centroid than to the nearest other one by the margin (a squared distance: reference quirk, cluster.py:203-206)
-        double sx[SP_MAX_CLASSES], sy[SP_MAX_CLASSES], cnt[SP_MAX_CLASSES];
-        int cls[SP_MAX_BLOCKS];
-#pragma unroll
-        for (int c = 0; c < SP_MAX_CLASSES; c++) { sx[c] = sy[c] = cnt[c] = 0.0; }
+        // centroid of every class = sum of its members in block order / their number -- (0, 0) for a class without members, as the
+        // reference has it (cluster.py:173-175); a block is correct when it is closer to its own centroid than to the nearest
+        // other one by the margin (a squared distance: reference quirk, cluster.py:203-206)
+        for (int c = 0; c < s.n_classes; c++) { l_cx[c][t] = 0.0; l_cy[c][t] = 0.0; l_cn[c][t] = 0.0; }
         for (int k = 0; k < s.n; k++) {
-            cls[k] = s.cls_env ? (int)s.cls_env[env * s.n + k] : s.cls_default[k];
-            if (!on[k]) continue;
-            for (int c = 0; c < s.n_classes; c++) if (c == cls[k]) { sx[c] += px[k]; sy[c] += py[k]; cnt[c] += 1.0; }
+            const int c = s.cls_env ? (int)s.cls_env[env * s.n + k] : s.cls_default[k];
+            l_cls[k][t] = (int8_t)c;
+            if (!l_on[k][t] || c < 0 || c >= s.n_classes) continue;
+            l_cx[c][t] += l_px[k][t]; l_cy[c][t] += l_py[k][t]; l_cn[c][t] += 1.0;
         }
-        for (int c = 0; c < s.n_classes; c++) { sx[c] = sx[c] / cnt[c]; sy[c] = sy[c] / cnt[c]; }
+        for (int c = 0; c < s.n_classes; c++) {
+            const double cn = l_cn[c][t];
+            l_cx[c][t] = cn > 0.0 ? l_cx[c][t] / cn : 0.0; l_cy[c][t] = cn > 0.0 ? l_cy[c][t] / cn : 0.0;
+        }
         int n_correct = 0;
         for (int k = 0; k < s.n; k++) {
             double true_sse = 0.0, bad = __builtin_inf();
             bool bad_nan = false;
+            const double x = l_px[k][t], y = l_py[k][t];
+            const int ck = l_cls[k][t];
             for (int c = 0; c < s.n_classes; c++) {
-                const double dx = px[k] - sx[c], dy = py[k] - sy[c];
+                const double dx = x - l_cx[c][t], dy = y - l_cy[c][t];
                 const double sse = dx * dx + dy * dy;
-                if (c == cls[k]) true_sse = sse;
-                else if (sse != sse) bad_nan = true;         // np.min propagates the NaN of a class without members
+                if (c == ck) true_sse = sse;
+                else if (sse != sse) bad_nan = true;         // np.min propagates a NaN
                 else bad = sse < bad ? sse : bad;
             }
             const double margin = 2.0 * true_sse;
             const bool ok = !bad_nan && sqrt(true_sse) < sqrt(bad) - margin;
-            n_correct += (ok && on[k]) ? 1 : 0;
+            n_correct += (ok && l_on[k][t]) ? 1 : 0;
         }
         const double frac = (double)n_correct / (double)(n_on > 1 ? n_on : 1);
         score = fmax(frac - 0.75, 0.0) / (1.0 - 0.75);

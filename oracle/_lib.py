@@ -31,6 +31,8 @@ def lib():
         'ref_new': (_P, []),
         'ref_free': (None, [_P]),
         'ref_clone': (_P, [_P]),
+        'ref_perturb_warm': (None, [_P, _D, C.c_uint]),
+        'ref_clear_warm': (None, [_P]),
         'ref_set_space': (None, [_P, _I, _D]),
         'ref_set_bg': (None, [_P, _D, _D, _D]),
         'ref_set_gjk_warm': (None, [_P, _I]),

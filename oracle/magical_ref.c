@@ -181,6 +181,32 @@ World *ref_clone(const World *w) {
     memcpy(c, w, sizeof(World));
     return c;
 }
+/* Sensitivity probe (tests only): every warm-start quantity the solver carries from one substep to the next -- the joints'
+ * accumulated impulses and the cached contact impulses -- scaled by (1 + rel * u), u uniform in [-1, 1] from a small LCG.
+ * What a second implementation of the same step differs from this one by after a few steps is exactly such a perturbation
+ * (plus one of the poses, which the callers apply through ref_set_bodies). */
+void ref_perturb_warm(World *w, double rel, unsigned seed) {
+    unsigned s = seed * 2654435761u + 12345u;
+#define PERT(x) do { s = s * 1664525u + 1013904223u; (x) *= 1.0 + rel * (((double)(s >> 8) / 8388608.0) - 1.0); } while (0)
+    for (int i = 0; i < w->njoints; i++) { Joint *j = &w->joints[i]; PERT(j->jacc); PERT(j->jacc_v.x); PERT(j->jacc_v.y); }
+    for (int i = 0; i < MAX_ARB; i++) {
+        Arbiter *a = &w->arbs[i];
+        if (!a->used) continue;
+        for (int k = 0; k < a->count; k++) { PERT(a->c[k].jn_acc); PERT(a->c[k].jt_acc); }
+    }
+#undef PERT
+}
+/* Cold solver state (tests only): every accumulated impulse zeroed -- joints and cached contact points -- with the arbiters (and so
+ * the contact persistence) left as they are.  Full-state teacher forcing: two implementations that start an env-step from equal
+ * poses, velocities AND zero warm start differ afterwards by their arithmetic alone. */
+void ref_clear_warm(World *w) {
+    for (int i = 0; i < w->njoints; i++) { Joint *j = &w->joints[i]; j->jacc = 0.0; j->jacc_v.x = j->jacc_v.y = 0.0; }
+    for (int i = 0; i < MAX_ARB; i++) {
+        Arbiter *a = &w->arbs[i];
+        if (!a->used) continue;
+        for (int k = 0; k < 2; k++) { a->c[k].jn_acc = 0.0; a->c[k].jt_acc = 0.0; }
+    }
+}
 void ref_set_space(World *w, int iterations, double slop) { w->iterations = iterations; w->collision_slop = slop; }
 void ref_set_bg(World *w, double r, double g, double b) { w->bg_rgb[0] = r; w->bg_rgb[1] = g; w->bg_rgb[2] = b; }
 void ref_set_gjk_warm(World *w, int on) { w->gjk_warm = on; }

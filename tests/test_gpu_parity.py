@@ -148,16 +148,54 @@ def _live_arbiters(env):
     return live.sum(axis=0), (live & (((heads >> 14) & 3) == 2)).sum(axis=0)
 
 
+def _pin_block_against_wall(ref, lane):
+    """Put the ORACLE's robot at (0.42, y) facing the right-hand wall with the task's first block between its fingers, a drive away from
+    the wall: two env-steps of driving later the block is squeezed between the robot's body, a finger and the wall -- three or more
+    arbiters on one body, Gauss-Seidel order and all (cpSpaceStep's arbiter loop, base_env.py:236-243).  The whole robot island
+    (control body, eyes, fingers) moves rigidly; velocities start at zero."""
+    from oracle.entities_ref import Shape as RefShape
+    blocks = [e.bodies[0] for e in ref.world.entities if isinstance(e, RefShape)]
+    if not blocks:
+        return False
+    b = ref.bodies()
+    rb = list(ref.task.robot.bodies)
+    x0, y0, a0 = b[rb[0], 0], b[rb[0], 1], b[rb[0], 2]
+    x1, y1, a1 = 0.42, -0.55 + 0.1 * lane, -np.pi / 2               # forward = (-sin a, cos a) = (1, 0)
+    da = a1 - a0
+    c, s = np.cos(da), np.sin(da)
+    for body in rb:
+        dx, dy = b[body, 0] - x0, b[body, 1] - y0
+        b[body, 0], b[body, 1] = x1 + c * dx - s * dy, y1 + s * dx + c * dy
+        b[body, 2] += da
+        b[body, 3:] = 0.0
+    b[blocks[0], :3] = (x1 + 0.2 + 0.15, y1, 0.3 * lane)
+    b[blocks[0], 3:] = 0.0
+    ref.set_bodies(b)
+    return True
+
+
 @pytest.mark.parametrize('task', TASKS)
 def test_f64_engine_one_step_equivalence_and_contact_coverage(task):
     """The device instantiation k_step<double, double, L> held to the oracle with ABSOLUTE bounds, the way tests/test_emu_parity.py
-    holds the host build of the phases: every env-step starts from the oracle's body state (teacher forcing; the solvers' warm-start
-    impulses and contact caches are each engine's own), 32 envs x 60 env-steps of a script that chases a block and shoves it.  Round-off agreement
-    (median < 1e-12, p90 < 1e-10) with a bounded tail (max < 5e-2, every sample above 1e-9 listed): where a finger is pressed
-    against something the reference dynamics turn 1e-13 differences of the warm-start impulses into 1e-3 within that env-step
-     -- an algorithmic mismatch would show on most samples.  The tape must actually exercise the contact path: arbiter counts and
-    two-point manifolds are compared with the oracle's (cpSpaceStep's arbiter list, base_env.py:236-243) and their share asserted."""
+    holds the host build of the phases.  FULL-STATE teacher forcing: every env-step starts from the oracle's body state AND from a
+    cold solver state on both sides (every accumulated joint / contact impulse zeroed -- oracle: ref_clear_warm, engine: the impulse
+    rows of its motion blob -- with arbiters and cache entries, i.e. contact persistence, left alone; inside the env-step the ten
+    substeps warm-start each other as always).  Round 3 forced the bodies only: the solvers' warm-start impulses stayed each
+    engine's own, and in a pressed contact they are sloppy variables -- after one amplified step they stay 0.5 % apart for the rest
+    of the contact episode while the poses re-agree to 1e-13, and surface again as 1e-6 .. 1e-2 at the next stick / slip change
+    (measured on the host build of the phases, round 4: every round-3 "offender" was that, and none is left once the impulses are
+    forced too).  32 envs x 60 env-steps of a script that chases a block and shoves it; every fourth env instead starts with a block
+    between its fingers in front of a wall and squeezes it there (three and more arbiters on one body).
+    Gates: median < 1e-13, p90 < 1e-12, p99 < 1e-6 from env-step 1 on, and EVERY sample accounted for: next to each sample three clones
+    of the oracle's world with poses perturbed by 1e-13 (48 more, perturbed by 1e-16 .. 1e-13, where that matters) take the same step; the engine's error must stay
+    below 1e-10 wherever the clones stay within 1e-11
+    of the oracle, and below F64_AMPLIFICATION x the clones' spread wherever they do not (the zero-length pin joints of the finger
+    roots turn 1e-13 into 1e-4 within one env-step when the robot starts from rest or changes its action, DESIGN.md section 5);
+    nothing above 5e-2.  An algorithmic mismatch shows as an error without a spread to explain it.  The tape must actually exercise
+    the contact path: arbiter counts and two-point manifolds are compared with the oracle's (cpSpaceStep's arbiter list,
+    base_env.py:236-243) and their shares asserted."""
     from oracle._lib import lib as ref_lib
+    from oracle.entities_ref import Shape as RefShape
     import ctypes as C
     n, t = 32, 60
     env = _make(f'{task}-Demo-v0', n, dtype='f64', max_episode_steps=1000)
@@ -169,44 +207,115 @@ def test_f64_engine_one_step_equivalence_and_contact_coverage(task):
         xy, rad, ty = (C.c_double * 64)(), C.c_double(), C.c_int()
         L.ref_shape_world(r.h, int(sidx), xy, C.byref(rad), C.byref(ty))
         return ty.value
-    errs, offenders = [], []
-    n_arb_equal = n_samples = n_multi = n_two_point = n_poly_poly = 0
+    def shape_body(r, sidx):
+        out = (C.c_int * 3)()
+        L.ref_shape_info(r.h, int(sidx), out)
+        return out[0]
+    block_bodies = set(e.bodies[0] for e in refs[0].world.entities if isinstance(e, RefShape))
+    pinned = [k % 4 == 3 and _pin_block_against_wall(r, k // 4) for k, r in enumerate(refs)]
+    warm_row0 = env._info('physvar_row') + 5
+    assert env.state_f.shape[0] == warm_row0 + env._info('n_jacc') + 4 * env._info('cache_slots')
+    errs, spreads, offenders = [], [], []
+    n_arb_equal = n_samples = n_multi = n_two_point = n_poly_poly = n_three = 0
+    prev = np.full(n, -1, dtype=np.int32)
+    rs = np.random.RandomState(23)
+    from oracle.env_ref import FPS
+    def clones_step(src, action, K=3, eps=EPS_F64):
+        """K clones of the oracle's world `src` (a handle) as it is (memcpy: solver state, contact cache and all), poses perturbed by
+        EPS_F64, one env-step of `action` each; returns their handles (freed by the caller once compared)."""
+        hs = []
+        for _ in range(K):
+            h = L.ref_clone(src)
+            nb = L.ref_nbodies(h)
+            buf = np.zeros((nb, 9), dtype=np.float64)
+            L.ref_get_bodies(h, buf.ctypes.data_as(C.POINTER(C.c_double)))
+            buf[idx, :3] += rs.uniform(-eps, eps, (len(idx), 3))
+            L.ref_set_bodies(h, buf.ctypes.data_as(C.POINTER(C.c_double)))
+            L.ref_step(h, int(action), float(FPS))
+            hs.append(h)
+        return hs
     for s in range(t):
         b = env.get_bodies()
         for k, r in enumerate(refs):
             b[k, 1:, :] = r.bodies()[idx]
+            L.ref_clear_warm(r.h)
         env.set_bodies(b)
-        acts = np.array([_chase_action(r, k, s) for k, r in enumerate(refs)], dtype=np.int32)
+        env.state_f[warm_row0:] = 0          # joint accumulators + cached contact impulses (mgx_sim.h state_rows_f: after the force limits)
+        acts = np.array([(9 if (s // 5) % 2 else 0) + 1 if pinned[k] else _chase_action(r, k, s) for k, r in enumerate(refs)], dtype=np.int32)
         env.step(acts)
         got = env.get_bodies()[:, 1:, :3]
         live, two = _live_arbiters(env)
         for k, r in enumerate(refs):
+            snap = L.ref_clone(r.h)
             r.step(acts[k])
-            e = masked_err(got[k], r.bodies()[idx][:, :3], mask)
+            want = r.bodies()[idx][:, :3]
+            e = masked_err(got[k], want, mask)
             errs.append(e)
-            if e >= 1e-9:
-                offenders.append((s, k, e))
+            def spread_of(K, eps=EPS_F64):
+                worst = 0.0
+                for h in clones_step(snap, acts[k], K, eps):
+                    buf = np.zeros((L.ref_nbodies(h), 9), dtype=np.float64)
+                    L.ref_get_bodies(h, buf.ctypes.data_as(C.POINTER(C.c_double)))
+                    worst = max(worst, masked_err(buf[idx][:, :3], want, mask))
+                    L.ref_free(h)
+                return worst
+            spread = spread_of(3)
+            if e > max(1e-9, F64_AMPLIFICATION * spread):
+                # Three clones at 1e-13 miss two things: a knife edge (a contact that appears or not) one time in eight, and the exact
+                # coincidences of the unperturbed oracle -- a finger root's pin of length EXACTLY zero exerts nothing (cpPinJointPreStep:
+                # n = delta / (dist ? dist : INFINITY)), one of length 1e-17 pulls in a round-off direction; which substep ends the
+                # exactness depends on the last bit, and a 1e-13 clone never has it.  So: 48 more, from one ulp up.
+                for eps in (1e-16, 1e-15, 1e-14, 1e-13):
+                    spread = max(spread, spread_of(12, eps))
+            L.ref_free(snap)
+            spreads.append(spread)
             rc = r.contacts()
+            per_block = {}
+            for row in rc:
+                for sh in (row[0], row[1]):
+                    bd = shape_body(r, sh)
+                    if bd in block_bodies:
+                        per_block[bd] = per_block.get(bd, 0) + 1
+            three = max(per_block.values(), default=0) >= 3
+            if e >= 1e-9:
+                offenders.append((s, k, float(f'{e:.1e}'), float(f'{spread:.1e}'), 'action changed' if acts[k] != prev[k] else 'same action', len(rc)))
             n_samples += 1
+            n_three += int(three)
             n_arb_equal += int(len(rc) == live[k] and int(sum(row[4] == 2 for row in rc)) == two[k])
             n_multi += int(len(rc) >= 2)
             n_two_point += int(any(row[4] == 2 for row in rc))
             n_poly_poly += int(any(row[4] == 2 and shape_type(r, row[0]) == 2 and shape_type(r, row[1]) == 2 for row in rc))
-    errs = np.array(errs)
+        prev = acts
+    errs, spreads = np.array(errs), np.array(spreads)
+    n_changed = sum(1 for o in offenders if o[4] == 'action changed')
+    calm = spreads < 1e-11
+    ratio = errs[~calm] / spreads[~calm]
+    print(f'{task}: {int(calm.sum())} of {len(errs)} samples calm (oracle clones within 1e-11): engine error there max {errs[calm].max():.1e}; '
+          f'sensitive samples: error / spread median {np.median(ratio) if len(ratio) else 0:.2g} p99 {np.percentile(ratio, 99) if len(ratio) else 0:.2g} max {ratio.max() if len(ratio) else 0:.2g}')
     print(f'{task}: teacher-forced fp64 one-step error median {np.median(errs):.1e} p90 {np.percentile(errs, 90):.1e} p99 {np.percentile(errs, 99):.1e} max {errs.max():.1e}; '
-          f'samples with >= 2 arbiters {n_multi}/{n_samples}, with a two-point manifold {n_two_point}, poly-poly two-point {n_poly_poly}; '
-          f'arbiter sets equal to the oracle\'s in {n_arb_equal}; above 1e-9: {offenders}')
+          f'samples with >= 2 arbiters {n_multi}/{n_samples}, with a two-point manifold {n_two_point}, poly-poly two-point {n_poly_poly}, '
+          f'with >= 3 arbiters on one block {n_three}; arbiter sets equal to the oracle\'s in {n_arb_equal}; above 1e-9: {len(offenders)} '
+          f'({n_changed} in an env-step whose action changed) as (env-step, env, error, oracle spread, action, arbiters): {offenders}')
     # (the device's sin / cos differ from libm's in the last place at some angles; the finger roots' zero-length pins then start
     # 1e-17 apart in another direction, and when the robot's velocity changes the reference dynamics turn that into 1e-4 within the
-    # env-step: that is the tail beyond p90, listed above, and why test_f64_engine_tracks_oracle measures against the oracle's spread)
-    assert np.median(errs) < 1e-12 and np.percentile(errs, 90) < 1e-10 and errs.max() < 5e-2, (task, offenders)
+    # env-step: those are the sensitive samples, where the oracle's own clones part as far)
+    later = np.arange(len(errs)) >= n          # (env-step 0 starts every robot from rest: in two tasks ALL 32 first steps are pin-amplified)
+    assert np.median(errs) < 1e-13 and np.percentile(errs, 90) < 1e-12 and np.percentile(errs[later], 99) < 1e-6 and errs.max() < 5e-2, (task, offenders)
+    assert errs[calm].max() < 1e-10, (task, 'an error the oracle\'s own sensitivity does not explain', [o for o in offenders if o[3] < 1e-11])
+    unexplained = [(i, errs[i], spreads[i]) for i in np.nonzero(~calm)[0] if errs[i] > max(1e-9, F64_AMPLIFICATION * spreads[i])]
+    assert not unexplained, (task, 'errors beyond the oracle\'s own one-step sensitivity', unexplained)
     has_blocks = task != 'MoveToRegion'
     # (MoveToRegion has no block: walls only, fewer simultaneous arbiters)
     assert n_multi >= (0.3 if has_blocks else 0.15) * n_samples and n_two_point >= 0.05 * n_samples and (n_poly_poly >= 0.02 * n_samples or not has_blocks), \
         (task, n_multi, n_two_point, n_poly_poly, n_samples)
+    assert n_three >= 0.08 * n_samples or not has_blocks, (task, 'samples with three arbiters on one block', n_three, n_samples)
     assert n_arb_equal >= 0.97 * n_samples, (task, n_arb_equal, n_samples)
     assert int(env.state_i[2].sum()) == 0          # nothing overflowed the working set
     env.close()
+
+
+F64_AMPLIFICATION = 100.0    # engine error allowed per unit of the oracle clones' spread (three clones sample the spread thinly; the printed ratios
+                             # -- profiles/r04_gpu_parity_tables.txt -- stay below 10)
 
 
 DRIFT_STEPS = (1, 5, 20, 80)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-measure the round's profile set on the GPU box (run through gpurun from the repo root:
 #   gpurun --timeout 3600 -- 'bash tools/regen_profiles.sh r03'); results land in gpurun_out/final/, to be copied into profiles/.
-R=${1:-r03}
+R=${1:-r04}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/final; rm -rf $O; mkdir -p $O
@@ -48,6 +48,11 @@ for t in mtc cc; do
   python $GRAFT_REPO_ROOT/tools/pmc_alu_summary.py /tmp/alu_${t}_A /tmp/alu_${t}_B /tmp/alu_${t}_C > $O/${R}_pmc_alu_${t}_lores4e.json
 done
 cd $GRAFT_REPO_ROOT
+# the parity tables the GPU tests print (one-step error quantiles against the oracle and its replicas, drift against the perturbation
+# envelope, the fp64 build's absolute one-step error with its contact-coverage shares and offenders) and the long drift table
+timeout 1700 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "one_step or drift or contact_coverage or tracks_oracle" 2>&1 | grep -v "amdgpu.ids" > $O/${R}_gpu_parity_tables.txt
+timeout 1200 python tools/drift_table.py 2>&1 | grep -v "amdgpu.ids" > $O/${R}_pose_drift_vs_oracle_envelope.txt
+python tools/kernel_resources.py > $O/${R}_kernel_resources.txt 2>> $O/err.txt
 timeout 1500 python tools/rollout_all_tasks.py --variant all --envs 4096 > $O/${R}_rollout_all_60_variants_4096x1gpu.jsonl 2>> $O/err.txt
 timeout 300 python tools/task_step_times.py 2>&1 | grep -v amdgpu > $O/${R}_task_step_times.txt
 timeout 600 python tools/lds_table.py 2>&1 | grep -v amdgpu > $O/${R}_lds_footprints_all_variants.txt
