@@ -117,6 +117,7 @@ struct mgx_engine {
     // step -> raster hand-off (mgx_engine_step_render): second stream + events, the queue of finished envs and its counters
     // longest-first dispatch of the step workgroups (launch_step_L): last durations, the order made of them, their capacity
     uint32_t *d_dur = nullptr, *d_order = nullptr; int order_cap = 0, n_cus = 0; bool order_valid = false;
+    uint32_t *d_env_cost = nullptr, *d_env_order = nullptr; bool env_order_valid = false, env_sort_pending = false;     // heavy envs together (TmplDev::env_order)
     hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long *d_queue = nullptr; unsigned *d_hand = nullptr, *d_deferred = nullptr;   // d_hand: tail, started, stats[2]
     unsigned hand_tail = 0, hand_started = 0, hand_epoch = 0;                                    // host mirrors of the monotonic counters
@@ -567,9 +568,26 @@ static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const i
         t.dur = e->d_dur;
         t.order = e->order_valid ? e->d_order : nullptr;
     }
+    // Heavy envs together: where every step workgroup is resident at once and a wavefront holds several envs, the launch's envs are
+    // ordered by the cost keys the previous launch left (contact points, overlapping pairs), costliest first -- envs in contact share
+    // wavefronts, and most CUs hold light wavefronts only and hand their SIMDs to the rasteriser early (MGX_NO_ENV_PACK=1: off)
+    static const bool no_pack = getenv("MGX_NO_ENV_PACK") != nullptr;
+    // (fused env-step only: on its own the step kernel gains nothing -- its longest wavefront gets longer -- and the sort would sit
+    // between two step launches: state-only MoveToCorner 15.5 -> 12.6 M env-steps/s when it was tried there)
+    const bool pack = !lpt && epb > 1 && count_step && !no_pack && ho.queue != nullptr && e->n_envs >= 8 * epb;
+    t.env_order = nullptr; t.env_cost = nullptr;
+    if (pack) {
+        if (!e->d_env_cost) {
+            HIP_OK(hipMalloc(&e->d_env_cost, (size_t)e->n_envs * 4)); HIP_OK(hipMalloc(&e->d_env_order, (size_t)e->n_envs * 4));
+            e->env_order_valid = false;
+        }
+        t.env_cost = e->d_env_cost;
+        t.env_order = e->env_order_valid ? e->d_env_order : nullptr;
+    }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, st, t, (P *)sp, (R *)sf, si, actions, done, e->n_envs, n_sub,
                        count_step, e->dbg_iterations >= 0 ? e->dbg_iterations : PHYS_ITER, ho);
     HIP_OK(hipGetLastError());
+    e->env_sort_pending = pack;       // (step_common enqueues k_env_order behind the kernel, outside the timing events around it)
     if (lpt) {
         hipLaunchKernelGGL(k_step_order, dim3(1), dim3(1024), 0, st, (const uint32_t *)e->d_dur, e->d_order, blocks);
         HIP_OK(hipGetLastError());
@@ -707,7 +725,7 @@ void mgx_engine_destroy(mgx_engine *e) {
     if (e->st2) { (void)hipStreamSynchronize(e->st2); (void)hipStreamDestroy(e->st2); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    for (void *p : {(void *)e->d_queue, (void *)e->d_hand, (void *)e->d_deferred, (void *)e->d_dur, (void *)e->d_order}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)e->d_queue, (void *)e->d_hand, (void *)e->d_deferred, (void *)e->d_dur, (void *)e->d_order, (void *)e->d_env_cost, (void *)e->d_env_order}) if (p) (void)hipFree(p);
     for (void *p : {(void *)e->d_score_lib, (void *)e->d_score_ent, (void *)e->d_score_prow, (void *)e->d_score_goal_ent,
                     (void *)e->d_score_goal_xyhw, (void *)e->d_ent_type_env, (void *)e->d_ent_present_env})
         if (p) (void)hipFree(p);
@@ -769,7 +787,15 @@ static int step_common(mgx_engine *e, void *sp, void *sf, int32_t *si, const int
        : e->dtype == MGX_F64 ? launch_step<double, double>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho)
                              : launch_step<float, float>(e, sp, sf, si, actions, done, n_sub, count_step, st, ho);
     if (rc) return rc;
-    return timing_end(e, 0, st);
+    rc = timing_end(e, 0, st);
+    if (rc) return rc;
+    if (e->env_sort_pending) {
+        // next launch's env order from this launch's cost keys: one small workgroup behind the step kernel (it runs under the rasterisation)
+        hipLaunchKernelGGL(k_env_order, dim3(1), dim3(1024), 0, st, (const uint32_t *)e->d_env_cost, e->d_env_order, e->n_envs);
+        HIP_OK(hipGetLastError());
+        e->env_order_valid = true; e->env_sort_pending = false;
+    }
+    return MGX_OK;
 }
 int mgx_engine_step(mgx_engine *e, void *state_p, void *state_f, int32_t *state_i, const int32_t *actions, uint8_t *done, void *stream) {
     return step_common(e, state_p, state_f, state_i, actions, done, PHYS_STEPS, 1, stream);
@@ -1233,27 +1259,25 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         int rc = configure_launch(e, mx(e->fp_step_words), mx(e->fp_env_stride), mx(e->fp_raster_words), mx(e->fp_raster_full), mx(e->fp_scratch_d), mx(e->fp_scratch_dc), mx(e->fp_raster_n_i));
         if (rc) return rc;
     }
-    for (auto &U : uniq) e->world_by_sig[U.sig] = U.world;
+    // worlds stay findable by signature for later calls -- where signatures repeat at all: with nearly every env its own world
+    // (ClusterColour-TestAll: ~4000 distinct of 4096) the table only cost its inserts and, every few resets, a 10 ms purge
+    if (uniq.size() * 4 <= (size_t)m) for (auto &U : uniq) e->world_by_sig[U.sig] = U.world;
     tm[ti++] = now();
+    const int n_uniq = (int)uniq.size();
     {
-        // a World is a few hundred small allocations: drop the retired ones (and this call's blob buffers) in parallel
-        auto drop = [&](int t) {
-            for (size_t k = t; k < retired.size(); k += n_threads) retired[k].reset();
-            for (size_t u = t; u < uniq.size(); u += n_threads) { WorldBlobs empty; std::swap(uniq[u].blobs, empty); }
-        };
-        if (n_threads == 1) drop(0);
-        else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < n_threads; t++) pool.emplace_back(drop, t);
-            for (auto &th : pool) th.join();
-        }
+        // a World is a few hundred small allocations, and ~4000 of them retire per reset: they (and this call's blob buffers) are
+        // dropped by a detached helper thread while the caller goes on (round 3 freed them here, a few threads wide: 5-14 ms of the
+        // call).  The helper owns what it frees -- shared_ptrs and vectors, nothing of the engine.
+        auto *bin_worlds = new std::vector<std::shared_ptr<World>>(std::move(retired));
+        auto *bin_uniq = new std::vector<Uniq>(std::move(uniq));
+        std::thread([bin_worlds, bin_uniq] { delete bin_worlds; delete bin_uniq; }).detach();
     }
     if (e->world_by_sig.size() > (size_t)4 * e->n_envs + 64)
         for (auto it = e->world_by_sig.begin(); it != e->world_by_sig.end();) it = it->second.expired() ? e->world_by_sig.erase(it) : std::next(it);
     tm[ti++] = now();
     if (dbg) fprintf(stderr, "mgx: set_env_variants %d envs, %zu distinct worlds, %d threads: signatures %.1f ms, build + serialise %.1f, pack %.1f, upload + place %.1f, bookkeeping %.1f, frees %.1f\n",
-                     m, uniq.size(), n_threads, tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], tm[6] - tm[5]);
-    return (int)uniq.size();
+                     m, (size_t)n_uniq, n_threads, tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], tm[6] - tm[5]);
+    return n_uniq;
 }
 
 int mgx_engine_env_randomise_all_poses_batch(const mgx_engine *e, int m, const int32_t *env_idx, double *poses, const int *ents, int n, const uint8_t *ignore,

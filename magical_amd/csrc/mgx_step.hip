@@ -32,6 +32,13 @@ struct TmplDev {
     // group order[blockIdx.x]; every group leaves its duration (shader clock >> 6) in dur[group] for k_step_order.  NULL = off
     const uint32_t *order;
     uint32_t *dur;
+    // heavy envs together (worlds whose step workgroups are all resident at once, several envs per wavefront): the env at position p of
+    // the launch is env_order[p], and every env leaves a cost key (contact points and overlapping pairs of its last substep) in
+    // env_cost[env] for k_env_order.  A wavefront lasts as long as its slowest env, and a CU gives its SIMDs to the rasteriser only
+    // once its slowest step wavefront is through: envs in contact share wavefronts instead of each holding up three light ones.
+    // Never changes what an env computes.  NULL = envs in index order
+    const uint32_t *env_order;
+    uint32_t *env_cost;
 };
 // Producer side of the step -> raster hand-off (mgx_engine_step_render): a workgroup that has written its envs' state back
 // publishes them, one 64-bit entry per env ((epoch << 32) | env), into a queue that raster workgroups of a concurrently
@@ -97,10 +104,11 @@ __device__ __forceinline__ void step_body(const TmplDev &t, P *__restrict__ sp, 
     int wg = blockIdx.x;
     const unsigned long long t_begin = t.dur ? __builtin_amdgcn_s_memtime() : 0ull;
     if (t.order) wg = (int)t.order[wg];
-    else if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
+    else if (!t.env_order && (gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
     long env = (long)wg * EPB + env_local;
     const bool valid = env < n_envs;
     if (!valid) env = n_envs - 1;   // tail lanes shadow the last env (no stores) so barriers stay uniform
+    if (t.env_order) env = (long)t.env_order[env];     // (position -> env: a permutation of 0 .. n_envs - 1, heaviest first)
     // the template in LDS.  Per-env worlds run one env per workgroup (L = 64), so the copy -- this env's own -- is still
     // shared by all lanes and every template address stays wave-uniform
     const bool per_env = L == 64 && t.tmpl_stride_words != 0;
@@ -167,6 +175,7 @@ __device__ __forceinline__ void step_body(const TmplDev &t, P *__restrict__ sp, 
     }
     SYNC(solve_ctx_flush(e, ctx, lane, nl))
     if (valid) ph_store_state(e, sp, sf, si, stride, env, lane, nl);
+    if (t.env_cost && valid && lane == 0) t.env_cost[env] = (uint32_t)(4 * E_I(misc, M_NK) + E_I(misc, M_NOV));
     if (ho.queue) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -228,6 +237,32 @@ __global__ __launch_bounds__(1024) void k_step_order(const uint32_t *__restrict_
     if (tid == 0) { uint32_t acc = 0; for (int b = 0; b < 256; b++) { const uint32_t c = hist[b]; hist[b] = acc; acc += c; } }
     __syncthreads();
     for (int i = tid; i < n; i += 1024) order[atomicAdd(&hist[cls(dur[i])], 1u)] = (uint32_t)i;
+}
+
+// Env order of the NEXT launch from the cost keys the last one left (TmplDev::env_order): a counting sort, costliest first, ties in
+// env order (a stable sort keeps neighbouring envs -- and their shared state lines -- together where nothing touches).
+__global__ __launch_bounds__(1024) void k_env_order(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, int n) {
+    __shared__ uint32_t hist[64], base[64];
+    const int tid = threadIdx.x;
+    auto cls = [](uint32_t c) { return 63u - (c > 63u ? 63u : c); };        // 0 = costliest
+    if (tid < 64) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[cls(cost[i])], 1u);
+    __syncthreads();
+    if (tid == 0) { uint32_t acc = 0; for (int b = 0; b < 64; b++) { base[b] = acc; acc += hist[b]; } }
+    __syncthreads();
+    // stable placement: one wavefront per class walks the envs in order (64 classes on 16 wavefronts, four rounds)
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int b = wave; b < 64; b += 16) {
+        uint32_t at = base[b];
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool mine = i < n && cls(cost[i]) == (uint32_t)b;
+            const unsigned long long m = __ballot(mine);
+            if (mine) order[at + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            at += (uint32_t)__popcll(m);
+        }
+    }
 }
 
 // BaseEnv.reset(): one thread per env writes the template state into the masked envs

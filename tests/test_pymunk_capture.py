@@ -89,7 +89,7 @@ def check_hip_engine_against(cap, task, exact_oracle):
     env.reset()
     ref = new_ref(task)
     idx, mask = ref_body_index(ref), comparable_mask(ref)
-    assert np.array_equal(env.get_bodies()[0, 1:, :3][mask], rec['states'][0][idx][:, :3][mask]), 'initial poses differ from the captured ones'
+    assert np.allclose(env.get_bodies()[0, 1:, :3][mask], rec['states'][0][idx][:, :3][mask], rtol=0, atol=1e-12), 'initial poses differ from the captured ones'
     orc = OracleEnvelope([lambda: new_ref(task)], K=8, eps=EPS_F32, seed=0, fp32_state=True)
     tally, shown = EnvelopeTally(), []
     for s, a in enumerate(tape):

@@ -24,12 +24,24 @@ class _Timed:
             return r
         return call
 env._lib = _Timed(env._lib)
+# steady state, without the profiler: seven resets (ten env-steps between them), wall time and native calls of each
+walls = []
+for rep in range(7):
+    for _ in range(10): env.step(torch.zeros(N, dtype=torch.int32, device='cuda:0'))
+    torch.cuda.synchronize()
+    native_ms.clear()
+    t0 = time.perf_counter()
+    env._reset_envs(idx, None); torch.cuda.synchronize()
+    walls.append((time.perf_counter() - t0) * 1e3)
+    print('  reset %d: %.1f ms' % (rep, walls[-1]), 'native calls (ms):', {k: round(v, 1) for k, v in native_ms.items()})
+print(name, 'steady-state reset of %d envs: median %.1f ms, min %.1f, max %.1f over %d resets' % (N, np.median(walls), min(walls), max(walls), len(walls)))
+native_ms.clear()
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()
 env._reset_envs(idx, None); torch.cuda.synchronize()
 pr.disable()
-print(name, 'reset of %d envs: %.1f ms' % (N, (time.perf_counter() - t0) * 1e3), 'native calls (ms):', {k: round(v, 1) for k, v in native_ms.items()})
+print(name, 'reset of %d envs under cProfile: %.1f ms' % (N, (time.perf_counter() - t0) * 1e3), 'native calls (ms):', {k: round(v, 1) for k, v in native_ms.items()})
 pstats.Stats(pr).sort_stats('cumulative').print_stats(40)
 for _ in range(3):
     t0 = time.perf_counter(); env.step(torch.zeros(N, dtype=torch.int32, device='cuda:0')); torch.cuda.synchronize()
