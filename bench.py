@@ -273,7 +273,8 @@ def measure(args, rank, world, device):
             dist.barrier()
         torch.cuda.synchronize()
 
-    env.set_timing(8 if K >= 160 else 2)       # HIP events around every 8th (short windows: every 2nd) launch of each kernel inside the timed region
+    every = int(os.environ.get('MGX_BENCH_TIMING_EVERY', '0')) or (8 if K >= 160 else 2)
+    env.set_timing(every)       # HIP events around every 8th (short windows: every 2nd) launch of each kernel inside the timed region
     last_score.zero_()
     score_host = np.zeros(n, dtype=np.float64)          # scores are collected on the host and uploaded once, for the gather
     n_eps = 0
@@ -288,12 +289,13 @@ def measure(args, rank, world, device):
             score_host[done] = info['eval_score'][done]
     last_score.copy_(torch.as_tensor(score_host))
     # end-of-rollout gather over xGMI (RCCL): per-env scores of every rank; observations never leave their GPU
-    torch.cuda.synchronize()
-    tg = time.perf_counter()
+    ev_g0, ev_g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # (device-side clock: no host sync before the collective)
+    ev_g0.record()
     all_scores = gather_rollout_results(last_score, n * world)
+    ev_g1.record()
     barrier()
-    gather_ms = (time.perf_counter() - tg) * 1e3
     elapsed = time.perf_counter() - t0
+    gather_ms = ev_g0.elapsed_time(ev_g1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -409,7 +411,7 @@ def measure(args, rank, world, device):
                                              'written per pixel + pose rows); frac_new_frame_row uses the 28.3 KB headline row'},
             'collective': {'backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')) if dist.is_initialized() else None,
                            'world_size': world, 'in_timed_region': f'one all_gather of the per-env scores f64[{n}] per rank at the end of the rollout',
-                           'ms': gather_ms} if dist.is_initialized() else {'backend': None, 'note': 'no process group: single process, gather skipped'},
+                           'ms_on_stream': gather_ms} if dist.is_initialized() else {'backend': None, 'note': 'no process group: single process, gather skipped'},
             'roofline': {'bound': bound_of(dom), 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          **alu_fields(dom), 'alu_source': alu_src, 'scratch_bytes': scratch_of(dom),

@@ -1603,7 +1603,8 @@ def test_batched_draws_equal_the_per_env_loop(env_name, n):
 @pytest.mark.gpu
 def test_fused_step_schedules_are_interchangeable():
     """The switches that change HOW the fused env-step is issued (the join on the rasteriser's own completion signal / on a marker
-    event behind it; the two kernels one after the other) change nothing about what it computes: one short rollout with a partial
+    event behind it; the two kernels one after the other; the step launch's envs in index order instead of costliest first, round 4)
+    change nothing about what it computes: one short rollout with a partial
     episode end inside, each schedule in a process of its own (the switches are read once per process), same observation and state
     digests."""
     import subprocess, sys, os, json
@@ -1624,12 +1625,13 @@ def test_fused_step_schedules_are_interchangeable():
         "h.update(env.get_bodies().tobytes())\n"
         "print(json.dumps({'digest': h.hexdigest(), 'stats': list(env.handoff_stats())}))\n" % root)
     out = {}
-    for name, var in (('completion signal', None), ('marker event', 'MGX_JOIN_MARKER'), ('one after the other', 'MGX_NO_OVERLAP')):
-        envv = {k: v for k, v in os.environ.items() if k not in ('MGX_JOIN_MARKER', 'MGX_NO_OVERLAP')}
+    for name, var in (('completion signal', None), ('marker event', 'MGX_JOIN_MARKER'), ('one after the other', 'MGX_NO_OVERLAP'),
+                      ('envs in index order', 'MGX_NO_ENV_PACK')):
+        envv = {k: v for k, v in os.environ.items() if k not in ('MGX_JOIN_MARKER', 'MGX_NO_OVERLAP', 'MGX_NO_ENV_PACK')}
         if var:
             envv[var] = '1'
         r = subprocess.run([sys.executable, '-c', prog], capture_output=True, text=True, env=envv, timeout=600)
         assert r.returncode == 0, (name, r.stderr[-2000:])
         out[name] = json.loads(r.stdout.strip().splitlines()[-1])
         assert out[name]['stats'][1] == 0, (name, out[name])          # no hand-off wait ran out
-    assert out['completion signal']['digest'] == out['marker event']['digest'] == out['one after the other']['digest'], out
+    assert out['completion signal']['digest'] == out['marker event']['digest'] == out['one after the other']['digest'] == out['envs in index order']['digest'], out
