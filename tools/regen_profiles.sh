@@ -73,3 +73,24 @@ for f in sorted(glob.glob('*pmc_traffic*.json')):
     d=json.load(open(f)); print(f, {k:(round(v['FETCH_SIZE_x2_bytes']/1e6,1), round(v['WRITE_SIZE_bytes_median']/1e6,1), round(v['hbm_traffic_bytes_per_launch']/1e6,1)) for k,v in d.items() if k!='calibration'})
 PY
 cat ${R}_task_step_times.txt; wc -l ${R}_rollout_all_60_variants_4096x1gpu.jsonl
+# development builds (python -c "import os; from magical_amd import _native; r = os.getcwd();
+#   _native.build(force=True, defines=['MGX_STEP_PROBE'], out=r + '/magical_amd/libmagical_hip_probe.so');
+#   _native.build(force=True, defines=['MGX_RASTER_CLOCKS'], out=r + '/magical_amd/libmagical_hip_clocks.so')" before the gpurun call): phase cycles, timelines
+cd $GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out/extra; rm -rf $O; mkdir -p $O
+if [ -f magical_amd/libmagical_hip_probe.so ]; then
+  for t in mtc:MoveToCorner-Demo-v0 cc:ClusterColour-Demo-v0; do
+    MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_probe.so python tools/step_phase_probe.py ${t#*:} 2>&1 | grep -v amdgpu > $O/${R}_step_phase_cycles_${t%%:*}.txt
+  done
+fi
+if [ -f magical_amd/libmagical_hip_clocks.so ]; then
+  MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so python tools/dev/fused_timeline.py 2>&1 | grep -v amdgpu > $O/${R}_fused_timeline_mtc_lores4e.txt
+  MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so python tools/dev/raster_phase_clocks.py 2>&1 | grep -v amdgpu > $O/${R}_raster_phase_clocks_mtc.txt
+  MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so python tools/dev/nq_stats.py 2>&1 | grep -v amdgpu > $O/${R}_raster_queue_load_by_task.txt
+fi
+for t in ClusterColour-TestAll-LoRes4E-v0 MatchRegions-TestCountPlus-LoRes4E-v0; do
+  timeout 300 python tools/reset_profile.py $t 2>&1 | grep -v amdgpu.ids > $O/${R}_reset_profile_$t.txt
+done
+timeout 600 python tools/window20_probe.py 2>&1 | grep -v amdgpu.ids > $O/${R}_window20_probe.txt
+timeout 600 python tools/raster_consistency_sweep.py 2>&1 | tail -20 > $O/${R}_raster_consistency_sweep_tail.txt
+head -30 $O/${R}_step_phase_cycles_mtc.txt
