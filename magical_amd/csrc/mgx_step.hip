@@ -242,7 +242,9 @@ __global__ __launch_bounds__(1024) void k_step_order(const uint32_t *__restrict_
 // Env order of the NEXT launch from the cost keys the last one left (TmplDev::env_order): a counting sort, costliest first, ties in
 // env order (a stable sort keeps neighbouring envs -- and their shared state lines -- together where nothing touches).
 __global__ __launch_bounds__(1024) void k_env_order(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, int n) {
+    constexpr int CHUNK = 8192;                         // envs whose classes are staged in LDS at a time
     __shared__ uint32_t hist[64], base[64];
+    __shared__ uint8_t cls_of[CHUNK];
     const int tid = threadIdx.x;
     auto cls = [](uint32_t c) { return 63u - (c > 63u ? 63u : c); };        // 0 = costliest
     if (tid < 64) hist[tid] = 0;
@@ -251,16 +253,27 @@ __global__ __launch_bounds__(1024) void k_env_order(const uint32_t *__restrict__
     __syncthreads();
     if (tid == 0) { uint32_t acc = 0; for (int b = 0; b < 64; b++) { base[b] = acc; acc += hist[b]; } }
     __syncthreads();
-    // stable placement: one wavefront per class walks the envs in order (64 classes on 16 wavefronts, four rounds)
+    // stable placement: one wavefront per NON-EMPTY class walks the envs in order, their classes read from LDS (the keys are small:
+    // a handful of classes are populated; round 4's first form walked all 64 classes over global memory: 166 us per launch)
     const int wave = tid >> 6, lane = tid & 63;
-    for (int b = wave; b < 64; b += 16) {
-        uint32_t at = base[b];
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + lane;
-            const bool mine = i < n && cls(cost[i]) == (uint32_t)b;
-            const unsigned long long m = __ballot(mine);
-            if (mine) order[at + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
-            at += (uint32_t)__popcll(m);
+    for (int c0 = 0; c0 < n; c0 += CHUNK) {
+        const int m = n - c0 < CHUNK ? n - c0 : CHUNK;
+        __syncthreads();
+        for (int i = tid; i < m; i += 1024) cls_of[i] = (uint8_t)cls(cost[c0 + i]);
+        __syncthreads();
+        int slot = 0;                                   // the slot-th non-empty class goes to wavefront slot % 16
+        for (int b = 0; b < 64; b++) {
+            if (hist[b] == 0) continue;
+            if ((slot++ & 15) != wave) continue;
+            uint32_t at = base[b];
+            for (int i0 = 0; i0 < m; i0 += 64) {
+                const int i = i0 + lane;
+                const bool mine = i < m && cls_of[i] == (uint8_t)b;
+                const unsigned long long mk = __ballot(mine);
+                if (mine) order[at + __popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)(c0 + i);
+                at += (uint32_t)__popcll(mk);
+            }
+            base[b] = at;                               // (only this wavefront touches class b: next chunk continues here)
         }
     }
 }
