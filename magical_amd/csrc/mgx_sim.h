@@ -1093,14 +1093,25 @@ template <typename R, typename P> MGX_HD void ph_refresh_trig(Env<R, P> &e, int 
         E_P(c, b) = c; E_P(s, b) = s;
     }
 }
+// the pose rows alone (the state the rasteriser reads): final after the last substep's ph_integrate
 template <typename R, typename P>
-MGX_HD void ph_store_state(Env<R, P> &e, P *sp, R *sf, int32_t *si, long stride, long env, int lane, int nl) {
+MGX_HD void ph_store_poses(Env<R, P> &e, P *sp, long stride, long env, int lane, int nl) {
+    const TmplHeader &h = *e.h;
+    for (int k = lane; k < h.n_state; k += nl) {
+        int m = T_I(state_map, k), comp = m & 15, b = (m >> 4) & 0xFF, row = m >> 12;
+        if (comp < 3) sp[(long)row * stride + env] = comp == 0 ? E_P(px, b) : (comp == 1 ? E_P(py, b) : E_P(ang, b));
+    }
+}
+template <typename R, typename P>
+MGX_HD void ph_store_state(Env<R, P> &e, P *sp, R *sf, int32_t *si, long stride, long env, int lane, int nl, bool poses_stored = false) {
     const TmplHeader &h = *e.h;
     int nvel = state_row_jacc0(h);      // first row after the velocities and force limits
     for (int k = lane; k < h.n_state; k += nl) {
         int m = T_I(state_map, k), comp = m & 15, b = (m >> 4) & 0xFF, row = m >> 12;
         if (comp < 3) {
-            sp[(long)row * stride + env] = comp == 0 ? E_P(px, b) : (comp == 1 ? E_P(py, b) : E_P(ang, b));
+            // (poses_stored: the rows went out after the last position update, ph_store_poses; the kinematic control body's angle is
+            // set again by Robot.update at the end of the substep -- not drawn, re-derived at the next step's start -- and is stored here)
+            if (!poses_stored || b == h.control_body) sp[(long)row * stride + env] = comp == 0 ? E_P(px, b) : (comp == 1 ? E_P(py, b) : E_P(ang, b));
         } else {
             R v;
             switch (comp) {
@@ -1167,8 +1178,12 @@ MGX_HD void reset_env_state(const TmplHeader &h, const int32_t *ti, const R *tr,
 
 // One physics substep as a list of phases; X(stmt) runs `stmt` for (lane, nl) and then
 // synchronises the env's lane group.  Used by mgx_step.hip (device) and tests/emu (host).
+// (everything after the position update: a substep's poses are final once ph_integrate has run -- what follows finds the collisions
+// at the new positions and solves for the velocities that the NEXT substep integrates, cpSpaceStep's order)
 #define MGX_SUBSTEP_PHASES(X)                                      \
     X(ph_integrate(e, lane, nl))                                   \
+    MGX_SUBSTEP_AFTER_INTEGRATE(X)
+#define MGX_SUBSTEP_AFTER_INTEGRATE(X)                             \
     X(ph_shapes(e, lane, nl))                                      \
     X(ph_broad(e, lane, nl))                                       \
     X(ph_narrow(e, lane, nl))                                      \

@@ -170,19 +170,39 @@ __device__ __forceinline__ void step_body(const TmplDev &t, P *__restrict__ sp, 
     if (lane == 0) ph_control(e);
     __syncthreads();
     solve_ctx_init(e, ctx, lane, nl);
+    // The hand-off to the rasteriser (fused env-step) happens as soon as the poses are final -- after the LAST substep's position update:
+    // what that substep still does (collisions at the new positions, the solve) only sets up the velocities of the next env-step.
+    // The pose rows go out and are published there, a tenth of the kernel before its end; everything else is stored at the end.
+#ifndef MGX_EARLY_HANDOFF
+#define MGX_EARLY_HANDOFF 1      // 0: publish at the end of the kernel (A/B builds)
+#endif
+    const bool early = MGX_EARLY_HANDOFF && ho.queue != nullptr && n_sub > 0;
     for (int sub = 0; sub < n_sub; sub++) {
-        MGX_SUBSTEP_PHASES(SYNC)
+        SYNC(ph_integrate(e, lane, nl))
+        if (early && sub == n_sub - 1) {
+            if (valid) ph_store_poses(e, sp, stride, env, lane, nl);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler may drop the fence's own wait: keep this one)
+            if (valid && lane == 0) {
+                const unsigned ticket = __hip_atomic_fetch_add(ho.tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ticket - ho.base < (unsigned)n_envs)       // (never false while the host's mirror of *tail is right: keeps a wrong base in bounds)
+                    __hip_atomic_store(&ho.queue[ticket - ho.base], ((unsigned long long)ho.epoch << 32) | (unsigned long long)env,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        MGX_SUBSTEP_AFTER_INTEGRATE(SYNC)
     }
     SYNC(solve_ctx_flush(e, ctx, lane, nl))
-    if (valid) ph_store_state(e, sp, sf, si, stride, env, lane, nl);
+    if (valid) ph_store_state(e, sp, sf, si, stride, env, lane, nl, early);
     if (t.env_cost && valid && lane == 0) t.env_cost[env] = (uint32_t)(4 * E_I(misc, M_NK) + E_I(misc, M_NOV));
-    if (ho.queue) {
+    if (ho.queue && !early) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler may drop the fence's own wait: keep this one)
         if (valid && lane == 0) {
             const unsigned ticket = __hip_atomic_fetch_add(ho.tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ticket - ho.base < (unsigned)n_envs)       // (never false while the host's mirror of *tail is right: keeps a wrong base in bounds)
+            if (ticket - ho.base < (unsigned)n_envs)
                 __hip_atomic_store(&ho.queue[ticket - ho.base], ((unsigned long long)ho.epoch << 32) | (unsigned long long)env,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
