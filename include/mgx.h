@@ -236,8 +236,9 @@ int mgx_engine_render(mgx_engine *e, const void *state_p, uint8_t *out, int64_t 
                       const uint8_t *fill_mask, void *stream);
 /* BaseEnv.step() physics + its observation in ONE call (base_env.py:255-292 with the wrappers of
  * benchmarks/__init__.py:80-136,219-256): = mgx_engine_step followed by mgx_engine_render(fill_mask = NULL) on the same
- * buffers, same results bit for bit, but issued as a producer / consumer pair: the step kernel publishes every env whose
- * state it has written back, and the raster kernel -- on a stream of the engine's own, joined to `stream` before and after --
+ * buffers, same results bit for bit, but issued as a producer / consumer pair: the step kernel publishes every env as soon as its
+ * POSES are final and written back (after the last substep's position update: cpSpaceStep moves the bodies first, the rest of the
+ * substep only prepares the next step's velocities; the motion blob follows at the kernel's end), and the raster kernel -- on a stream of the engine's own, joined to `stream` before and after --
  * rasterises envs in the order they finish, so the long tail of the physics (a few envs with many contacts) runs under the
  * rasterisation of the others.  Not for steps in which envs are reset between physics and rendering (episode ends:
  * use the two calls).  Every world takes this path (a consumer waits at length only once all producers are resident, otherwise

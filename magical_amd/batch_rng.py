@@ -18,15 +18,21 @@ from . import _native as nat
 _U64P, _IP, _DP = C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_double)
 
 
+def state_addresses(rngs):
+    """uint64[m]: where each RandomState's MT19937 state lives (the native batch calls advance it in place)."""
+    out = np.empty(len(rngs), dtype=np.uint64)
+    for i, rng in enumerate(rngs):
+        bg = rng._bit_generator
+        assert type(bg).__name__ == 'MT19937'
+        out[i] = bg.ctypes.state_address
+    return out
+
+
 class BatchRng:
     def __init__(self, rngs, lib=None):
         self.L = lib or nat.lib()
         self.m = len(rngs)
-        self.addrs = np.empty(self.m, dtype=np.uint64)
-        for i, rng in enumerate(rngs):
-            bg = rng._bit_generator
-            assert type(bg).__name__ == 'MT19937'
-            self.addrs[i] = bg.ctypes.state_address
+        self.addrs = state_addresses(rngs)
         self._rngs = rngs          # keep the generators (and so the states the addresses point at) alive
 
     def _sel(self, rows):

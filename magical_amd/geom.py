@@ -135,11 +135,8 @@ def pm_randomise_all_poses_batch(env, poses, entities, arena_lrbt, rngs, rand_po
             a = np.tile(a, (m, 1)) if per_env else a
         return np.ascontiguousarray(np.where(np.isnan(a), -1.0, a))
     pl, rl = lim(rel_pos_linf_limits), lim(rel_rot_limits)
-    addrs = np.empty(m, dtype=np.uint64)
-    for i, rng in enumerate(rngs):
-        bg = rng._bit_generator
-        assert type(bg).__name__ == 'MT19937'
-        addrs[i] = bg.ctypes.state_address
+    from .batch_rng import state_addresses
+    addrs = state_addresses(rngs)
     ents = (C.c_int * n)(*[e.ent_id for e in entities])
     ign = np.zeros(poses.shape[1], dtype=np.uint8)
     for e in ignore:
