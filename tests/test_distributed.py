@@ -32,6 +32,10 @@ def _worker(rank, world, port, n_total, out_dir):
     all_poses = gather_rollout_results(poses, n_total)
     np.save(os.path.join(out_dir, f'scores_{rank}.npy'), all_scores.numpy())
     np.save(os.path.join(out_dir, f'poses_{rank}.npy'), all_poses.numpy())
+    # equal shards (the weak-scaling bench: every rank the same env count): one collective straight into the result
+    even = torch.arange(rank * 4, rank * 4 + 4, dtype=torch.float64).reshape(4, 1).repeat(1, 3)
+    np.save(os.path.join(out_dir, f'even_{rank}.npy'), gather_rollout_results(even, 4 * world).numpy())
+    np.save(os.path.join(out_dir, f'even_unsized_{rank}.npy'), gather_rollout_results(even).numpy())      # sizes exchanged, not derived
     dist.destroy_process_group()
 
 
@@ -48,6 +52,8 @@ def test_gather_rollout_results_gloo_world2(tmp_path):
         assert np.array_equal(scores, np.arange(n_total) / n_total)
         assert np.array_equal(poses[:, 0], np.arange(n_total, dtype=np.float32))
         assert np.array_equal(poses[:, 1], np.array([0.0] * 6 + [1.0] * 5, dtype=np.float32))
+        want = np.repeat(np.arange(8, dtype=np.float64)[:, None], 3, axis=1)
+        assert np.array_equal(np.load(tmp_path / f'even_{rank}.npy'), want) and np.array_equal(np.load(tmp_path / f'even_unsized_{rank}.npy'), want)
 
 
 # ---- RCCL on the one GPU of the box: a process group of ONE rank, backend "nccl" (= RCCL on ROCm), and the payloads
