@@ -489,9 +489,9 @@ MGX_HD void tile_centre(int tile, float &xc, float &yc) {
 // 16-bit coverage of the 4x4 sample block whose top-left sample is (x0, y0); bit 4*j + i = sample (x0 + i, y0 - j).
 // fp32 first: a sample is decided in fp32 when |E| > CLASS_EPS_F, otherwise that one sample is re-evaluated in fp64
 // against the fp64 edge function -- the result equals the all-fp64 test.
-// TWO_PASS: the two-pass form below (false: the edge-by-edge form -- for the rasteriser's 96-register variant, which runs the
-// small worlds: there the extra code costs more in spills than it saves; measured, MoveToCorner's fused env-step 0.68 -> 0.70 ms)
-template <bool TWO_PASS = true> MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, int X, int Y, uint32_t &unc) {
+// (Rounds 2-3 kept an edge-by-edge form of this for the rasteriser's 96-register variant, which then spilled 63 registers; since phase Q was
+// shrunk in round 4 the two-pass form wins there too: MoveToCorner 7.65 -> 7.77 M env-steps/s, profiles/r04_raster_phase_q_shrink_ab.txt.)
+MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, int X, int Y, uint32_t &unc) {
 #ifdef MGX_Q_NO_POLY      // development probe: what phase Q costs without the polygon coverage arithmetic (wrong pixels)
     return 0x0F0Fu;
 #endif
@@ -499,42 +499,6 @@ template <bool TWO_PASS = true> MGX_HD uint32_t poly_coverage16(const Raster &rs
     const uint32_t ends = rs.prim_ends(k) | (1u << (nv - 1));               // bit e: edge e closes a convex part
     const float x0 = 4.0f * X + 0.5f, y0 = (float)NATIVE_RES - 0.5f - 4.0f * Y;
     const Item *items = reinterpret_cast<const Item *>(&RI(items, 0)) + i0;
-    if (!TWO_PASS) {
-        // the edges in turn, samples only where an edge crosses the block.  `part` = samples inside every edge of the convex part
-        // being walked; the polygon is the union of its parts (a sample that is ambiguous for one part stays flagged even when
-        // another part holds it: the exact painter then decides it)
-        uint32_t cov = 0, part = 0xFFFFu;
-        for (int e = 0; e < nv; e++) {
-            if (part) {
-                const float a = items[e].a, b = items[e].b;
-                float row = a * x0 + b * y0 + items[e].c;
-                // block spans x0..x0+3, y0-3..y0: worst / best corner value of this edge function
-                const float lo = row + r_min(0.0f, 3.0f * a) - r_max(0.0f, 3.0f * b);
-                const float hi = row + r_max(0.0f, 3.0f * a) - r_min(0.0f, 3.0f * b);
-                if (hi < -CLASS_EPS_F) part = 0;                               // whole block outside this edge
-                else if (lo < CLASS_EPS_F) {                                   // (else: whole block inside it)
-                    uint32_t in = 0, amb = 0;
-                    for (int j = 0; j < 4; j++) {
-                        float v = row;
-                        for (int i = 0; i < 4; i++) {
-                            in |= (v >= CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
-                            amb |= (r_abs(v) < CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
-                            v += a;
-                        }
-                        row -= b;
-                    }
-                    unc |= amb & part;                                         // samples too close to call in fp32
-                    part &= in;
-                }
-            }
-            if ((ends >> e) & 1u) {
-                cov |= part;
-                if (e == nv - 1 || cov == 0xFFFFu) break;
-                part = 0xFFFFu;
-            }
-        }
-        return cov;
-    }
     // Two passes, so that the lanes of a wavefront (each on its own pixel, often on different polygons) diverge as little as
     // possible.  Pass 1, the same few operations per edge for every lane: is the block wholly outside the edge (`dead`), does
     // the edge cross it (`cross`), or is the block wholly inside?  Pass 2 evaluates the 16 samples only for the crossing edges
@@ -630,26 +594,23 @@ MGX_HD uint32_t ngon_coverage16(const Raster &rs, int k, int X, int Y, uint32_t 
     }
     return cov;
 }
-// samples of the block that a line loop may touch (alpha > 0 possible), fp32 conservative
+// The segments of a line loop that can touch the pixel's 4x4 block (fp32, conservative), as a bit mask; the return value is the set of
+// samples the line then CLAIMS: all sixteen.  Alpha is exactly 0 wherever the line is not, and an alpha of 0 leaves the colour underneath, so
+// blending every sample of a crossed block gives the painter's pixel -- round 3 first tested the sixteen samples against every crossing
+// segment to claim only the touched ones: 64 more instructions per segment in a kernel that pays for its code in spilled registers.
 MGX_HD uint32_t lineloop_touch16(const Raster &rs, int k, int X, int Y, uint32_t &segmask) {
     segmask = 0;
     const int nv = rs.prim_nv(k), i0 = RI(pitem, k) & 0xFFFF;
     const float x0 = 4.0f * X + 0.5f, y0 = (float)NATIVE_RES - 0.5f - 4.0f * Y;
     const Item *items = reinterpret_cast<const Item *>(&RI(items, 0)) + i0;
-    uint32_t touch = 0;
     for (int e = 0; e < nv; e++) {
         const float a = items[e].a, b = items[e].b, hw = items[e].g3 + CLASS_EPS_F;
-        float row = a * x0 + b * y0 + items[e].c;
+        const float row = a * x0 + b * y0 + items[e].c;
         const float lo = row + r_min(0.0f, 3.0f * a) - r_max(0.0f, 3.0f * b), hi = row + r_max(0.0f, 3.0f * a) - r_min(0.0f, 3.0f * b);
         if (lo > hw || hi < -hw) continue;                                  // block entirely off the carrier line
         segmask |= 1u << e;
-        for (int j = 0; j < 4; j++) {
-            float v = row;
-            for (int i = 0; i < 4; i++) { touch |= (r_abs(v) <= hw ? 1u : 0u) << (4 * j + i); v += a; }
-            row -= b;
-        }
     }
-    return touch;
+    return segmask ? 0xFFFFu : 0u;
 }
 
 // fp32 alpha of all 16 samples of the block for the segments in `segmask`, in block-local coordinates: the fp64 edge
@@ -700,82 +661,97 @@ MGX_HD void lineloop_alpha16(const Raster &rs, int k, int X, int Y, uint32_t seg
 // guaranteed to agree with the fp64 painter (within the fp32 margin of an edge, a blended channel within TAU of a
 // rounding boundary, an undecidable stipple bit, two line loops on top of each other) that sample is left out of the
 // sums and reported in `uncertain`, to be added with pixel_add_exact.  sums = r | g << 12 | b << 24 (each <= 4080).
-template <bool TWO_PASS = true> MGX_HD uint64_t pixel_resolve_fast(const Raster &rs, int X, int Y, uint64_t mixed, int base, uint32_t &uncertain) {
+#ifndef MGX_Q_MAXL
+#define MGX_Q_MAXL 1          // undecided opaque primitives remembered under a line loop (more than that under one line: the exact painter)
+#endif
+// One walk down the pixel's primitives, every coverage function called from ONE place.  A line loop that touches still-unclaimed samples
+// becomes PENDING: the walk goes on below it and notes, for the opaque primitives it meets, mask and colour (at most MGX_Q_MAXL of them);
+// when the list ends -- or every sample is accounted for -- the pending line's alphas are computed and blended over what lies underneath.
+// (Round 3 evaluated the primitives below a line from inside the line's branch -- the coverage code inlined twice -- remembered four of them and
+// tested all sixteen samples against every crossing segment first; the rasteriser's 96-register variant pays for every instruction and every
+// live value of phase Q in spilled registers, and each of the three cuts made it faster: profiles/r04_raster_phase_q_shrink_ab.txt.)
+MGX_HD uint64_t pixel_resolve_fast(const Raster &rs, int X, int Y, uint64_t mixed, int base, uint32_t &uncertain) {
+    constexpr int MAXL = MGX_Q_MAXL;
     uint32_t remaining = 0xFFFFu, unc = 0;
     int sr = 0, sg = 0, sb = 0;
+    int pk = -1;                              // the pending line loop, the samples it claimed, its segments that cross the block
+    uint32_t pcov = 0, psegmask = 0, pneed = 0, lunc = 0;
+    uint32_t lcov[MAXL]; int lcol[MAXL]; int nlow = 0;
     uint64_t m = mixed;
     MGX_RSTAT(0, 1); MGX_RSTAT(1, __builtin_popcountll(mixed));
-    while (m && remaining) {
+    while (m && (remaining | pneed)) {
         const int k = 63 - __builtin_clzll(m);
         m &= ~(1ull << k);
         const int kind = rs.prim_kind(k);
-        uint32_t cov;
         if (kind == PR_LINELOOP) {
-            uint32_t segmask;
 #ifdef MGX_Q_NO_LINE      // development probe: ... without the line loops
             continue;
 #endif
-            cov = lineloop_touch16(rs, k, X, Y, segmask) & remaining;
+            uint32_t segmask;
+            const uint32_t cov = lineloop_touch16(rs, k, X, Y, segmask) & remaining;
             MGX_RSTAT(2, 1);
-            if (cov) {
+            if (pk >= 0) {
+                // a second line loop below a pending one: the pending line's samples and this one's go to the exact painter
+                lunc = 0xFFFFu; unc |= cov;
+            } else if (cov) {
                 MGX_RSTAT(3, 1); MGX_RSTAT(4, __builtin_popcount(cov)); MGX_RSTAT(5, __builtin_popcount(segmask));
-                // colour under the line for each touched sample: coverage masks of the opaque prims below it (front to back)
-                constexpr int MAXL = 4;
-                uint32_t lcov[MAXL]; int lcol[MAXL]; int nlow = 0;
-                uint32_t lunc = 0;
-                const uint64_t lower = mixed & ((1ull << k) - 1ull);
-                for (uint64_t lm = lower; lm;) {
-                    const int kk = 63 - __builtin_clzll(lm);
-                    lm &= ~(1ull << kk);
-                    const int kd = rs.prim_kind(kk);
-                    if (kd == PR_LINELOOP || nlow == MAXL) { lunc = 0xFFFFu; break; }
-                    lcov[nlow] = kd == PR_POLY ? poly_coverage16<TWO_PASS>(rs, kk, X, Y, lunc) : ngon_coverage16(rs, kk, X, Y, lunc);
-                    lcol[nlow] = rs.prim_rgb(kk);
-                    nlow++;
-                }
-                const int col = rs.prim_rgb(k);
-                float alpha[16];
-                lineloop_alpha16(rs, k, X, Y, segmask, alpha, lunc);
-                const float lrf = (float)(col & 0xFF), lgf = (float)((col >> 8) & 0xFF), lbf = (float)((col >> 16) & 0xFF);
-                constexpr float TAU = 255.0f * ALPHA_ERR_F + 5e-4f;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-                for (int sidx = 0; sidx < 16; sidx++) {
-                    if (!(((cov & ~lunc) >> sidx) & 1u)) continue;
-                    int c = base;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-                    for (int q = MAXL - 1; q >= 0; q--) if (q < nlow && ((lcov[q] >> sidx) & 1u)) c = lcol[q];   // back to front
-                    const float a = alpha[sidx];
-                    const float cr = (float)(c & 0xFF), cg = (float)((c >> 8) & 0xFF), cb = (float)((c >> 16) & 0xFF);
-                    const float vr = cr + a * (lrf - cr) + 0.5f, vg = cg + a * (lgf - cg) + 0.5f, vb = cb + a * (lbf - cb) + 0.5f;
-                    const float fr = floorf(vr), fg = floorf(vg), fb = floorf(vb);
-                    const float dr = r_abs(vr - fr - 0.5f), dg = r_abs(vg - fg - 0.5f), db = r_abs(vb - fb - 0.5f);
-                    if (r_max(r_max(dr, dg), db) > 0.5f - TAU) { lunc |= 1u << sidx; continue; }
-                    sr += (int)fr; sg += (int)fg; sb += (int)fb;
-                }
-                unc |= lunc & cov;
+                pk = k; pcov = cov; psegmask = segmask; pneed = cov;
             }
-        } else {
-            uint32_t punc = 0;
-            cov = (kind == PR_POLY ? poly_coverage16<TWO_PASS>(rs, k, X, Y, punc) : ngon_coverage16(rs, k, X, Y, punc)) & remaining;
-            MGX_RSTAT(9, 1);
-            punc &= remaining;
-            unc |= punc;
-            cov = (cov & ~punc);
-            if (cov) {
-                const int n = __builtin_popcount(cov), col = rs.prim_rgb(k);
-                sr += n * (col & 0xFF); sg += n * ((col >> 8) & 0xFF); sb += n * ((col >> 16) & 0xFF);
-            }
-            cov |= punc;
+            remaining &= ~cov;
+            continue;
         }
-        remaining &= ~cov;
+        uint32_t punc = 0;
+        const uint32_t full = kind == PR_POLY ? poly_coverage16(rs, k, X, Y, punc) : ngon_coverage16(rs, k, X, Y, punc);
+        MGX_RSTAT(9, 1);
+        const int col = rs.prim_rgb(k);
+        if (pneed) {
+            // under the pending line: remember this primitive (front to back), its uncertain samples are the line's too
+            lunc |= punc & pcov;
+            if (full & pneed) {
+                if (nlow == MAXL) lunc = 0xFFFFu;
+                else { lcov[nlow] = full; lcol[nlow] = col; nlow++; }
+                pneed &= ~full;
+            }
+        }
+        uint32_t cov = full & remaining;
+        punc &= remaining;
+        unc |= punc;
+        cov &= ~punc;
+        if (cov) {
+            const int n = __builtin_popcount(cov);
+            sr += n * (col & 0xFF); sg += n * ((col >> 8) & 0xFF); sb += n * ((col >> 16) & 0xFF);
+        }
+        remaining &= ~(cov | punc);
     }
     if (remaining) {
         const int n = __builtin_popcount(remaining);
         sr += n * (base & 0xFF); sg += n * ((base >> 8) & 0xFF); sb += n * ((base >> 16) & 0xFF);
+    }
+    if (pk >= 0) {
+        const int col = rs.prim_rgb(pk);
+        float alpha[16];
+        lineloop_alpha16(rs, pk, X, Y, psegmask, alpha, lunc);
+        const float lrf = (float)(col & 0xFF), lgf = (float)((col >> 8) & 0xFF), lbf = (float)((col >> 16) & 0xFF);
+        constexpr float TAU = 255.0f * ALPHA_ERR_F + 5e-4f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int sidx = 0; sidx < 16; sidx++) {
+            if (!(((pcov & ~lunc) >> sidx) & 1u)) continue;
+            int c = base;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int q = MAXL - 1; q >= 0; q--) if (q < nlow && ((lcov[q] >> sidx) & 1u)) c = lcol[q];   // back to front: the frontmost wins
+            const float a = alpha[sidx];
+            const float cr = (float)(c & 0xFF), cg = (float)((c >> 8) & 0xFF), cb = (float)((c >> 16) & 0xFF);
+            const float vr = cr + a * (lrf - cr) + 0.5f, vg = cg + a * (lgf - cg) + 0.5f, vb = cb + a * (lbf - cb) + 0.5f;
+            const float fr = floorf(vr), fg = floorf(vg), fb = floorf(vb);
+            const float dr = r_abs(vr - fr - 0.5f), dg = r_abs(vg - fg - 0.5f), db = r_abs(vb - fb - 0.5f);
+            if (r_max(r_max(dr, dg), db) > 0.5f - TAU) { lunc |= 1u << sidx; continue; }
+            sr += (int)fr; sg += (int)fg; sb += (int)fb;
+        }
+        unc |= lunc & pcov;
     }
     MGX_RSTAT(6, unc ? 1 : 0); MGX_RSTAT(7, __builtin_popcount(unc));
     uncertain = unc;
