@@ -39,12 +39,12 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(_CSRC, f)) > t for f in _DEPS)
 
 
-def build(force=False, verbose=False, defines=(), out=None):
-    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  defines / out: development builds with other -D knobs."""
+def build(force=False, verbose=False, defines=(), out=None, extra=()):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  defines / out / extra: development builds with other -D knobs / compiler flags."""
     if not force and not defines and not needs_build():
         return LIB_PATH
     cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-parameter', '-Wno-extern-c-compat',
-           '-pthread', '-o', out or LIB_PATH] + [f'-D{d}' for d in defines] + [os.path.join(_CSRC, f) for f in _SOURCES]
+           '-pthread', '-o', out or LIB_PATH] + list(extra) + [f'-D{d}' for d in defines] + [os.path.join(_CSRC, f) for f in _SOURCES]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)
