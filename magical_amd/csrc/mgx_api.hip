@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <mutex>
 #include <iterator>
 #include <thread>
@@ -288,24 +289,30 @@ int mgx_world_randomise_all_poses(const mgx_world *w, double *poses, const int *
 
 // pm_randomise_all_poses for m envs, env k in the world world_of(k): envs are independent (own stream, own poses), so
 // they are spread over a few host threads
-static int host_threads() {
-    // world building and placement at a reset: as many threads as the host has cores, within [1, MGX_HOST_THREADS (default 32: ClusterColour-TestAll
-    // resets 41-62 ms at 16 threads, 31-48 at 32, no better at 64, worse at 128 -- the allocator)]
+static int host_threads(bool allocating = true) {
+    // world building at a reset: as many threads as the host has cores, within [1, MGX_HOST_THREADS (default 32: ClusterColour-TestAll
+    // resets 41-62 ms at 16 threads, 31-48 at 32, no better at 64, worse at 128 -- the allocator)].  The placement of the entities
+    // (randomise_batch: rejection sampling, no allocation in its loop) keeps scaling: 7.4 ms at 32 threads, 5.8 at 48, 4.5 at 96
+    // (256-core host, profiles/r04_reset_threads.txt) -- MGX_PLACE_THREADS, default 96.
     static const int cap = [] { const char *v = getenv("MGX_HOST_THREADS"); const int c = v ? atoi(v) : 32; return c < 1 ? 1 : (c > 256 ? 256 : c); }();
-    const int hw = (int)std::thread::hardware_concurrency();
-    return hw < 1 ? 1 : (hw > cap ? cap : hw);
+    static const int cap_place = [] { const char *v = getenv("MGX_PLACE_THREADS"); const char *h = getenv("MGX_HOST_THREADS");
+                                      const int c = v ? atoi(v) : (h ? atoi(h) : 96); return c < 1 ? 1 : (c > 256 ? 256 : c); }();
+    const int hw = (int)std::thread::hardware_concurrency(), c = allocating ? cap : cap_place;
+    return hw < 1 ? 1 : (hw > c ? c : hw);
 }
 template <typename WorldOf>
 static int randomise_batch(WorldOf world_of, int ne, int m, double *poses, const int *ents, int n, const uint8_t *ignore,
                            const double arena_lrbt[4], const uint8_t *rand_pos, const uint8_t *rand_rot,
                            const double *pos_limits, const double *rot_limits, int limits_per_env,
                            const uint64_t *mt_state_addr, const double *ent_hw) {
-    int n_threads = host_threads();
+    int n_threads = host_threads(false);
     if (m < 64) n_threads = 1;
     std::vector<long> rej(n_threads, 0);
     std::vector<int> bad(n_threads, 0);
+    std::atomic<int> next{0};                         // (envs differ in their number of rejected draws: chunks of 8 are handed out as threads come free)
     auto work = [&](int t) {
-        for (int k = t; k < m; k += n_threads) {
+        for (int k0 = next.fetch_add(8); k0 < m; k0 = next.fetch_add(8))
+        for (int k = k0; k < k0 + 8 && k < m; k++) {
             // numpy's mt19937_state: uint32 key[624]; int pos
             uint32_t *key = reinterpret_cast<uint32_t *>((uintptr_t)mt_state_addr[k]);
             int *pos = reinterpret_cast<int *>((uintptr_t)mt_state_addr[k] + 624 * sizeof(uint32_t));

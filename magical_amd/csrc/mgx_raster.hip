@@ -304,6 +304,10 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
     long env = blockIdx.x;
 #ifdef MGX_RASTER_CLOCKS
     if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + 9] = clk0;        // (absolute: tools/dev/fused_timeline.py)
+#ifndef MGX_RASTER_PROBE
+    if (t.dbg_clk && (tid & 63) == 0)                                        // where each wavefront runs (tools/dev/placement_probe.py)
+        t.dbg_clk[blockIdx.x * 16 + 10 + (tid >> 6)] = __builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+#endif
 #endif
     // the shared draw list does not depend on the env: stage it before waiting for the hand-off
     if (!t.tmpl_stride_words) { const int n = raster_staged_words(t, t.words); for (int i = tid; i < n; i += 256) lds[i] = t.words[i]; }
@@ -354,6 +358,9 @@ __global__ __launch_bounds__(256, 3) void k_raster_deferred(RasterDev t, const P
     extern __shared__ __align__(16) uint32_t lds[];
     const int tid = threadIdx.x;
 #define CLK(i)
+#ifdef MGX_RASTER_PROBE
+    const unsigned long long clk0 = wall_clock64();     // (the body's PROBE lines refer to it)
+#endif
     if (ho.deferred[blockIdx.x] != ho.epoch) return;                        // (workgroup-uniform)
     const long env = (long)(ho.queue[blockIdx.x] & 0xFFFFFFFFull);         // written by a kernel that has completed
     const uint8_t *fill_mask = nullptr;

@@ -922,15 +922,52 @@ template <typename R, typename P> MGX_HD void solve_iter_publish(Env<R, P> &e, c
     if (lane == 0) ri_store_vel(e, c);
     if (is_block_lane(c, lane)) { E_R(vx, c.mbody) = c.mvx; E_R(vy, c.mbody) = c.mvy; E_R(w, c.mbody) = c.mw; }
 }
+// cpArbiterApplyImpulse's two halves on two lanes.  A contact point carries two impulse chains that never meet inside the
+// iterations: the velocity chain (jnAcc / jtAcc against v, w) and the bias chain (jBias against v_bias, w_bias) -- same
+// constants, same expression trees (relative velocity at the point, normal impulse, clamp at 0, apply to both bodies), disjoint
+// rows of the working set.  Lane 0 of the env runs the first and lane 1 the second in ONE instruction stream: the operands that
+// differ (which velocity rows, jnAcc or jBias, the bias term, the tangent part) are per-lane selects, every arithmetic expression is
+// the one contact_apply_loaded evaluates for that chain, in its order.  The contact chain -- what the slowest workgroups of a
+// launch spend their time in -- then costs the velocity half alone.
+#ifndef MGX_CONTACT_SPLIT
+#define MGX_CONTACT_SPLIT 1
+#endif
+template <typename R, typename P> MGX_HD void contact_apply_split(Env<R, P> &e, int k, const ContactK<R> &c, bool bl) {
+    const int a = c.a, b = c.b;
+    const R nx = c.nx, ny = c.ny, r1x = c.r1x, r1y = c.r1y, r2x = c.r2x, r2y = c.r2y, ma = c.ma, ia = c.ia, mb = c.mb, ib = c.ib;
+    const int ox = bl ? e.wo.vbx : e.wo.vx, oy = bl ? e.wo.vby : e.wo.vy, ow = bl ? e.wo.wb : e.wo.w;
+    R *wr = e.wr;
+    R vax = wr[ox + a * WorkOff::S_vx], vay = wr[oy + a * WorkOff::S_vy], wa = wr[ow + a * WorkOff::S_w];
+    R vbx = wr[ox + b * WorkOff::S_vx], vby = wr[oy + b * WorkOff::S_vy], wb = wr[ow + b * WorkOff::S_w];
+    R rx = (vbx - r2y * wb) - (vax - r1y * wa), ry = (vby + r2x * wb) - (vay + r1x * wa);
+    R vn = rx * nx + ry * ny;
+    R vrt = -rx * ny + ry * nx;                             // dot(vr, perp(n)): the velocity lane's
+    R acc_old = bl ? c.jb : c.jn;
+    R jd = bl ? (c.bias - vn) * c.n_mass : -vn * c.n_mass;  // bounce = 0 (elasticity 0 everywhere)
+    R acc_new = r_max(acc_old + jd, R(0));
+    wr[(bl ? e.wo.kjb : e.wo.kjn) + k * WorkOff::S_kjn] = acc_new;
+    static_assert(WorkOff::S_kjb == WorkOff::S_kjn, "contact record strides");
+    R jt_max = c.mu * acc_new;
+    R jt = -vrt * c.t_mass;
+    R jt_old = c.jt;
+    R jt_new = r_clamp(jt_old + jt, -jt_max, jt_max);
+    if (!bl) E_R(kjt, k) = jt_new;
+    R dn = acc_new - acc_old, dtg = jt_new - jt_old;
+    R jx = bl ? nx * dn : nx * dn - ny * dtg, jy = bl ? ny * dn : nx * dtg + ny * dn;     // cpvrotate(n, (dn, dt)) / n * dn
+    vax -= jx * ma; vay -= jy * ma; wa -= ia * (r1x * jy - r1y * jx);
+    vbx += jx * mb; vby += jy * mb; wb += ib * (r2x * jy - r2y * jx);
+    wr[ox + a * WorkOff::S_vx] = vax; wr[oy + a * WorkOff::S_vy] = vay; wr[ow + a * WorkOff::S_w] = wa;
+    wr[ox + b * WorkOff::S_vx] = vbx; wr[oy + b * WorkOff::S_vy] = vby; wr[ow + b * WorkOff::S_w] = wb;
+}
 template <typename R, typename P> MGX_HD void solve_iter_contacts(Env<R, P> &e, const SolveCtx<R> &c, int lane) {
-    if (!c.has_contacts || lane != 0) return;
+    if (!c.has_contacts || lane > (MGX_CONTACT_SPLIT ? 1 : 0)) return;
     int nk = E_I(misc, M_NK);
     if (nk == 0) return;
     ContactK<R> cur = contact_load(e, 0);
     for (int k = 0; k < nk; k++) {
         // the next contact's constants are in flight while this one's dependent chain runs
         const ContactK<R> nxt = contact_load(e, k + 1 < nk ? k + 1 : k);
-        contact_apply_loaded(e, k, cur);
+        if (MGX_CONTACT_SPLIT) contact_apply_split(e, k, cur, lane == 1); else contact_apply_loaded(e, k, cur);
         cur = nxt;
     }
 }
