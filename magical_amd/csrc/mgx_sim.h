@@ -288,9 +288,43 @@ template <typename R, typename P> MGX_HD int support_index(const Env<R, P> &e, i
     }
     return idx;
 }
+// Up to eight world vertices of a shape in registers: the loads go out back to back (one LDS round trip for the shape) and the loops
+// over them unroll with static indices -- ph_narrow's inner loops were one round trip per vertex (a pair of squares: 52 of them, now 14).
+// Slots past the shape's last vertex repeat vertex 0, which changes no minimum and wins no strict comparison.
+#ifndef MGX_NARROW_REGS
+#define MGX_NARROW_REGS 1
+#endif
+constexpr int NV_REGS = 8;
+template <typename R> struct Verts8 { R x[NV_REGS], y[NV_REGS]; };
+template <typename R, typename P> MGX_HD void load_verts8(const Env<R, P> &e, int vo, int nv, int j0, Verts8<R> &v) {
+#pragma unroll
+    for (int j = 0; j < NV_REGS; j++) { const int jj = j0 + j < nv ? j0 + j : 0; v.x[j] = E_R(wx, vo + jj); v.y[j] = E_R(wy, vo + jj); }
+}
+// min over the shape's vertices of f . v (the same products and sums, in vertex order, as the loop it replaces)
+template <typename R, typename P> MGX_HD R min_proj(const Env<R, P> &e, int vo, int nv, const Verts8<R> &v, R fx, R fy) {
+    R mn = r_inf<R>();
+#pragma unroll
+    for (int j = 0; j < NV_REGS; j++) mn = r_min(mn, fx * v.x[j] + fy * v.y[j]);
+    for (int j0 = NV_REGS; j0 < nv; j0 += NV_REGS) {       // (no shape of the benchmark suite has more than eight vertices)
+        Verts8<R> t; load_verts8(e, vo, nv, j0, t);
+#pragma unroll
+        for (int j = 0; j < NV_REGS; j++) mn = r_min(mn, fx * t.x[j] + fy * t.y[j]);
+    }
+    return mn;
+}
+template <typename R, typename P> MGX_HD int support_index_regs(const Env<R, P> &e, int vo, int nv, const Verts8<R> &v, R nx, R ny) {
+    if (nv > NV_REGS) return support_index(e, vo, nv, nx, ny);
+    R best = -r_inf<R>(); int idx = 0;
+#pragma unroll
+    for (int i = 0; i < NV_REGS; i++) {
+        R d = v.x[i] * nx + v.y[i] * ny;
+        if (d > best) { best = d; idx = i; }
+    }
+    return idx;
+}
 // cpCollision.c SupportEdgeForPoly / SupportEdgeForSegment
-template <typename R, typename P> MGX_HD EdgeRef<R> support_edge(const Env<R, P> &e, int vo, int nv, R rad, R nx, R ny) {
-    int i1 = support_index(e, vo, nv, nx, ny);
+template <typename R, typename P> MGX_HD EdgeRef<R> support_edge(const Env<R, P> &e, int vo, int nv, R rad, R nx, R ny, int i1 = -1) {
+    if (i1 < 0) i1 = support_index(e, vo, nv, nx, ny);
     int i0 = (i1 - 1 + nv) % nv, i2 = (i1 + 1) % nv;
     R d1 = nx * E_R(wnx, vo + i1) + ny * E_R(wny, vo + i1);
     R d2 = nx * E_R(wnx, vo + i2) + ny * E_R(wny, vo + i2);
@@ -353,8 +387,29 @@ template <typename R> MGX_HD R point_segment(R px, R py, R ax, R ay, R bx, R by,
 // Separated cores: the exact closest feature pair (== GJK), which matters only inside the
 // radius band of bevelled / thick shapes.
 template <typename R, typename P>
-MGX_HD bool poly_axis(const Env<R, P> &e, int voa, int na, int vob, int nb, R rsum, R &nx, R &ny, R &d) {
+MGX_HD bool poly_axis(const Env<R, P> &e, int voa, int na, int vob, int nb, R rsum, R &nx, R &ny, R &d, int &sup_a, int &sup_b) {
     R best = -r_inf<R>(); int best_i = 0; bool best_a = true;
+    sup_a = -1; sup_b = -1;
+#if MGX_NARROW_REGS
+    Verts8<R> vb;
+    load_verts8(e, vob, nb, 0, vb);
+    for (int i = 0; i < na; i++) {
+        R fx = E_R(wnx, voa + i), fy = E_R(wny, voa + i);
+        R off = fx * E_R(wx, voa + i) + fy * E_R(wy, voa + i);
+        R sep = min_proj(e, vob, nb, vb, fx, fy) - off;
+        if (sep > best) { best = sep; best_i = i; best_a = true; }
+    }
+    if (best > rsum) return false;
+    Verts8<R> va;
+    load_verts8(e, voa, na, 0, va);
+    for (int j = 0; j < nb; j++) {
+        R fx = E_R(wnx, vob + j), fy = E_R(wny, vob + j);
+        R off = fx * E_R(wx, vob + j) + fy * E_R(wy, vob + j);
+        R sep = min_proj(e, voa, na, va, fx, fy) - off;
+        if (sep > best) { best = sep; best_i = j; best_a = false; }
+    }
+    if (best > rsum) return false;
+#else
     for (int i = 0; i < na; i++) {
         R fx = E_R(wnx, voa + i), fy = E_R(wny, voa + i);
         R off = fx * E_R(wx, voa + i) + fy * E_R(wy, voa + i);
@@ -373,9 +428,13 @@ MGX_HD bool poly_axis(const Env<R, P> &e, int voa, int na, int vob, int nb, R rs
         if (sep > best) { best = sep; best_i = j; best_a = false; }
     }
     if (best > rsum) return false;
+#endif
     if (best_a) { nx = E_R(wnx, voa + best_i); ny = E_R(wny, voa + best_i); }
     else { nx = -E_R(wnx, vob + best_i); ny = -E_R(wny, vob + best_i); }
     d = best;
+#if MGX_NARROW_REGS   // the vertices the caller's two support edges start from, while both shapes are in registers
+    sup_a = support_index_regs(e, voa, na, va, nx, ny); sup_b = support_index_regs(e, vob, nb, vb, -nx, -ny);
+#endif
     if (best <= R(0)) return true;
     // separated cores inside the radius band: check the feature pair is vertex/edge, else go exact
     {
@@ -413,6 +472,7 @@ MGX_HD bool poly_axis(const Env<R, P> &e, int voa, int na, int vob, int nb, R rs
     if (dist > rsum) return false;
     R inv = R(1) / (dist + r_tiny<R>());
     nx = (pbx - pax) * inv; ny = (pby - pay) * inv; d = dist;
+    sup_a = -1; sup_b = -1;                     // (another axis: the caller looks its support vertices up)
     return true;
 }
 
@@ -478,9 +538,10 @@ template <typename R, typename P> MGX_HD void collide_pair(const Env<R, P> &e, i
         }
     } else {                                                  // SegmentToPoly / PolyToPoly
         R nx, ny, d;
-        if (poly_axis(e, voa, na, vob, nb, ra + rb, nx, ny, d)) {
-            EdgeRef<R> e1 = support_edge(e, voa, na, ra, nx, ny);
-            EdgeRef<R> e2 = support_edge(e, vob, nb, rb, -nx, -ny);
+        int sup_a, sup_b;
+        if (poly_axis(e, voa, na, vob, nb, ra + rb, nx, ny, d, sup_a, sup_b)) {
+            EdgeRef<R> e1 = support_edge(e, voa, na, ra, nx, ny, sup_a);
+            EdgeRef<R> e2 = support_edge(e, vob, nb, rb, -nx, -ny, sup_b);
             contact_points(e1, e2, nx, ny, d, m);
         }
     }
