@@ -11,4 +11,5 @@ for t in MatchRegions ClusterColour FixColour; do for v in "" $V; do
   MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip$v.so python bench.py --no-cpu-baseline --no-secondary --steps 240 --task $t-Demo-LoRes4E-v0 2>/dev/null | python -c "$P" ${t}$v
   MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip$v.so python bench.py --no-cpu-baseline --no-secondary --steps 240 --task $t-Demo-v0 2>/dev/null | python -c "$P" ${t}_state$v
 done; done
+for L in 16 32; do python bench.py --no-cpu-baseline --no-secondary --task MoveToCorner-Demo-v0 --lanes $L 2>/dev/null | python -c "$P" mtc_state_lanes$L; python bench.py --no-cpu-baseline --no-secondary --lanes $L 2>/dev/null | python -c "$P" mtc_lanes$L; done
 timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -3

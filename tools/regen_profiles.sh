@@ -87,7 +87,13 @@ if [ -f magical_amd/libmagical_hip_clocks.so ]; then
   MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so python tools/dev/fused_timeline.py 2>&1 | grep -v amdgpu > $O/${R}_fused_timeline_mtc_lores4e.txt
   MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so python tools/dev/raster_phase_clocks.py 2>&1 | grep -v amdgpu > $O/${R}_raster_phase_clocks_mtc.txt
   MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so python tools/dev/nq_stats.py 2>&1 | grep -v amdgpu > $O/${R}_raster_queue_load_by_task.txt
+  MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so python tools/dev/placement_probe.py 2>&1 | grep -v amdgpu | head -12 > $O/${R}_fused_placement_mtc_lores4e.txt
 fi
+if [ -f magical_amd/libmagical_hip_rprobe.so ]; then      # (-DMGX_RASTER_PROBE build: the rasteriser truncated after each phase, under rocprofv3 --pmc)
+  bash tools/dev/raster_phase_pmc.sh 2>&1 | grep -v amdgpu > $O/${R}_raster_phase_instructions_mtc.txt
+fi
+bash tools/dev/step_gaps.sh 2>&1 | grep -v amdgpu > $O/${R}_fused_step_gaps_mtc.txt
+cd $GRAFT_REPO_ROOT
 for t in ClusterColour-TestAll-LoRes4E-v0 MatchRegions-TestCountPlus-LoRes4E-v0; do
   timeout 300 python tools/reset_profile.py $t 2>&1 | grep -v amdgpu.ids > $O/${R}_reset_profile_$t.txt
 done
