@@ -290,13 +290,14 @@ int mgx_world_randomise_all_poses(const mgx_world *w, double *poses, const int *
 // pm_randomise_all_poses for m envs, env k in the world world_of(k): envs are independent (own stream, own poses), so
 // they are spread over a few host threads
 static int host_threads(bool allocating = true) {
-    // world building at a reset: as many threads as the host has cores, within [1, MGX_HOST_THREADS (default 32: ClusterColour-TestAll
+    // world building and placement at a reset: as many threads as the host has cores, within [1, MGX_HOST_THREADS (default 32: ClusterColour-TestAll
     // resets 41-62 ms at 16 threads, 31-48 at 32, no better at 64, worse at 128 -- the allocator)].  The placement of the entities
-    // (randomise_batch: rejection sampling, no allocation in its loop) keeps scaling: 7.4 ms at 32 threads, 5.8 at 48, 4.5 at 96
-    // (256-core host, profiles/r04_reset_threads.txt) -- MGX_PLACE_THREADS, default 96.
+    // (randomise_batch: rejection sampling) scales further on its own -- 7.4 ms at 32 threads, 5.8 at 48, 4.5 at 96 on the 256-core
+    // host -- but every extra thread that ever allocated leaves glibc another arena, and the world builders of the NEXT reset, spread
+    // over those, take 15-25 ms instead of 9 (profiles/r04_reset_threads.txt: 24 ms per reset at 32 placement threads, 26 at 48, 35 at
+    // 64 / 96).  So MGX_PLACE_THREADS is a knob that defaults to MGX_HOST_THREADS.
     static const int cap = [] { const char *v = getenv("MGX_HOST_THREADS"); const int c = v ? atoi(v) : 32; return c < 1 ? 1 : (c > 256 ? 256 : c); }();
-    static const int cap_place = [] { const char *v = getenv("MGX_PLACE_THREADS"); const char *h = getenv("MGX_HOST_THREADS");
-                                      const int c = v ? atoi(v) : (h ? atoi(h) : 96); return c < 1 ? 1 : (c > 256 ? 256 : c); }();
+    static const int cap_place = [] { const char *v = getenv("MGX_PLACE_THREADS"); const int c = v ? atoi(v) : cap; return c < 1 ? 1 : (c > 256 ? 256 : c); }();
     const int hw = (int)std::thread::hardware_concurrency(), c = allocating ? cap : cap_place;
     return hw < 1 ? 1 : (hw > c ? c : hw);
 }

@@ -305,8 +305,8 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
 #ifdef MGX_RASTER_CLOCKS
     if (t.dbg_clk && tid == 0) t.dbg_clk[blockIdx.x * 16 + 9] = clk0;        // (absolute: tools/dev/fused_timeline.py)
 #ifndef MGX_RASTER_PROBE
-    if (t.dbg_clk && (tid & 63) == 0)                                        // where each wavefront runs (tools/dev/placement_probe.py)
-        t.dbg_clk[blockIdx.x * 16 + 10 + (tid >> 6)] = __builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    if (t.dbg_clk && (tid & 63) == 0)                                        // where each wavefront runs (slots 6, 7, 8, 10; tools/dev/placement_probe.py)
+        t.dbg_clk[blockIdx.x * 16 + ((tid >> 6) < 3 ? 6 + (tid >> 6) : 10)] = __builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
 #endif
 #endif
     // the shared draw list does not depend on the env: stage it before waiting for the hand-off

@@ -35,7 +35,7 @@ print(f'CUs holding step workgroups: {len(per_cu)}; step workgroups per CU: {col
 pat = collections.Counter(tuple(sorted(collections.Counter(v).values(), reverse=True)) for v in per_cu.values())
 print('step wavefronts per SIMD within a CU (sorted counts): ', dict(pat))
 # rasteriser: SIMDs of a workgroup's four wavefronts
-rw = c[:, 10:14]
+rw = c[:, [6, 7, 8, 10]]
 simds = (rw >> 4) & 3
 print('distinct SIMDs among a rasteriser workgroup\'s 4 wavefronts:', dict(collections.Counter(len(set(r.tolist())) for r in simds)))
 start = (c[:, 9] - t0) / 100.0; end = start + c[:, 4] / 100.0
