@@ -14,21 +14,23 @@ _SRCS = [os.path.join(_HERE, 'mgx_emu.cpp')] + [
 MODES = {'f32': 0, 'mixed': 1, 'f64': 2}
 
 
-def build():
+def build(defines=()):
+    """The emulation library; `defines` (e.g. ('MGX_CONTACT_SPLIT=0',)) builds a variant of the phase code beside it."""
+    so = _SO if not defines else _SO.replace('.so', '_' + '_'.join(d.replace('=', '') for d in defines) + '.so')
     newest = max(os.path.getmtime(p) for p in _SRCS)
-    if not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
-        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-ffp-contract=off', '-DMGX_RASTER_STATS', '-shared', '-o', _SO,
-                               _SRCS[0], _SRCS[1]])
-    return _SO
+    if not os.path.exists(so) or os.path.getmtime(so) < newest:
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-ffp-contract=off', '-DMGX_RASTER_STATS', '-shared', '-o', so,
+                               _SRCS[0], _SRCS[1]] + ['-D' + d for d in defines])
+    return so
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        L = C.CDLL(build())
+def lib(defines=()):
+    defines = tuple(defines)
+    if defines not in _libs:
+        L = C.CDLL(build(defines))
         L.emu_world_new.restype = C.c_void_p
         for name, args in {
             'emu_free': [C.c_void_p], 'emu_add_robot': [C.c_void_p] + [C.c_double] * 3,
@@ -43,15 +45,15 @@ def lib():
                         C.c_int, C.c_void_p],
         }.items():
             getattr(L, name).argtypes = args
-        _lib = L
-    return _lib
+        _libs[defines] = L
+    return _libs[defines]
 
 
 class EmuBatch:
     """N envs of one world stepped by the emulated kernel phases."""
 
-    def __init__(self, entities, max_steps, n_envs, mode='mixed'):
-        L = lib()
+    def __init__(self, entities, max_steps, n_envs, mode='mixed', defines=()):
+        L = lib(defines)
         self.L, self.mode, self.n = L, MODES[mode], n_envs
         self.h = L.emu_world_new()
         for ent in entities:

@@ -195,3 +195,31 @@ def test_shipped_precision_drift_within_perturbation_envelope(task):
             v1 = np.median([masked_err(r.bodies()[orc.idx][:, :3], want[k], orc.mask) for k, r in enumerate(vround)])
             assert m <= 10 * v1, (task, m, v1)
     assert int(em.si[2].sum()) == 0
+
+
+@pytest.mark.parametrize('mode', ['mixed', 'f64'])
+@pytest.mark.parametrize('task', ['MoveToCorner', 'MatchRegions', 'ClusterColour'])
+def test_contact_split_and_register_narrowphase_change_no_bit(task, mode):
+    """k_step's two round-4 restructurings are claimed to evaluate the expressions they replace, in their order: the contact point's
+    velocity and bias chains on two lanes (MGX_CONTACT_SPLIT) and the SAT loops on a shape's vertices in registers (MGX_NARROW_REGS).
+    With contraction off (the emulation's build) the phase code with and without them must then produce the SAME BITS: 16 envs, 60
+    env-steps of driving into things, every persistent state row compared."""
+    ref = new_ref(task)
+    ents = ref_entities_as_tuples(ref)
+    rng = np.random.RandomState(zlib.crc32(task.encode()) % 1000)
+    tape = rng.randint(0, 18, size=(60, 16)).astype(np.int32)
+    tape[::3] = 1                                           # forward: contacts with blocks and walls
+    runs = []
+    for defines in ((), ('MGX_CONTACT_SPLIT=0',), ('MGX_NARROW_REGS=0',), ('MGX_CONTACT_SPLIT=0', 'MGX_NARROW_REGS=0')):
+        em = EmuBatch(ents, ref.max_episode_steps, 16, mode=mode, defines=defines)
+        em.reset()
+        touched = 0
+        for t in range(60):
+            em.run(tape[t])
+            touched += len(em.contacts())
+        runs.append((em.sp.copy(), em.sf.copy(), em.si.copy(), touched))
+    assert runs[0][3] > 50, 'the tape must produce contacts'
+    for other in runs[1:]:
+        assert other[3] == runs[0][3]
+        for a, b in zip(runs[0][:3], other[:3]):
+            assert a.tobytes() == b.tobytes()
