@@ -265,6 +265,10 @@ def measure(args, rank, world, device):
             env.set_episode_steps(clocks)
         obs, rew, done, info = env.step(tape[s])
     tape = tape[preroll:]
+    # the collective's first use (RCCL creates its communicator, proxy thread and buffers there) comes BEFORE the warm-up steps: straight
+    # before the timed region it left the first steps of the window 0.3 ms slower (stamps: MGX_BENCH_STAMPS=1)
+    gather_rollout_results(last_score, n * world)
+    torch.cuda.synchronize()
     for s in range(W):
         obs, rew, done, info = env.step(tape[s])
 
@@ -273,8 +277,8 @@ def measure(args, rank, world, device):
             dist.barrier()
         torch.cuda.synchronize()
 
-    every = int(os.environ.get('MGX_BENCH_TIMING_EVERY', '0')) or (8 if K >= 160 else 2)
-    env.set_timing(every)       # HIP events around every 8th (short windows: every 2nd) launch of each kernel inside the timed region
+    every = int(os.environ.get('MGX_BENCH_TIMING_EVERY', '0')) or (8 if K >= 160 else 4)
+    env.set_timing(every)       # HIP events around every 8th (short windows: every 4th) launch of each kernel inside the timed region
     last_score.zero_()
     # scores are collected on the host -- in PINNED memory, so that the one upload before the gather is asynchronous: the host, which
     # runs a few steps ahead of the GPU, goes straight on into the collective call (c10d's ≈ 0.3 ms of host work) while the GPU is
@@ -291,14 +295,19 @@ def measure(args, rank, world, device):
         if done.any():
             n_eps += int(done.sum())
             score_host[done] = info['eval_score'][done]
+    t_loop = time.perf_counter()
     last_score.copy_(score_pin, non_blocking=True)
     # end-of-rollout gather over xGMI (RCCL): per-env scores of every rank; observations never leave their GPU
     ev_g0, ev_g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # (device-side clock: no host sync before the collective)
     ev_g0.record()
     all_scores = gather_rollout_results(last_score, n * world)
     ev_g1.record()
+    t_call = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get('MGX_BENCH_STAMPS'):      # development: where the host was when (stderr)
+        print('stamps: host step loop %.2f ms, upload + collective calls %.3f ms, final synchronize %.2f ms' % (
+            (t_loop - t0) * 1e3, (t_call - t_loop) * 1e3, (t0 + elapsed - t_call) * 1e3), file=sys.stderr)
     gather_ms = ev_g0.elapsed_time(ev_g1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
