@@ -265,6 +265,80 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
     }
 }
 
+// Phase C's form: NT tiles per lane (144 tiles = 48 lanes x 3), so that every wavefront sees the whole tile grid and the ITEM LIST can be
+// dealt out over the workgroup's four wavefronts instead (mgx_raster_body.inc).  Per item three broadcasts + (2 FMA + 1 min) per tile.
+// Same arithmetic per tile as classify_items_regs<true>; consumes items [0, n) of `src`, which never end inside a convex part.
+template <int NT>
+__device__ __forceinline__ void classify_items_regs_tiles(const Raster &rs, const RegItems &src, int n, const float (&xc)[NT], const float (&yc)[NT],
+                                                          ClassState (&st)[NT], bool active) {
+    auto bc = [&](float v, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); };
+    const float hx = TILE_HX, hy = TILE_HY;
+    int i = 0;
+    while (i < n) {
+        const int meta = __builtin_amdgcn_readlane(src.my.meta, i);
+        const int kind = meta & 3, rem = (meta >> IT_REM_SHIFT) & IT_REM_MASK, k = meta >> IT_K_SHIFT;
+        const int run = rem < n - i ? rem : n - i;
+        const int rgb = rs.prim_rgb(k);
+        float lo[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) lo[t] = st[t].lo;
+        if (kind == IT_EDGE) {
+            for (int j = i; j < i + run; j++) {
+                const float a = bc(src.my.a, j), b = bc(src.my.b, j), c = bc(src.my.c, j), g3 = bc(src.my.g3, j);
+#pragma unroll
+                for (int t = 0; t < NT; t++) lo[t] = raw_min(lo[t], __builtin_fmaf(a, xc[t], __builtin_fmaf(b, yc[t], c)) * g3);
+            }
+        } else if (kind == IT_NGON) {
+            const float ca = bc(src.my.a, i), cb = bc(src.my.b, i);
+            const float apo = bc(src.my.c, i) - CLASS_EPS_F, rad = bc(src.my.g0, i) + CLASS_EPS_F;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const float qx = r_abs(xc[t] - ca), qy = r_abs(yc[t] - cb);
+                const float nx = r_max(qx - hx, 0.0f), ny = r_max(qy - hy, 0.0f);
+                const float fx = qx + hx, fy = qy + hy;
+                const float l = rad * rad - (nx * nx + ny * ny);
+                const float h = apo > 0.0f ? apo * apo - (fx * fx + fy * fy) : -1.0f;
+                lo[t] = l < 0.0f ? -2.0f : (h > 0.0f ? 2.0f : 0.0f);
+            }
+        } else {
+            for (int j = i; j < i + run; j++) {
+                const float a = bc(src.my.a, j), b = bc(src.my.b, j);
+                const float hw = bc(src.my.g3, j) + CLASS_EPS_F;
+                const float c = bc(src.my.c, j), g0 = bc(src.my.g0, j), g1 = bc(src.my.g1, j), g2 = bc(src.my.g2, j);
+                const float el = hx * r_abs(a) + hy * r_abs(b), es = hx * r_abs(b) + hy * r_abs(a);
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const float e = a * xc[t] + (b * yc[t] + c);
+                    const float sl = (xc[t] - g0) * b - (yc[t] - g1) * a;
+                    const float tt = r_min(r_min(hw + el - r_abs(e), sl + es + hw), g2 + hw + es - sl);
+                    lo[t] = lo[t] >= BIG_F ? tt : r_max(lo[t], tt);
+                }
+            }
+        }
+        i += run;
+        if (run == rem) {
+            bool all_decided = true;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const bool open = !st[t].decided;
+                const bool touch = kind == IT_SEG ? lo[t] >= 0.0f : !(lo[t] < -1.0f);
+                const bool all = kind != IT_SEG && lo[t] > 1.0f;
+                const bool mix = open && touch && !all, cover = open && touch && all;
+                const uint64_t bit = 1ull << k;
+                st[t].mixed |= mix ? bit : 0ull;
+                st[t].base = cover ? rgb : st[t].base;
+                st[t].decided |= cover ? 1 : 0;
+                st[t].lo = BIG_F;
+                all_decided = all_decided && st[t].decided;
+            }
+            if (__all(all_decided || !active)) break;
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; t++) st[t].lo = lo[t];
+        }
+    }
+}
+
 template <typename P, int LAYOUT, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
                                                 long env_stride, int view, const uint8_t *__restrict__ fill_mask, int n_envs, RasterHandoff ho) {
