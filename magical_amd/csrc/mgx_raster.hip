@@ -419,7 +419,10 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
 #ifndef MGX_T_DYNAMIC
 #define MGX_T_DYNAMIC 1
 #endif
-    constexpr bool SCALAR_WAVE = WAVES < 5, T_UNIFORM_FAST = WAVES >= 5, E_SPLIT = WAVES < 5, T_DYNAMIC = MGX_T_DYNAMIC;
+#ifndef MGX_Q_DYNAMIC
+#define MGX_Q_DYNAMIC 1
+#endif
+    constexpr bool SCALAR_WAVE = WAVES < 5, T_UNIFORM_FAST = WAVES >= 5, E_SPLIT = WAVES < 5, T_DYNAMIC = MGX_T_DYNAMIC, Q_DYNAMIC = MGX_Q_DYNAMIC;
 #include "mgx_raster_body.inc"
 #undef CLK
 }
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256, 3) void k_raster_deferred(RasterDev t, const P
     const long env = (long)(ho.queue[blockIdx.x] & 0xFFFFFFFFull);         // written by a kernel that has completed
     const uint8_t *fill_mask = nullptr;
     if (!t.tmpl_stride_words) { const int n = raster_staged_words(t, t.words); for (int i = tid; i < n; i += 256) lds[i] = t.words[i]; }
-    constexpr bool SCALAR_WAVE = true, T_UNIFORM_FAST = false, E_SPLIT = false, T_DYNAMIC = false;
+    constexpr bool SCALAR_WAVE = true, T_UNIFORM_FAST = false, E_SPLIT = false, T_DYNAMIC = false, Q_DYNAMIC = false;
 #include "mgx_raster_body.inc"
 #undef CLK
 }
