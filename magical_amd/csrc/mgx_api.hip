@@ -422,7 +422,8 @@ static const int HDR_WORDS = even((int)sizeof(TmplHeader) / 4);
 // serialise a world into the two device blobs (host side) for the engine's precision
 template <typename R, typename P>
 static void make_blobs_t(const World &w, WorldBlobs &b) {
-    std::vector<int32_t> iw; std::vector<double> rw, pw;
+    // (the serialiser's buffers keep their capacity from world to world: a reset serialises thousands of worlds per thread)
+    static thread_local std::vector<int32_t> iw, ir; static thread_local std::vector<double> rw, pw;
     {
         TmplHeader hs;
         w.serialise(hs, iw, rw, pw, /*strip_prims=*/true);
@@ -448,7 +449,7 @@ static void make_blobs_t(const World &w, WorldBlobs &b) {
         hr.n_shapes = hr.n_verts = hr.n_joints = hr.n_pairs = hr.n_state = hr.n_islands = 0;
         TmplOff orr(hr);
         hr.n_words_i = orr.n_i;
-        std::vector<int32_t> ir(orr.n_i, 0);
+        ir.assign(orr.n_i, 0);
         auto keep = [&](int from, int to, int n) { std::memcpy(ir.data() + to, iw.data() + from, (size_t)n * 4); };
         keep(o.body_type, orr.body_type, b.h.n_bodies); keep(o.body_parent, orr.body_parent, b.h.n_bodies); keep(o.body_ent, orr.body_ent, b.h.n_bodies);
         keep(o.prim_i, orr.prim_i, b.h.n_prims * PRIM_IWORDS); keep(o.pv_prim, orr.pv_prim, b.h.n_pverts); keep(o.body_prow, orr.body_prow, 3 * b.h.n_bodies);
@@ -1130,7 +1131,11 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     const int ne = (int)e->w.entities.size();
     for (int k = 0; k < m; k++) if (env_idx[k] < 0 || env_idx[k] >= e->n_envs) return fail(MGX_ERR_ARG, "env index out of range");
     // unique signatures of this call; worlds that are still alive are reused
-    struct Uniq { std::string sig; int first; std::shared_ptr<World> world; WorldBlobs blobs; std::string err; int rc = 0; };
+    // (a world's two blobs are serialised into buffers of the building thread and copied straight into the pinned staging buffer, at an
+    // offset the thread reserves with one atomic add: what a Uniq keeps of them is sizes and offsets -- round 3 kept 160 MB of blob
+    // vectors per reset of 4096 Cluster worlds alive until a second, packing pass had copied them)
+    struct BlobMeta { TmplHeader h; int step_words = 0, raster_words = 0, step_env_stride = 0, raster_lds_words = 0, raster_scratch_d = 0, raster_scratch_dc = 0, raster_n_i = 0; int32_t off_s = 0, off_r = 0; };
+    struct Uniq { std::string sig; int first; std::shared_ptr<World> world; BlobMeta blobs; std::string err; int rc = 0; };
     std::vector<Uniq> uniq;
     std::unordered_map<std::string, int> index;
     std::vector<int> which(m);
@@ -1152,21 +1157,45 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         which[k] = it->second;
     }
     tm[ti++] = now();
+    // the staging buffer holds every distinct world's blobs back to back; no blob is larger than the capacity world's
+    const size_t stage_bound = uniq.size() * ((size_t)e->step_stride + (size_t)e->raster_stride);
+    if (stage_bound > 0x7fffffffull) return fail(MGX_ERR_CAPACITY, "too many distinct worlds in one call");
+    // (pinned staging: a pageable copy of this size -- 160 MB for 4096 distinct Cluster worlds -- would dominate the reset)
+    if (e->h_stage_words < stage_bound) {
+        if (e->h_stage) (void)hipHostFree(e->h_stage);
+        e->h_stage = nullptr; e->h_stage_words = 0;
+        HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&e->h_stage), stage_bound * 4 + 4096, hipHostMallocDefault));
+        e->h_stage_words = stage_bound + 1024;
+    }
+    uint32_t *host = e->h_stage;
+    std::atomic<size_t> cursor{0};
     // build what is missing and serialise everything, a few host threads wide
     int n_threads = host_threads();
     if (uniq.size() < 8) n_threads = 1;
-    auto work = [&](int t) {
-        for (size_t u = t; u < uniq.size(); u += n_threads) {
+    std::atomic<size_t> next_u{0};
+    auto work = [&](int) {
+        static thread_local WorldBlobs tb;
+        static thread_local std::vector<uint8_t> en; static thread_local std::vector<int> st;
+        for (size_t u0 = next_u.fetch_add(4); u0 < uniq.size(); u0 = next_u.fetch_add(4))
+        for (size_t u = u0; u < u0 + 4 && u < uniq.size(); u++) {
             Uniq &U = uniq[u];
             if (!U.world) {
-                std::vector<uint8_t> en(ne); std::vector<int> st(ne);
+                en.resize(ne); st.resize(ne);
                 for (int i = 0; i < ne; i++) { en[i] = (uint8_t)U.sig[i]; st[i] = (int)U.sig[ne + i] - 1; }
                 auto w = std::make_shared<World>();
                 U.rc = e->w.variant(en.data(), st.data(), *w, U.err);
                 if (U.rc) continue;
                 U.world = std::move(w);
             }
-            make_blobs(e->dtype, *U.world, U.blobs);
+            make_blobs(e->dtype, *U.world, tb);
+            BlobMeta &B = U.blobs;
+            B.h = tb.h; B.step_words = (int)tb.step.size(); B.raster_words = (int)tb.raster.size(); B.step_env_stride = tb.step_env_stride;
+            B.raster_lds_words = tb.raster_lds_words; B.raster_scratch_d = tb.raster_scratch_d; B.raster_scratch_dc = tb.raster_scratch_dc; B.raster_n_i = tb.raster_n_i;
+            if (B.step_words > e->step_stride || B.raster_words > e->raster_stride) { U.rc = -2; U.err = "world variant larger than the capacity world"; continue; }
+            const size_t off = cursor.fetch_add((size_t)B.step_words + (size_t)B.raster_words);
+            B.off_s = (int32_t)off; B.off_r = (int32_t)(off + B.step_words);
+            std::memcpy(host + B.off_s, tb.step.data(), (size_t)B.step_words * 4);
+            std::memcpy(host + B.off_r, tb.raster.data(), (size_t)B.raster_words * 4);
         }
     };
     if (n_threads == 1) work(0);
@@ -1178,47 +1207,18 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     tm[ti++] = now();
     for (auto &U : uniq) {
         if (U.rc) return fail(U.rc == -2 ? MGX_ERR_CAPACITY : MGX_ERR_ARG, U.err);
-        if ((int)U.blobs.step.size() > e->step_stride || (int)U.blobs.raster.size() > e->raster_stride ||
-            U.blobs.h.n_prims > 64)
-            return fail(MGX_ERR_CAPACITY, "world variant larger than the capacity world");
+        if (U.blobs.h.n_prims > 64) return fail(MGX_ERR_CAPACITY, "world variant larger than the capacity world");
         if (state_rows_p(U.blobs.h) > e->rows_p || state_rows_f(U.blobs.h) > e->rows_f || state_rows_i(U.blobs.h) > e->rows_i)
             return fail(MGX_ERR_CAPACITY, "world variant needs more state rows than the capacity world");
     }
-    // upload: the distinct blobs once, packed back to back, then one device-side copy per env into its table slot
-    std::vector<int32_t> off_s(uniq.size()), off_r(uniq.size());
-    size_t total = 0;
-    for (size_t u = 0; u < uniq.size(); u++) {
-        off_s[u] = (int32_t)total; total += uniq[u].blobs.step.size();
-        off_r[u] = (int32_t)total; total += uniq[u].blobs.raster.size();
-        if (total > 0x7fffffffull) return fail(MGX_ERR_CAPACITY, "too many distinct worlds in one call");
-    }
-    // (pinned staging: a pageable copy of this size -- 160 MB for 4096 distinct Cluster worlds -- would dominate the reset)
-    if (e->h_stage_words < total) {
-        if (e->h_stage) (void)hipHostFree(e->h_stage);
-        e->h_stage = nullptr; e->h_stage_words = 0;
-        HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&e->h_stage), total * 4 + 4096, hipHostMallocDefault));
-        e->h_stage_words = total + 1024;
-    }
-    uint32_t *host = e->h_stage;
-    auto pack = [&](int t) {
-        for (size_t u = t; u < uniq.size(); u += n_threads) {
-            std::memcpy(host + off_s[u], uniq[u].blobs.step.data(), uniq[u].blobs.step.size() * 4);
-            std::memcpy(host + off_r[u], uniq[u].blobs.raster.data(), uniq[u].blobs.raster.size() * 4);
-        }
-    };
-    if (n_threads == 1) pack(0);
-    else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; t++) pool.emplace_back(pack, t);
-        for (auto &th : pool) th.join();
-    }
+    const size_t total = cursor.load();
     tm[ti++] = now();
     // per env: destination env, source offsets and sizes of its two blobs
     std::vector<int32_t> rows((size_t)5 * m);
     for (int k = 0; k < m; k++) {
         const int u = which[k];
-        rows[5 * k] = env_idx[k]; rows[5 * k + 1] = off_s[u]; rows[5 * k + 2] = (int32_t)uniq[u].blobs.step.size();
-        rows[5 * k + 3] = off_r[u]; rows[5 * k + 4] = (int32_t)uniq[u].blobs.raster.size();
+        rows[5 * k] = env_idx[k]; rows[5 * k + 1] = uniq[u].blobs.off_s; rows[5 * k + 2] = uniq[u].blobs.step_words;
+        rows[5 * k + 3] = uniq[u].blobs.off_r; rows[5 * k + 4] = uniq[u].blobs.raster_words;
     }
     if (e->stage_words < total) {
         if (e->d_stage) (void)hipFree(e->d_stage);
@@ -1256,11 +1256,11 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     std::vector<std::shared_ptr<World>> retired(m);      // the envs' previous worlds: freed below, a few threads wide
     for (int k = 0; k < m; k++) {
         const int env = env_idx[k];
-        const WorldBlobs &B = uniq[which[k]].blobs;
+        const BlobMeta &B = uniq[which[k]].blobs;
         retired[k] = std::move(e->env_world[env]);
         e->env_world[env] = uniq[which[k]].world;
-        e->fp_step_words[env] = (int)B.step.size(); e->fp_env_stride[env] = B.step_env_stride;
-        e->fp_raster_words[env] = B.raster_lds_words; e->fp_raster_full[env] = (int)B.raster.size(); e->fp_scratch_d[env] = B.raster_scratch_d; e->fp_scratch_dc[env] = B.raster_scratch_dc; e->fp_raster_n_i[env] = B.raster_n_i;
+        e->fp_step_words[env] = B.step_words; e->fp_env_stride[env] = B.step_env_stride;
+        e->fp_raster_words[env] = B.raster_lds_words; e->fp_raster_full[env] = B.raster_words; e->fp_scratch_d[env] = B.raster_scratch_d; e->fp_scratch_dc[env] = B.raster_scratch_dc; e->fp_raster_n_i[env] = B.raster_n_i;
     }
     {
         auto mx = [](const std::vector<int> &v) { return *std::max_element(v.begin(), v.end()); };

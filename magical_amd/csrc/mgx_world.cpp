@@ -113,7 +113,29 @@ int palette_rgb(int colour, int role) {
 
 // ---------------------------------------------------------------- placement queries (host only)
 namespace {
-struct WShape { int kind; double r; std::vector<Vec2> v; int group; };   // world-space: circle centre / polygon verts / segment ends
+// (fixed capacity, no allocation: a reset with per-env worlds runs millions of these queries)
+constexpr int WS_MAXV = 16, WS_MAXS = 8;          // vertices per shape (finalize() checks), shapes per entity (robot 5, star 6)
+struct VList {
+    Vec2 d[WS_MAXV]; int n = 0;
+    size_t size() const { return (size_t)n; }
+    const Vec2 &operator[](size_t i) const { return d[i]; }
+    const Vec2 *begin() const { return d; }
+    const Vec2 *end() const { return d + n; }
+    void push_back(Vec2 p) { d[n++] = p; }
+};
+struct WShape {       // world-space: circle centre / polygon verts / segment ends, and the box around it (radius included)
+    int kind; double r; VList v; int group; double lox, loy, hix, hiy;
+    void bound() {
+        lox = loy = 1e300; hix = hiy = -1e300;
+        for (auto &p : v) { lox = std::min(lox, p.x); hix = std::max(hix, p.x); loy = std::min(loy, p.y); hiy = std::max(hiy, p.y); }
+        lox -= r; loy -= r; hix += r; hiy += r;
+    }
+};
+// shapes whose boxes are further apart than round-off could explain cannot touch (cpCollide needs distance <= r_a + r_b)
+inline bool boxes_apart(const WShape &a, const WShape &b) {
+    const double s = 1e-9;
+    return a.lox > b.hix + s || b.lox > a.hix + s || a.loy > b.hiy + s || b.loy > a.hiy + s;
+}
 
 double pt_seg_dist2(Vec2 p, Vec2 a, Vec2 b) {
     double dx = b.x - a.x, dy = b.y - a.y, l2 = dx * dx + dy * dy;
@@ -123,7 +145,7 @@ double pt_seg_dist2(Vec2 p, Vec2 a, Vec2 b) {
     return qx * qx + qy * qy;
 }
 // signed distance of a point to a convex CCW polygon (negative inside)
-double pt_poly_dist(Vec2 p, const std::vector<Vec2> &v) {
+double pt_poly_dist(Vec2 p, const VList &v) {
     bool inside = true; double best = 1e300; size_t n = v.size();
     for (size_t i = 0; i < n; i++) {
         Vec2 a = v[i], b = v[(i + 1) % n];
@@ -135,8 +157,8 @@ double pt_poly_dist(Vec2 p, const std::vector<Vec2> &v) {
     return inside ? -std::sqrt(best) : std::sqrt(best);
 }
 // distance between two convex CCW polygons: negative when they overlap, else the exact gap
-double poly_poly_dist(const std::vector<Vec2> &A, const std::vector<Vec2> &B) {
-    auto separated = [](const std::vector<Vec2> &P, const std::vector<Vec2> &Q) {
+double poly_poly_dist(const VList &A, const VList &B) {
+    auto separated = [](const VList &P, const VList &Q) {
         size_t n = P.size();
         for (size_t i = 0; i < n; i++) {
             Vec2 a = P[i], b = P[(i + 1) % n];
@@ -172,43 +194,63 @@ bool shapes_touch(const WShape &a, const WShape &b) {
     if (a.kind == SH_POLY && b.kind == SH_POLY) return poly_poly_dist(a.v, b.v) - rr <= 0.0;
     return false;   // segment-segment: both static
 }
+// world-space shapes of entity e of world W with the entity at (x, y, a) (bodies follow the entity rigidly, as in finalize());
+// hw: this env's (h, w) of a goal region, or NULL.  Returns how many (<= WS_MAXS)
+int world_shapes_of(const World &W, int e, double x, double y, double a, const double *hw_of_e, WShape *out) {
+    const EntityDef &E = W.entities[e];
+    if (!E.enabled) return 0;
+    if (E.kind == 2) {                      // goal sensor: box (w, h) around its centre, never rotated
+        double hw = (hw_of_e ? hw_of_e[1] : E.w) / 2, hh = (hw_of_e ? hw_of_e[0] : E.h) / 2;
+        WShape &G = out[0];
+        G.kind = SH_POLY; G.r = 0.0; G.group = 0; G.v.n = 0;
+        G.v.push_back({x - hw, y - hh}); G.v.push_back({x + hw, y - hh}); G.v.push_back({x + hw, y + hh}); G.v.push_back({x - hw, y + hh});
+        G.bound();
+        return 1;
+    }
+    int n = 0;
+    for (int si : E.shapes) {
+        if (n == WS_MAXS) break;
+        const ShapeDef &S = W.shapes[si];
+        const BodyDef &B = W.bodies[S.body];
+        double bx = x, by = y, ba = a + B.aoff;
+        if (B.parent >= 0) { Vec2 r = rot({B.ax, B.ay}, a + W.bodies[B.parent].aoff); bx = x + r.x; by = y + r.y; }
+        WShape &O = out[n++];
+        O.kind = S.kind; O.r = S.radius; O.group = S.group; O.v.n = 0;
+        if (S.kind == SH_CIRCLE) O.v.push_back({bx, by});
+        else for (auto &lv : S.verts) { Vec2 r = rot(lv, ba); O.v.push_back({bx + r.x, by + r.y}); }
+        O.bound();
+    }
+    return n;
+}
+int wall_shapes_of(const World &W, WShape *out) {
+    int n = 0;
+    for (const ShapeDef &S : W.shapes) if (S.kind == SH_SEGMENT && n < WS_MAXS) {
+        WShape &O = out[n++];
+        O.kind = SH_SEGMENT; O.r = S.radius; O.group = 0; O.v.n = 0;
+        for (auto &p : S.verts) O.v.push_back(p);
+        O.bound();
+    }
+    return n;
+}
+inline bool any_touch(const WShape *A, int na, const WShape *B, int nb, bool groups) {
+    for (int i = 0; i < na; i++) for (int j = 0; j < nb; j++) {
+        if (groups && A[i].group != 0 && A[i].group == B[j].group) continue;       // ShapeFilter groups (cpShapeFilterReject)
+        if (boxes_apart(A[i], B[j])) continue;
+        if (shapes_touch(A[i], B[j])) return true;
+    }
+    return false;
+}
 }  // namespace
 
 bool World::placement_collides(int ent, const double *poses, const uint8_t *enabled, const double *ent_hw) const {
-    // world-space shapes of entity e at its pose (bodies follow the entity rigidly, as in finalize())
-    auto shapes_of = [&](int e, std::vector<WShape> &out) {
-        const EntityDef &E = entities[e];
-        if (!E.enabled) return;
-        double x = poses[3 * e], y = poses[3 * e + 1], a = poses[3 * e + 2];
-        if (E.kind == 2) {                      // goal sensor: box (w, h) around its centre, never rotated
-            double hw = (ent_hw ? ent_hw[2 * e + 1] : E.w) / 2, hh = (ent_hw ? ent_hw[2 * e] : E.h) / 2;
-            out.push_back({SH_POLY, 0.0, {{x - hw, y - hh}, {x + hw, y - hh}, {x + hw, y + hh}, {x - hw, y + hh}}, 0});
-            return;
-        }
-        for (const ShapeDef &S : shapes) {
-            if (S.entity != e) continue;
-            const BodyDef &B = bodies[S.body];
-            double bx = x, by = y, ba = a + B.aoff;
-            if (B.parent >= 0) { Vec2 r = rot({B.ax, B.ay}, a + bodies[B.parent].aoff); bx = x + r.x; by = y + r.y; }
-            WShape W{S.kind, S.radius, {}, S.group};
-            if (S.kind == SH_CIRCLE) W.v.push_back({bx, by});
-            else for (auto &lv : S.verts) { Vec2 r = rot(lv, ba); W.v.push_back({bx + r.x, by + r.y}); }
-            out.push_back(W);
-        }
-    };
-    std::vector<WShape> mine;
-    shapes_of(ent, mine);
-    std::vector<WShape> walls;
-    for (const ShapeDef &S : shapes) if (S.kind == SH_SEGMENT) walls.push_back({SH_SEGMENT, S.radius, S.verts, 0});
-    for (auto &m : mine) for (auto &wl : walls) if (shapes_touch(m, wl)) return true;
+    WShape mine[WS_MAXS], walls[WS_MAXS], theirs[WS_MAXS];
+    const int n_mine = world_shapes_of(*this, ent, poses[3 * ent], poses[3 * ent + 1], poses[3 * ent + 2], ent_hw ? ent_hw + 2 * ent : nullptr, mine);
+    const int n_walls = wall_shapes_of(*this, walls);
+    if (any_touch(mine, n_mine, walls, n_walls, false)) return true;
     for (int e = 0; e < (int)entities.size(); e++) {
         if (e == ent || !enabled[e]) continue;
-        std::vector<WShape> theirs;
-        shapes_of(e, theirs);
-        for (auto &m : mine) for (auto &t : theirs) {
-            if (m.group != 0 && m.group == t.group) continue;       // ShapeFilter groups (cpShapeFilterReject)
-            if (shapes_touch(m, t)) return true;
-        }
+        const int n_theirs = world_shapes_of(*this, e, poses[3 * e], poses[3 * e + 1], poses[3 * e + 2], ent_hw ? ent_hw + 2 * e : nullptr, theirs);
+        if (any_touch(mine, n_mine, theirs, n_theirs, true)) return true;
     }
     return false;
 }
@@ -272,9 +314,17 @@ int World::randomise_all_poses(double *poses, const int *ents, int n, const uint
     Mt19937 rng{mt_key, mt_pos};
     const int ne = (int)entities.size(), max_retries = 10, max_tries = 10000;
     int rejected = 0;
+    // World-space shapes of the entities that stay where they are during an attempt: worked out when an entity is first asked
+    // about (the ones this call does not move) or when its pose is accepted (the ones it does), not once per attempt -- only the
+    // entity being placed moves between attempts.  Same tests on the same numbers as placement_collides(), so the same draws.
+    static thread_local std::vector<WShape> held; static thread_local std::vector<int> n_held; static thread_local std::vector<uint8_t> enabled;
+    held.resize((size_t)ne * WS_MAXS); n_held.assign(ne, -1);
+    WShape walls[WS_MAXS], mine[WS_MAXS];
+    const int n_walls = wall_shapes_of(*this, walls);
+    auto hw_of = [&](int e) { return ent_hw ? ent_hw + 2 * e : nullptr; };
     for (int retry = 0; retry < max_retries; retry++) {
-        std::vector<uint8_t> enabled(ne, 1);
-        for (int i = 0; i < n; i++) enabled[ents[i]] = 0;                 // categories = 0 until its turn
+        enabled.assign(ne, 1);
+        for (int i = 0; i < n; i++) { enabled[ents[i]] = 0; n_held[ents[i]] = -1; }       // categories = 0 until its turn
         for (int e = 0; e < ne; e++) if (ignore && ignore[e]) enabled[e] = 0;
         bool failed = false;
         for (int i = 0; i < n && !failed; i++) {
@@ -289,16 +339,26 @@ int World::randomise_all_poses(double *poses, const int *ents, int n, const uint
                 y0 = std::max(arena[2], oy - pos_limits[i]); y1 = std::min(arena[3], oy + pos_limits[i]);
             }
             if (rot_limits[i] >= 0) { r0 = oa - rot_limits[i]; r1 = oa + rot_limits[i]; }
-            int n_tries = 0;
+            int n_tries = 0, n_mine = 0;
             for (; n_tries < max_tries; n_tries++) {
                 if (rand_pos[i]) { poses[3 * e] = rng.uniform(x0, x1); poses[3 * e + 1] = rng.uniform(y0, y1); }
                 if (rand_rot[i]) poses[3 * e + 2] = rng.uniform(r0, r1);
-                if (!placement_collides(e, poses, enabled.data(), ent_hw)) break;
+                n_mine = world_shapes_of(*this, e, poses[3 * e], poses[3 * e + 1], poses[3 * e + 2], hw_of(e), mine);
+                bool hit = any_touch(mine, n_mine, walls, n_walls, false);
+                for (int o = 0; o < ne && !hit; o++) {
+                    if (o == e || !enabled[o]) continue;
+                    if (n_held[o] < 0) n_held[o] = world_shapes_of(*this, o, poses[3 * o], poses[3 * o + 1], poses[3 * o + 2], hw_of(o), &held[(size_t)o * WS_MAXS]);
+                    hit = any_touch(mine, n_mine, &held[(size_t)o * WS_MAXS], n_held[o], true);
+                }
+                if (!hit) break;
             }
             rejected += n_tries;
             if (n_tries == max_tries) {                                    // PlacementError: put it back, start over
                 poses[3 * e] = ox; poses[3 * e + 1] = oy; poses[3 * e + 2] = oa;
                 failed = true;
+            } else {
+                for (int k = 0; k < n_mine; k++) held[(size_t)e * WS_MAXS + k] = mine[k];
+                n_held[e] = n_mine;
             }
         }
         if (!failed) return rejected;
@@ -310,6 +370,11 @@ int World::finalize(int max_steps, std::string &err) {
     if (finalized) { err = "world already finalized"; return -3; }
     max_episode_steps = max_steps;
     const double *pv = phys_vars;
+    {   // (no regrowth of the tables while they fill: a reset with per-env worlds finalizes thousands of worlds)
+        const size_t n = entities.size();
+        bodies.reserve(8 + n); shapes.reserve(16 + 6 * n); joints.reserve(12 + 2 * n); prims.reserve(16 + 2 * n);
+        island_j.reserve(n); joint_acc_off.reserve(12 + 2 * n);
+    }
     // body 0: every static body (space.static_body, the arena body, goal bodies) in one world frame
     bodies.push_back({BODY_STATIC, 0, 0, 0, 0, 0, -1, 0, 0, 0});
 
@@ -319,15 +384,15 @@ int World::finalize(int max_steps, std::string &err) {
         Vec2 pts[4] = {{l - rad, t + rad}, {r + rad, t + rad}, {r + rad, b - rad}, {l - rad, b - rad}};
         for (int i = 0; i < 4; i++) {
             ShapeDef s{SH_SEGMENT, 0, rad, 0.8, 0, -1, {pts[i], pts[(i + 1) % 4]}};
-            shapes.push_back(s);
+            shapes.push_back(std::move(s));
         }
         PrimDef q = prim(PR_POLY, WHITE, XF_WORLD, 0);
         q.verts = draw_rect(r - l, t - b);
-        prims.push_back(q);
+        prims.push_back(std::move(q));
         // PolyLine: attrs enabled in reverse add order (gym_render.py:306-311) -> glLineWidth(1) wins
         PrimDef ln = prim(PR_LINELOOP, GREY, XF_WORLD, 0);
         ln.verts = draw_rect(r - l, t - b); ln.line_width = 1.0;
-        prims.push_back(ln);
+        prims.push_back(std::move(ln));
     }
 
     int n_blocks = 0, n_goals = 0;
@@ -405,24 +470,24 @@ int World::finalize(int max_steps, std::string &err) {
             }
             // graphics (:377-437): finger outers, finger inners, then the body compound
             for (int k = 0; k < 2; k++) {
-                PrimDef a = prim(PR_POLY, GREY, XF_BODY, finger_body[k]); a.verts = f_upper[k]; prims.push_back(a);
-                PrimDef b = prim(PR_POLY, GREY, XF_BODY, finger_body[k]); b.verts = f_fore[k]; prims.push_back(b);
+                PrimDef a = prim(PR_POLY, GREY, XF_BODY, finger_body[k]); a.verts = f_upper[k]; prims.push_back(std::move(a));
+                PrimDef b = prim(PR_POLY, GREY, XF_BODY, finger_body[k]); b.verts = f_fore[k]; prims.push_back(std::move(b));
             }
             for (int k = 0; k < 2; k++) {
-                PrimDef a = prim(PR_POLY, BACKGROUND, XF_BODY, finger_body[k]); a.verts = fi_upper[k]; prims.push_back(a);
-                PrimDef b = prim(PR_POLY, BACKGROUND, XF_BODY, finger_body[k]); b.verts = fi_fore[k]; prims.push_back(b);
+                PrimDef a = prim(PR_POLY, BACKGROUND, XF_BODY, finger_body[k]); a.verts = fi_upper[k]; prims.push_back(std::move(a));
+                PrimDef b = prim(PR_POLY, BACKGROUND, XF_BODY, finger_body[k]); b.verts = fi_fore[k]; prims.push_back(std::move(b));
             }
-            PrimDef co = prim(PR_NGON, GREY_DARK, XF_BODY, body); co.ngon = 100; co.radius = radius; prims.push_back(co);
-            PrimDef ci = prim(PR_NGON, GREY, XF_BODY, body); ci.ngon = 100; ci.radius = radius - ROBOT_LINE; prims.push_back(ci);
+            PrimDef co = prim(PR_NGON, GREY_DARK, XF_BODY, body); co.ngon = 100; co.radius = radius; prims.push_back(std::move(co));
+            PrimDef ci = prim(PR_NGON, GREY, XF_BODY, body); ci.ngon = 100; ci.radius = radius - ROBOT_LINE; prims.push_back(std::move(ci));
             for (int k = 0; k < 2; k++) {
                 double xs = k == 0 ? -1.0 : 1.0;
                 PrimDef eye = prim(PR_NGON, WHITE, XF_EYE, body);
                 eye.ngon = 20; eye.radius = 0.2 * radius; eye.eye_base[0] = xs * 0.4 * radius; eye.eye_base[1] = 0.3 * radius;
-                prims.push_back(eye);
+                prims.push_back(std::move(eye));
                 PrimDef pup = prim(PR_NGON, PUPIL, XF_EYE, body);
                 pup.ngon = 10; pup.radius = 0.12 * radius; pup.eye_base[0] = eye.eye_base[0]; pup.eye_base[1] = eye.eye_base[1];
                 pup.eye_body = eye_bodies[k]; pup.eye_pre[0] = 0; pup.eye_pre[1] = radius * 0.07;
-                prims.push_back(pup);
+                prims.push_back(std::move(pup));
             }
         } else if (e.kind == 1 && !e.enabled) {
             // not part of this env's episode: an inert body that only keeps body indices and state rows aligned
@@ -434,50 +499,63 @@ int World::finalize(int max_steps, std::string &err) {
             double mass = SHAPE_MASS, size = SHAPE_RAD;
             int body = (int)bodies.size();
             e.body = body;
-            std::vector<std::vector<Vec2>> phys_parts, draw_outer, draw_inner;
-            double inertia = 0, poly_radius = 0;
-            bool circle = false;
-            int group = 0;
-            Rgb col = BASE[e.colour], dark = DARK[e.colour];
-            if (e.shape_type == 1) {                                       // SQUARE :620-635
-                double side = std::sqrt(PI) * size, hw = side / 2;
-                std::vector<Vec2> box = {{hw, -hw}, {hw, hw}, {-hw, hw}, {-hw, -hw}};   // cpBoxShapeInit2 order
-                inertia = mass * moment_for_poly(1.0, box);               // mass comes from shape.mass
-                poly_radius = 0.01 * side;
-                phys_parts = {box};
-                draw_outer = {draw_rect(side, side)};
-                draw_inner = {draw_rect(side - 2 * SHAPE_LINE, side - 2 * SHAPE_LINE)};
-            } else if (e.shape_type == 5) {                                // CIRCLE :636-645
-                inertia = moment_for_circle(mass, 0, size);
-                circle = true;
-            } else if (e.shape_type == 6) {                                // STAR :646-668
-                double r_out = 1.3 * size, r_in = 0.5 * r_out;
-                std::vector<Vec2> sv = star_verts(5, r_out, r_in);
-                std::vector<Vec2> hull;                                    // to_convex_hull -> the 5 tips
-                for (int k = 0; k < 5; k++) hull.push_back(sv[2 * k]);
-                inertia = moment_for_poly(mass, hull);
-                phys_parts = star_parts(sv);
-                group = ++group_ctr;                                       // generate_group_id :60-66
-                draw_outer = phys_parts;
-                draw_inner = star_parts(star_verts(5, r_out - SHAPE_LINE, r_in - SHAPE_LINE));
-            } else {                                                       // regular polygons :669-697
-                int ns; double factor = 1.0;
-                switch (e.shape_type) {
-                    case 0: ns = 3; factor = 0.8; break;
-                    case 2: ns = 5; break;
-                    case 3: ns = 6; break;
-                    case 4: ns = 8; break;
-                    default: err = "bad shape type"; return -1;
+            // a block's geometry depends on its shape type alone: worked out once per thread and type (a reset with per-env worlds
+            // finalizes thousands of worlds per thread, and the trigonometry and the star's decomposition were a third of that)
+            struct ShapeGeom { bool have = false, circle = false; double inertia = 0, poly_radius = 0; std::vector<std::vector<Vec2>> phys_parts, draw_outer, draw_inner; };
+            static thread_local ShapeGeom geom_cache[7];
+            if (e.shape_type < 0 || e.shape_type > 6) { err = "bad shape type"; return -1; }
+            ShapeGeom &G = geom_cache[e.shape_type];
+            if (!G.have) {
+                std::vector<std::vector<Vec2>> phys_parts, draw_outer, draw_inner;
+                double inertia = 0, poly_radius = 0;
+                bool circle = false;
+                if (e.shape_type == 1) {                                       // SQUARE :620-635
+                    double side = std::sqrt(PI) * size, hw = side / 2;
+                    std::vector<Vec2> box = {{hw, -hw}, {hw, hw}, {-hw, hw}, {-hw, -hw}};   // cpBoxShapeInit2 order
+                    inertia = mass * moment_for_poly(1.0, box);               // mass comes from shape.mass
+                    poly_radius = 0.01 * side;
+                    phys_parts = {box};
+                    draw_outer = {draw_rect(side, side)};
+                    draw_inner = {draw_rect(side - 2 * SHAPE_LINE, side - 2 * SHAPE_LINE)};
+                } else if (e.shape_type == 5) {                                // CIRCLE :636-645
+                    inertia = moment_for_circle(mass, 0, size);
+                    circle = true;
+                } else if (e.shape_type == 6) {                                // STAR :646-668
+                    double r_out = 1.3 * size, r_in = 0.5 * r_out;
+                    std::vector<Vec2> sv = star_verts(5, r_out, r_in);
+                    std::vector<Vec2> hull;                                    // to_convex_hull -> the 5 tips
+                    for (int k = 0; k < 5; k++) hull.push_back(sv[2 * k]);
+                    inertia = moment_for_poly(mass, hull);
+                    phys_parts = star_parts(sv);
+                    draw_outer = phys_parts;
+                    draw_inner = star_parts(star_verts(5, r_out - SHAPE_LINE, r_in - SHAPE_LINE));
+                } else {                                                       // regular polygons :669-697
+                    int ns; double factor = 1.0;
+                    switch (e.shape_type) {
+                        case 0: ns = 3; factor = 0.8; break;
+                        case 2: ns = 5; break;
+                        case 3: ns = 6; break;
+                        case 4: ns = 8; break;
+                        default: err = "bad shape type"; return -1;
+                    }
+                    double side = factor * area_equiv_side(ns, size);
+                    std::vector<Vec2> pv_ = regular_poly(ns, side);
+                    inertia = moment_for_poly(mass, pv_);
+                    phys_parts = {pv_};
+                    double apothem = side / (2 * std::tan(PI / ns));
+                    double short_side = 2 * (apothem - SHAPE_LINE) * std::tan(PI / ns);
+                    draw_outer = {pv_};
+                    draw_inner = {regular_poly(ns, short_side)};
                 }
-                double side = factor * area_equiv_side(ns, size);
-                std::vector<Vec2> pv_ = regular_poly(ns, side);
-                inertia = moment_for_poly(mass, pv_);
-                phys_parts = {pv_};
-                double apothem = side / (2 * std::tan(PI / ns));
-                double short_side = 2 * (apothem - SHAPE_LINE) * std::tan(PI / ns);
-                draw_outer = {pv_};
-                draw_inner = {regular_poly(ns, short_side)};
+                G.have = true; G.circle = circle; G.inertia = inertia; G.poly_radius = poly_radius;
+                G.phys_parts = std::move(phys_parts); G.draw_outer = std::move(draw_outer); G.draw_inner = std::move(draw_inner);
             }
+            const std::vector<std::vector<Vec2>> &phys_parts = G.phys_parts, &draw_outer = G.draw_outer, &draw_inner = G.draw_inner;
+            const double inertia = G.inertia, poly_radius = G.poly_radius;
+            const bool circle = G.circle;
+            int group = 0;
+            if (e.shape_type == 6) group = ++group_ctr;                    // generate_group_id :60-66
+            Rgb col = BASE[e.colour], dark = DARK[e.colour];
             bodies.push_back({BODY_DYNAMIC, 1.0 / mass, 1.0 / inertia, e.x, e.y, e.angle, -1, 0, 0, 0x1FF, (int)ei, 0.0});
             if (circle) {
                 e.shapes.push_back((int)shapes.size());
@@ -496,8 +574,8 @@ int World::finalize(int max_steps, std::string &err) {
             rj.p0 = 0.0; rj.p1 = 1.0; rj.max_bias = 0; rj.max_force = pv[4]; rj.pv = 4;
             joints.push_back(rj);
             if (circle) {
-                PrimDef o = prim(PR_NGON, dark, XF_BODY, body); o.ngon = 100; o.radius = size; o.ent = (int)ei; o.role = 0; prims.push_back(o);
-                PrimDef i = prim(PR_NGON, col, XF_BODY, body); i.ngon = 100; i.radius = size - SHAPE_LINE; i.ent = (int)ei; i.role = 1; prims.push_back(i);
+                PrimDef o = prim(PR_NGON, dark, XF_BODY, body); o.ngon = 100; o.radius = size; o.ent = (int)ei; o.role = 0; prims.push_back(std::move(o));
+                PrimDef i = prim(PR_NGON, col, XF_BODY, body); i.ngon = 100; i.radius = size - SHAPE_LINE; i.ent = (int)ei; i.role = 1; prims.push_back(std::move(i));
             } else {
                 // the convex parts of one compound are painted back to back in one opaque colour (entities.py:750-757), so
                 // each compound is a single multi-part primitive: the union of its parts
@@ -505,7 +583,7 @@ int World::finalize(int max_steps, std::string &err) {
                     PrimDef q = prim(PR_POLY, c, XF_BODY, body);
                     for (auto &g : geoms) { q.verts.insert(q.verts.end(), g.begin(), g.end()); q.parts.push_back((int)g.size()); }
                     q.ent = (int)ei; q.role = role;
-                    prims.push_back(q);
+                    prims.push_back(std::move(q));
                 };
                 compound(draw_outer, dark, 0);
                 compound(draw_inner, col, 1);
@@ -518,15 +596,17 @@ int World::finalize(int max_steps, std::string &err) {
             std::vector<Vec2> rect = draw_rect(e.w, e.h);
             for (auto &v : rect) { v.x += cx; v.y += cy; }
             const int goal_ord = n_goals++;
-            PrimDef fill = prim(PR_POLY, LIGHT2[e.colour], XF_WORLD, 0); fill.verts = rect; fill.ent = (int)ei; fill.role = 2; fill.goal = goal_ord; prims.push_back(fill);
+            PrimDef fill = prim(PR_POLY, LIGHT2[e.colour], XF_WORLD, 0); fill.verts = rect; fill.ent = (int)ei; fill.role = 2; fill.goal = goal_ord; prims.push_back(std::move(fill));
             PrimDef outl = prim(PR_LINELOOP, BASE[e.colour], XF_WORLD, 0);
             outl.verts = rect; outl.line_width = 2.5; outl.stipple = 0x00FF; outl.ent = (int)ei; outl.role = 1; outl.goal = goal_ord;
-            prims.push_back(outl);
+            prims.push_back(std::move(outl));
         }
     }
     if (robot_body < 0) { err = "world has no robot"; return -1; }
 
     // ---- filtered candidate pairs (cpSpaceCollideShapes QueryReject minus the BB test)
+    pairs.reserve(shapes.size() * (shapes.size() - 1) / 2);
+    state_map.reserve(bodies.size() * 9);
     for (int i = 0; i < (int)shapes.size(); i++)
         for (int j = i + 1; j < (int)shapes.size(); j++) {
             const ShapeDef &a = shapes[i], &b = shapes[j];
@@ -565,6 +645,8 @@ int World::finalize(int max_steps, std::string &err) {
     for (auto &s : shapes) nverts += (s.kind == SH_CIRCLE) ? 1 : (int)s.verts.size();
     for (auto &p : prims) npv += (int)p.verts.size();
     for (auto &p : prims) if (p.verts.size() > 32) { err = "primitive with more than 32 vertices"; return -2; }
+    for (auto &s : shapes) if (s.verts.size() > 16) { err = "collision shape with more than 16 vertices"; return -2; }      // (WS_MAXV of the placement queries)
+    for (auto &e : entities) if (e.shapes.size() > 8) { err = "entity with more than 8 collision shapes"; return -2; }
     for (auto &p : prims) if (p.goal + 1 > 31) { err = "more than 30 goal regions"; return -2; }      // (5-bit field of the primitive record)
     if ((int)bodies.size() > CAP_BODIES || (int)shapes.size() > CAP_SHAPES || nverts > CAP_VERTS ||
         (int)joints.size() > CAP_JOINTS || (int)pairs.size() > CAP_PAIRS || (int)prims.size() > CAP_PRIMS ||
