@@ -477,11 +477,12 @@ class BaseEnv(abc.ABC):
         owner = lambda name: next(c for c in type(self).__mro__ if name in c.__dict__)
         batched = (draws and self.batch_draws and owner('sample_variation_batch') is not BaseEnv
                    and issubclass(owner('sample_variation_batch'), owner('sample_variation')))
-        hw_batch = None
+        hw_batch, rng_addrs = None, None
         if batched:
             # every kind of draw for all envs of this reset at once, in the reference's order per env: physics variables first
             from .batch_rng import BatchRng
             brng = BatchRng([self.rngs[k] for k in env_idx], self._lib)
+            rng_addrs = brng.addrs          # where the envs' MT19937 states live: the placement below draws from the same streams
             if self.rand_dynamics:
                 pvs = PhysicsVariables.sample_batch(brng)
             var = self.sample_variation_batch(brng, np.asarray(env_idx)) or {}
@@ -564,10 +565,10 @@ class BaseEnv(abc.ABC):
                         # task-specific step between placements (e.g. move a block onto its region), or a placement whose
                         # limits depend on the env; gets the poses so far, the envs' goal sizes and a runner for placements
                         stage(batch, ent_hw, lambda ents, **kw: geom.pm_randomise_all_poses_batch(
-                            self, batch, ents, self.ARENA_BOUNDS_LRBT, rngs, ent_hw=ent_hw, env_idx=env_idx, **kw))
+                            self, batch, ents, self.ARENA_BOUNDS_LRBT, rngs, ent_hw=ent_hw, env_idx=env_idx, addrs=rng_addrs, **kw))
                     else:
                         ents, kwargs = stage
-                        geom.pm_randomise_all_poses_batch(self, batch, ents, self.ARENA_BOUNDS_LRBT, rngs, ent_hw=ent_hw, env_idx=env_idx, **kwargs)
+                        geom.pm_randomise_all_poses_batch(self, batch, ents, self.ARENA_BOUNDS_LRBT, rngs, ent_hw=ent_hw, env_idx=env_idx, addrs=rng_addrs, **kwargs)
             pose_rows = list(batch)
             if len(self._goal_ent_idx):
                 # the goal regions' rectangles of these envs, back in GoalRegion(x, y, h, w) form: x, y = top-left corner

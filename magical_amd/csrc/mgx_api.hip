@@ -10,6 +10,9 @@
 #include <iterator>
 #include <thread>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <unistd.h>
 #include <type_traits>
 
 #include <cstdio>
@@ -108,6 +111,10 @@ struct mgx_engine {
     uint32_t *d_stage = nullptr; size_t stage_words = 0;                 // upload staging (device)
     uint32_t *h_stage = nullptr; size_t h_stage_words = 0;               // upload staging (pinned host memory)
     int32_t *d_stage_idx = nullptr; size_t stage_idx_n = 0;       // (env, offsets, sizes) rows of an upload
+    // set_env_variants does not wait for its uploads: what they read stays untouched until the next call has waited for ev_variants
+    hipEvent_t ev_variants = nullptr; bool variants_pending = false;
+    std::vector<int32_t> v_rows, v_idx; std::vector<int8_t> v_ty; std::vector<uint8_t> v_on;
+    int8_t *d_v_ty = nullptr; uint8_t *d_v_on = nullptr; int32_t *d_v_idx = nullptr; size_t d_v_ent_cap = 0, d_v_idx_cap = 0;
     // k_score (goal-region overlap sets): fp64 shape library, entity / body / goal tables of the engine's world, and with
     // per-env worlds the envs' shape types and presence flags
     ScoreLib *d_score_lib = nullptr;
@@ -290,16 +297,65 @@ int mgx_world_randomise_all_poses(const mgx_world *w, double *poses, const int *
 // pm_randomise_all_poses for m envs, env k in the world world_of(k): envs are independent (own stream, own poses), so
 // they are spread over a few host threads
 static int host_threads(bool allocating = true) {
-    // world building and placement at a reset: as many threads as the host has cores, within [1, MGX_HOST_THREADS (default 32: ClusterColour-TestAll
-    // resets 41-62 ms at 16 threads, 31-48 at 32, no better at 64, worse at 128 -- the allocator)].  The placement of the entities
-    // (randomise_batch: rejection sampling) scales further on its own -- 7.4 ms at 32 threads, 5.8 at 48, 4.5 at 96 on the 256-core
-    // host -- but every extra thread that ever allocated leaves glibc another arena, and the world builders of the NEXT reset, spread
-    // over those, take 15-25 ms instead of 9 (profiles/r04_reset_threads.txt: 24 ms per reset at 32 placement threads, 26 at 48, 35 at
-    // 64 / 96).  So MGX_PLACE_THREADS is a knob that defaults to MGX_HOST_THREADS.
-    static const int cap = [] { const char *v = getenv("MGX_HOST_THREADS"); const int c = v ? atoi(v) : 32; return c < 1 ? 1 : (c > 256 ? 256 : c); }();
+    // world building and placement at a reset: as many threads as the host has cores, within [1, MGX_HOST_THREADS (default 64)].
+    // History (256-core host, ClusterColour-TestAll, 4096 envs per reset): with a World built from hundreds of small allocations, blob
+    // vectors per world and threads created per call, 32 was the best (41-62 ms at 16, 31-48 at 32, no better at 64, worse at 128 -- the
+    // allocator; threads that only ran the placement left glibc arenas behind that slowed the NEXT reset's builds,
+    // profiles/r04_reset_threads.txt).  Since the builds serialise into per-thread buffers and the pinned staging buffer, the block
+    // geometry is cached per thread, the placement queries allocate nothing and the threads persist (HostPool below), more threads pay
+    // again: 16.0 ms per reset at 32, 15.7 at 48, 12.2-13.8 at 64, 13.7 at 96, 18.1 at 128 (profiles/r04_reset_threads_pool.txt).
+    // MGX_PLACE_THREADS (placement alone) still exists and defaults to MGX_HOST_THREADS; a pool larger than a burst wakes threads for nothing.
+    static const int cap = [] { const char *v = getenv("MGX_HOST_THREADS"); const int c = v ? atoi(v) : 64; return c < 1 ? 1 : (c > 256 ? 256 : c); }();
     static const int cap_place = [] { const char *v = getenv("MGX_PLACE_THREADS"); const int c = v ? atoi(v) : cap; return c < 1 ? 1 : (c > 256 ? 256 : c); }();
     const int hw = (int)std::thread::hardware_concurrency(), c = allocating ? cap : cap_place;
     return hw < 1 ? 1 : (hw > c ? c : hw);
+}
+// A few persistent host threads for the batch work of a reset (world builds, placement sampling): a reset of 4096 per-env worlds is
+// two bursts of a few ms each, and creating and joining 32 threads per burst was a good part of them.  The threads keep their
+// thread-local buffers (blob serialiser, shape geometry, held placement shapes) warm from reset to reset.  The pool is never torn
+// down (its threads block on a condition variable of a leaked object: no static destructor to race with at exit); a forked child
+// starts its own.  One burst at a time.
+struct HostPool {
+    std::mutex run_mu, mu; std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> threads;
+    const std::function<void(int)> *job = nullptr; int n_job = 0, next = 0, pending = 0;
+    pid_t pid = 0;
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] { return job && next < n_job; });
+            const int t = next++;
+            const std::function<void(int)> *fn = job;
+            lk.unlock();
+            (*fn)(t);
+            lk.lock();
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+    void run(int n, const std::function<void(int)> &fn) {      // fn(0 .. n-1), fn(0) on the caller
+        if (n <= 1) { fn(0); return; }
+        std::lock_guard<std::mutex> one(run_mu);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            while ((int)threads.size() < n - 1) { threads.emplace_back([this] { worker(); }); threads.back().detach(); }
+            job = &fn; n_job = n; next = 1; pending = n - 1;
+        }
+        cv_work.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        job = nullptr; n_job = 0;
+    }
+};
+static void host_parallel(int n, const std::function<void(int)> &fn) {
+    static std::mutex mu; static HostPool *pool = nullptr;
+    HostPool *p;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!pool || pool->pid != getpid()) { pool = new HostPool(); pool->pid = getpid(); }
+        p = pool;
+    }
+    p->run(n, fn);
 }
 template <typename WorldOf>
 static int randomise_batch(WorldOf world_of, int ne, int m, double *poses, const int *ents, int n, const uint8_t *ignore,
@@ -325,12 +381,7 @@ static int randomise_batch(WorldOf world_of, int ne, int m, double *poses, const
             rej[t] += rc;
         }
     };
-    if (n_threads == 1) work(0);
-    else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; t++) pool.emplace_back(work, t);
-        for (auto &th : pool) th.join();
-    }
+    host_parallel(n_threads, work);
     long rejected = 0;
     for (int t = 0; t < n_threads; t++) {
         if (bad[t] == 1) return fail(MGX_ERR_ARG, "bad MT19937 state");
@@ -741,6 +792,9 @@ void mgx_engine_destroy(mgx_engine *e) {
     if (e->d_step) (void)hipFree(e->d_step);
     if (e->d_raster) (void)hipFree(e->d_raster);
     if (e->d_palette) (void)hipFree(e->d_palette);
+    if (e->variants_pending) (void)hipEventSynchronize(e->ev_variants);
+    if (e->ev_variants) (void)hipEventDestroy(e->ev_variants);
+    for (void *p : {(void *)e->d_v_ty, (void *)e->d_v_on, (void *)e->d_v_idx}) if (p) (void)hipFree(p);
     if (e->d_stage) (void)hipFree(e->d_stage);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->d_stage_idx) (void)hipFree(e->d_stage_idx);
@@ -1125,6 +1179,8 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     if (!e->env_worlds) return fail(MGX_ERR_STATE, "call mgx_engine_enable_env_worlds first");
     if (m == 0) return MGX_OK;
     ON_DEVICE(e);
+    if (e->variants_pending) { HIP_OK(hipEventSynchronize(e->ev_variants)); e->variants_pending = false; }      // the previous call's uploads read the buffers reused below
+    if (!e->ev_variants) HIP_OK(hipEventCreateWithFlags(&e->ev_variants, hipEventDisableTiming));
     const bool dbg = getenv("MGX_DEBUG_VARIANTS") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tm[8]; int ti = 0; tm[ti++] = now();
@@ -1158,7 +1214,9 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     }
     tm[ti++] = now();
     // the staging buffer holds every distinct world's blobs back to back; no blob is larger than the capacity world's
-    const size_t stage_bound = uniq.size() * ((size_t)e->step_stride + (size_t)e->raster_stride);
+    // (sized for one world per env from the start: the number of distinct worlds differs from reset to reset, and every regrowth would
+    // be another pinned allocation of a few hundred MB)
+    const size_t stage_bound = std::max(uniq.size(), (size_t)e->n_envs) * ((size_t)e->step_stride + (size_t)e->raster_stride);
     if (stage_bound > 0x7fffffffull) return fail(MGX_ERR_CAPACITY, "too many distinct worlds in one call");
     // (pinned staging: a pageable copy of this size -- 160 MB for 4096 distinct Cluster worlds -- would dominate the reset)
     if (e->h_stage_words < stage_bound) {
@@ -1198,12 +1256,7 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
             std::memcpy(host + B.off_r, tb.raster.data(), (size_t)B.raster_words * 4);
         }
     };
-    if (n_threads == 1) work(0);
-    else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; t++) pool.emplace_back(work, t);
-        for (auto &th : pool) th.join();
-    }
+    host_parallel(n_threads, work);
     tm[ti++] = now();
     for (auto &U : uniq) {
         if (U.rc) return fail(U.rc == -2 ? MGX_ERR_CAPACITY : MGX_ERR_ARG, U.err);
@@ -1214,7 +1267,8 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     const size_t total = cursor.load();
     tm[ti++] = now();
     // per env: destination env, source offsets and sizes of its two blobs
-    std::vector<int32_t> rows((size_t)5 * m);
+    std::vector<int32_t> &rows = e->v_rows;
+    rows.resize((size_t)5 * m);
     for (int k = 0; k < m; k++) {
         const int u = which[k];
         rows[5 * k] = env_idx[k]; rows[5 * k + 1] = uniq[u].blobs.off_s; rows[5 * k + 2] = uniq[u].blobs.step_words;
@@ -1223,8 +1277,8 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     if (e->stage_words < total) {
         if (e->d_stage) (void)hipFree(e->d_stage);
         e->d_stage = nullptr; e->stage_words = 0;
-        HIP_OK(hipMalloc(&e->d_stage, total * 4 + 4096));
-        e->stage_words = total + 1024;
+        HIP_OK(hipMalloc(&e->d_stage, total * 4 + (total >> 3) * 4 + 4096));       // (some room: the total differs from reset to reset)
+        e->stage_words = total + (total >> 3) + 1024;
     }
     if (e->stage_idx_n < rows.size()) {
         if (e->d_stage_idx) (void)hipFree(e->d_stage_idx);
@@ -1238,20 +1292,34 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     hipLaunchKernelGGL(k_place_blobs, dim3(m), dim3(256), 0, st, e->d_step, (long)e->step_stride, e->d_raster, (long)e->raster_stride, e->d_stage, e->d_stage_idx);
     HIP_OK(hipGetLastError());
     // k_score's per-env entity tables (shape type / presence of every entity of these envs)
-    std::vector<int8_t> ent_ty((size_t)m * ne); std::vector<uint8_t> ent_on((size_t)m * ne);
+    std::vector<int8_t> &ent_ty = e->v_ty; std::vector<uint8_t> &ent_on = e->v_on;
+    ent_ty.resize((size_t)m * ne); ent_on.resize((size_t)m * ne);
+    e->v_idx.assign(env_idx, env_idx + m);
     for (int k = 0; k < m; k++) {
         const std::string &sig = uniq[which[k]].sig;
         for (int i = 0; i < ne; i++) { ent_on[(size_t)k * ne + i] = (uint8_t)sig[i]; ent_ty[(size_t)k * ne + i] = (int8_t)(e->w.entities[i].kind == 1 ? (int)sig[ne + i] - 1 : -1); }
     }
-    int8_t *d_ty = nullptr; uint8_t *d_on = nullptr; int32_t *d_idx = nullptr;
-    HIP_OK(hipMalloc(&d_ty, ent_ty.size())); HIP_OK(hipMalloc(&d_on, ent_on.size())); HIP_OK(hipMalloc(&d_idx, (size_t)m * 4));
-    HIP_OK(hipMemcpyAsync(d_ty, ent_ty.data(), ent_ty.size(), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(d_on, ent_on.data(), ent_on.size(), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(d_idx, env_idx, (size_t)m * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_scatter_ent_rows, dim3(m), dim3(64), 0, st, e->d_ent_type_env, e->d_ent_present_env, d_ty, d_on, (const int32_t *)d_idx, ne, (long)e->n_envs);
+    if (e->d_v_ent_cap < ent_ty.size()) {
+        if (e->d_v_ty) (void)hipFree(e->d_v_ty);
+        if (e->d_v_on) (void)hipFree(e->d_v_on);
+        e->d_v_ty = nullptr; e->d_v_on = nullptr; e->d_v_ent_cap = 0;
+        HIP_OK(hipMalloc(&e->d_v_ty, ent_ty.size())); HIP_OK(hipMalloc(&e->d_v_on, ent_on.size()));
+        e->d_v_ent_cap = ent_ty.size();
+    }
+    if (e->d_v_idx_cap < (size_t)m) {
+        if (e->d_v_idx) (void)hipFree(e->d_v_idx);
+        e->d_v_idx = nullptr; e->d_v_idx_cap = 0;
+        HIP_OK(hipMalloc(&e->d_v_idx, (size_t)m * 4));
+        e->d_v_idx_cap = (size_t)m;
+    }
+    HIP_OK(hipMemcpyAsync(e->d_v_ty, ent_ty.data(), ent_ty.size(), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->d_v_on, ent_on.data(), ent_on.size(), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->d_v_idx, e->v_idx.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_scatter_ent_rows, dim3(m), dim3(64), 0, st, e->d_ent_type_env, e->d_ent_present_env, e->d_v_ty, e->d_v_on, (const int32_t *)e->d_v_idx, ne, (long)e->n_envs);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(st));        // the staging buffer, `rows` and the entity rows are read by the copies above
-    (void)hipFree(d_ty); (void)hipFree(d_on); (void)hipFree(d_idx);
+    // (no wait here: the copies and the two small kernels run while the caller goes on to the placement sampling, which is host
+    // work; the staging buffer, the row table and the entity rows are the engine's and stay as they are until the next call)
+    HIP_OK(hipEventRecord(e->ev_variants, st)); e->variants_pending = true;
     tm[ti++] = now();
     std::vector<std::shared_ptr<World>> retired(m);      // the envs' previous worlds: freed below, a few threads wide
     for (int k = 0; k < m; k++) {

@@ -117,7 +117,7 @@ def pm_randomise_all_poses(env, poses, entities, arena_lrbt, rng, rand_pos=True,
 
 
 def pm_randomise_all_poses_batch(env, poses, entities, arena_lrbt, rngs, rand_pos=True, rand_rot=True, rel_pos_linf_limits=None,
-                                 rel_rot_limits=None, ignore=(), ent_hw=None, env_idx=None):
+                                 rel_rot_limits=None, ignore=(), ent_hw=None, env_idx=None, addrs=None):
     """pm_randomise_all_poses for M envs in one native call: poses float64[M, n_entities, 3] (updated in place), rngs the
     M envs' np.random.RandomState objects, whose MT19937 states are advanced in place through their ctypes address.
     The limits are scalars / per-entity lists as in the reference, or float64[M, n] arrays (NaN = no limit) when they
@@ -135,8 +135,10 @@ def pm_randomise_all_poses_batch(env, poses, entities, arena_lrbt, rngs, rand_po
             a = np.tile(a, (m, 1)) if per_env else a
         return np.ascontiguousarray(np.where(np.isnan(a), -1.0, a))
     pl, rl = lim(rel_pos_linf_limits), lim(rel_rot_limits)
-    from .batch_rng import state_addresses
-    addrs = state_addresses(rngs)
+    if addrs is None:        # (uint64[M] from batch_rng.state_addresses(rngs), if the caller has them already)
+        from .batch_rng import state_addresses
+        addrs = state_addresses(rngs)
+    assert len(addrs) == m
     ents = (C.c_int * n)(*[e.ent_id for e in entities])
     ign = np.zeros(poses.shape[1], dtype=np.uint8)
     for e in ignore:
