@@ -252,6 +252,94 @@ def test_native_pose_sampler_matches_python_and_numpy_stream():
     L.mgx_world_destroy(w)
 
 
+def _placement_world(L, _native):
+    class Ent:
+        def __init__(self, i):
+            self.ent_id = i
+
+    class Shim:          # what geom.py needs of an env
+        _lib = L
+    w = ctypes.c_void_p()
+    _native.check(L.mgx_world_create(ctypes.byref(w)))
+    Shim._world = w
+    poses0 = []
+    for (x, y, h, wd, c) in [(-0.9, 0.9, 0.5, 0.6, 0), (0.2, 0.8, 0.45, 0.5, 2)]:
+        _native.check(L.mgx_world_add_goal(w, x, y, h, wd, c)); poses0.append((x + wd / 2, y - h / 2, 0.0))
+    _native.check(L.mgx_world_add_robot(w, 0.6, -0.4, 0.8)); poses0.append((0.6, -0.4, 0.8))
+    for (t, c, x, y, a) in [(5, 2, -0.51, 0.14, -0.39), (6, 2, -0.13, -0.71, 1.05), (1, 2, -0.74, -0.1, 1.16), (2, 1, -0.08, -0.43, -0.64),
+                            (4, 1, 0.52, 0.19, -1.18), (0, 0, -0.53, -0.62, 2.94), (6, 3, 0.1, 0.3, 0.07)]:
+        _native.check(L.mgx_world_add_shape(w, t, c, x, y, a)); poses0.append((x, y, a))
+    _native.check(L.mgx_world_finalize(w, 100))
+    return Shim, w, [Ent(i) for i in range(len(poses0))], np.array(poses0, dtype=np.float64)
+
+
+def test_native_pose_sampler_batch_on_the_host_pool_equals_the_calls_one_by_one():
+    """mgx_world_randomise_all_poses_batch spreads its envs over the persistent host pool (mgx_api.hip HostPool) and answers its
+    collision queries from world-space shapes it holds per entity (only the entity being placed is rebuilt per attempt); the
+    single call and the Python loop over mgx_world_placement_collides (geom.py:116-341 restated) rebuild everything per query.
+    Goal regions with per-env sizes, an ignored entity, per-env limits: same poses, same stream positions -- twice, so that
+    the second burst runs on pool threads that already hold buffers from the first."""
+    from magical_amd import _native, geom
+    if not os.path.exists(_native.LIB_PATH):
+        pytest.skip('HIP library not built')
+    L = _native.lib()
+    Shim, w, ents, poses0 = _placement_world(L, _native)
+    m, ne = 200, len(ents)
+    rs = np.random.RandomState(7)
+    for rep in range(2):
+        ent_hw = np.zeros((m, ne, 2)); ent_hw[:, :2] = 0.3 + 0.3 * rs.rand(m, 2, 2)
+        order = ents[:2] + ents[2:]                     # regions first, then the robot, then the blocks (find_dupe.py:84-112's order)
+        pl = np.where(rs.rand(m, ne) < 0.4, 0.2 + 0.3 * rs.rand(m, ne), np.nan)
+        rl = np.where(rs.rand(m, ne) < 0.4, 0.1 + rs.rand(m, ne), np.nan)
+        rngs = [np.random.RandomState(1000 * rep + k) for k in range(m)]
+        twins = [np.random.RandomState(1000 * rep + k) for k in range(m)]
+        batch = np.ascontiguousarray(np.tile(poses0, (m, 1, 1)))
+        geom.pm_randomise_all_poses_batch(Shim, batch, order, [-1, 1, -1, 1], rngs, rel_pos_linf_limits=pl, rel_rot_limits=rl,
+                                          ignore=[ents[-1]], ent_hw=ent_hw)
+        en_all = np.ones(ne, dtype=np.uint8); en_all[-1] = 0
+        for k in range(m):
+            lim = lambda row: [None if np.isnan(x) else float(x) for x in row]
+            one = geom.pm_randomise_all_poses(Shim, poses0.copy(), order, [-1, 1, -1, 1], twins[k], rel_pos_linf_limits=lim(pl[k]),
+                                              rel_rot_limits=lim(rl[k]), ignore=[ents[-1]], ent_hw=ent_hw[k], native=(k % 8 != 0))
+            assert np.array_equal(batch[k], one), (rep, k)
+            assert rngs[k].randint(1 << 30) == twins[k].randint(1 << 30)
+            for e in ents[:-1]:
+                assert not geom.placement_collides(Shim, e.ent_id, batch[k], en_all, ent_hw=ent_hw[k])
+    L.mgx_world_destroy(w)
+
+
+def _placement_batch_in_child(q):
+    from magical_amd import _native, geom
+    L = _native.lib()
+    Shim, w, ents, poses0 = _placement_world(L, _native)
+    rngs = [np.random.RandomState(k) for k in range(128)]
+    batch = np.ascontiguousarray(np.tile(poses0, (128, 1, 1)))
+    geom.pm_randomise_all_poses_batch(Shim, batch, ents, [-1, 1, -1, 1], rngs)
+    q.put(float(batch.sum()))
+
+
+def test_host_pool_survives_a_fork():
+    """The pool's threads do not exist in a forked child: it has to start its own instead of waiting for the parent's."""
+    import multiprocessing as mp
+    from magical_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        pytest.skip('HIP library not built')
+    ctx = mp.get_context('fork')
+    q0 = ctx.Queue()
+    _placement_batch_in_child(q0)                 # the parent's pool exists from here on
+    want = q0.get(timeout=10)
+    q = ctx.Queue()
+    p = ctx.Process(target=_placement_batch_in_child, args=(q,))
+    p.start()
+    try:
+        got = q.get(timeout=60)
+    finally:
+        p.join(timeout=10)
+        if p.is_alive():
+            p.kill()
+    assert got == want
+
+
 def test_make_line_batched_score_is_bit_identical():
     """longest_line_batch == longest_line (the per-env mirror of make_line.py:31-71) on random layouts, near-collinear
     layouts around the inlier threshold, and degenerate ones (coincident points)."""
