@@ -130,7 +130,8 @@ int mgx_world_randomise_all_poses_batch(const mgx_world *w, int m, double *poses
  *   bounded: counts[k] (NULL: `count`) draws of rng.randint(0, max_inclusive + 1) -- what rng.choice(seq) indexes with --
  *            into out[k][..] (row stride out_stride);
  *   doubles: likewise rng.random_sample() (rng.uniform(lo, hi) = lo + (hi - lo) * it);
- *   shuffle: the permutation rng.shuffle() applies to a list of n_items[k] items: shuffled[i] = original[perm[k][i]]. */
+ *   shuffle: the permutation rng.shuffle() applies to a list of n_items[k] items: shuffled[i] = original[perm[k][i]].
+ * The m addresses of one call must be distinct (one stream per env): batches of 1024 envs or more are spread over host threads. */
 int mgx_rng_bounded_batch(int m, const uint64_t *mt_state_addr, const int32_t *counts, int count, int max_inclusive, int32_t *out, int out_stride);
 int mgx_rng_doubles_batch(int m, const uint64_t *mt_state_addr, const int32_t *counts, int count, double *out, int out_stride);
 int mgx_rng_shuffle_batch(int m, const uint64_t *mt_state_addr, const int32_t *n_items, int32_t *perm, int perm_stride);

@@ -33,6 +33,8 @@ class BatchRng:
         self.L = lib or nat.lib()
         self.m = len(rngs)
         self.addrs = state_addresses(rngs)
+        # one stream per env: the native calls spread large batches over host threads (include/mgx.h)
+        assert len(np.unique(self.addrs)) == self.m, 'the same RandomState twice in one batch'
         self._rngs = rngs          # keep the generators (and so the states the addresses point at) alive
 
     def _sel(self, rows):

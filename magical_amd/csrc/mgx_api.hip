@@ -411,37 +411,58 @@ static bool mt_state_ok(uint64_t addr, uint32_t *&key, int *&pos) {
     pos = reinterpret_cast<int *>((uintptr_t)addr + 624 * sizeof(uint32_t));
     return key && *pos >= 0 && *pos <= 624;
 }
+// (the m streams are independent and each call touches every env's 2.5 KB state once -- a cache miss per env: large batches are spread
+// over the host pool; the addresses of one call must be distinct, one stream per env; per_env returns 0 or which argument was bad)
+}  // extern "C"
+template <typename F>
+static int rng_batch(int m, F per_env) {
+    if (m < 1024) {
+        for (int k = 0; k < m; k++) if (int rc = per_env(k)) return rc;
+        return 0;
+    }
+    const int nt = std::min(host_threads(false), 16);
+    std::atomic<int> err{0};
+    host_parallel(nt, [&](int t) {
+        const int k0 = (int)((long)m * t / nt), k1 = (int)((long)m * (t + 1) / nt);
+        for (int k = k0; k < k1 && err.load(std::memory_order_relaxed) == 0; k++) if (int rc = per_env(k)) { err.store(rc); return; }
+    });
+    return err.load();
+}
+static int rng_batch_status(int rc, const char *range_msg) {
+    return rc == 0 ? (int)MGX_OK : fail(MGX_ERR_ARG, rc == 1 ? "bad MT19937 state" : range_msg);
+}
+extern "C" {
 int mgx_rng_bounded_batch(int m, const uint64_t *mt_state_addr, const int32_t *counts, int count, int max_inclusive, int32_t *out, int out_stride) {
     if (m < 0 || !mt_state_addr || !out || max_inclusive < 0 || count < 0 || out_stride < count) return fail(MGX_ERR_ARG, "bad argument");
-    for (int k = 0; k < m; k++) {
+    return rng_batch_status(rng_batch(m, [&](int k) {
         uint32_t *key; int *pos;
-        if (!mt_state_ok(mt_state_addr[k], key, pos)) return fail(MGX_ERR_ARG, "bad MT19937 state");
+        if (!mt_state_ok(mt_state_addr[k], key, pos)) return 1;
         const int n = counts ? counts[k] : count;
-        if (n < 0 || n > out_stride) return fail(MGX_ERR_ARG, "count out of range");
+        if (n < 0 || n > out_stride) return 2;
         rng_bounded(key, pos, n, (uint32_t)max_inclusive, out + (size_t)k * out_stride);
-    }
-    return MGX_OK;
+        return 0;
+    }), "count out of range");
 }
 int mgx_rng_doubles_batch(int m, const uint64_t *mt_state_addr, const int32_t *counts, int count, double *out, int out_stride) {
     if (m < 0 || !mt_state_addr || !out || count < 0 || out_stride < count) return fail(MGX_ERR_ARG, "bad argument");
-    for (int k = 0; k < m; k++) {
+    return rng_batch_status(rng_batch(m, [&](int k) {
         uint32_t *key; int *pos;
-        if (!mt_state_ok(mt_state_addr[k], key, pos)) return fail(MGX_ERR_ARG, "bad MT19937 state");
+        if (!mt_state_ok(mt_state_addr[k], key, pos)) return 1;
         const int n = counts ? counts[k] : count;
-        if (n < 0 || n > out_stride) return fail(MGX_ERR_ARG, "count out of range");
+        if (n < 0 || n > out_stride) return 2;
         rng_doubles(key, pos, n, out + (size_t)k * out_stride);
-    }
-    return MGX_OK;
+        return 0;
+    }), "count out of range");
 }
 int mgx_rng_shuffle_batch(int m, const uint64_t *mt_state_addr, const int32_t *n_items, int32_t *perm, int perm_stride) {
     if (m < 0 || !mt_state_addr || !n_items || !perm) return fail(MGX_ERR_ARG, "bad argument");
-    for (int k = 0; k < m; k++) {
+    return rng_batch_status(rng_batch(m, [&](int k) {
         uint32_t *key; int *pos;
-        if (!mt_state_ok(mt_state_addr[k], key, pos)) return fail(MGX_ERR_ARG, "bad MT19937 state");
-        if (n_items[k] < 0 || n_items[k] > perm_stride) return fail(MGX_ERR_ARG, "item count out of range");
+        if (!mt_state_ok(mt_state_addr[k], key, pos)) return 1;
+        if (n_items[k] < 0 || n_items[k] > perm_stride) return 2;
         rng_shuffle(key, pos, n_items[k], perm + (size_t)k * perm_stride);
-    }
-    return MGX_OK;
+        return 0;
+    }), "item count out of range");
 }
 int mgx_world_palette(int colour, int role) {
     if (colour < 0 || colour > 3 || role < 0 || role > 2) return fail(MGX_ERR_ARG, "colour 0..3, role 0..2");
@@ -1193,24 +1214,49 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     struct BlobMeta { TmplHeader h; int step_words = 0, raster_words = 0, step_env_stride = 0, raster_lds_words = 0, raster_scratch_d = 0, raster_scratch_dc = 0, raster_n_i = 0; int32_t off_s = 0, off_r = 0; };
     struct Uniq { std::string sig; int first; std::shared_ptr<World> world; BlobMeta blobs; std::string err; int rc = 0; };
     std::vector<Uniq> uniq;
-    std::unordered_map<std::string, int> index;
     std::vector<int> which(m);
-    for (int k = 0; k < m; k++) {
-        std::string sig((size_t)2 * ne, '\0');
-        for (int i = 0; i < ne; i++) {
-            sig[i] = (char)(enabled ? (enabled[(size_t)k * ne + i] ? 1 : 0) : (e->w.entities[i].enabled ? 1 : 0));
-            int st = shape_types ? shape_types[(size_t)k * ne + i] : -1;
-            sig[ne + i] = (char)((e->w.entities[i].kind == 1 ? (st >= 0 ? st : e->w.entities[i].shape_type) : 0) + 1);
+    {
+        // the signatures (and their hashes) of all envs on the pool, then one serial pass that dedups them through an open-addressed table
+        // of indices (round 3: a string allocated, hashed and inserted into an unordered_map per env, serially: 1 ms of a 10 ms reset)
+        std::vector<std::string> sigs(m); std::vector<uint64_t> hs(m);
+        const int nt = m >= 1024 ? std::min(host_threads(false), 16) : 1;
+        host_parallel(nt, [&](int t) {
+            const int k0 = (int)((long)m * t / nt), k1 = (int)((long)m * (t + 1) / nt);
+            for (int k = k0; k < k1; k++) {
+                std::string &sig = sigs[k];
+                sig.assign((size_t)2 * ne, '\0');
+                uint64_t h = 1469598103934665603ull;
+                for (int i = 0; i < ne; i++) {
+                    sig[i] = (char)(enabled ? (enabled[(size_t)k * ne + i] ? 1 : 0) : (e->w.entities[i].enabled ? 1 : 0));
+                    int st = shape_types ? shape_types[(size_t)k * ne + i] : -1;
+                    sig[ne + i] = (char)((e->w.entities[i].kind == 1 ? (st >= 0 ? st : e->w.entities[i].shape_type) : 0) + 1);
+                }
+                for (char c : sig) { h ^= (uint8_t)c; h *= 1099511628211ull; }
+                hs[k] = h;
+            }
+        });
+        size_t cap = 16;
+        while (cap < (size_t)2 * m) cap <<= 1;
+        std::vector<int> slot(cap, -1);
+        uniq.reserve(m);
+        const bool any_live = !e->world_by_sig.empty();
+        for (int k = 0; k < m; k++) {
+            size_t i = (size_t)hs[k] & (cap - 1);
+            for (;; i = (i + 1) & (cap - 1)) {
+                const int u = slot[i];
+                if (u < 0) {
+                    slot[i] = (int)uniq.size(); which[k] = (int)uniq.size();
+                    Uniq nu; nu.sig = std::move(sigs[k]); nu.first = k;
+                    if (any_live) {
+                        auto live = e->world_by_sig.find(nu.sig);
+                        if (live != e->world_by_sig.end()) nu.world = live->second.lock();
+                    }
+                    uniq.push_back(std::move(nu));
+                    break;
+                }
+                if (hs[uniq[u].first] == hs[k] && uniq[u].sig == sigs[k]) { which[k] = u; break; }
+            }
         }
-        auto it = index.find(sig);
-        if (it == index.end()) {
-            it = index.emplace(sig, (int)uniq.size()).first;
-            Uniq u; u.sig = sig; u.first = k;
-            auto live = e->world_by_sig.find(sig);
-            if (live != e->world_by_sig.end()) u.world = live->second.lock();
-            uniq.push_back(std::move(u));
-        }
-        which[k] = it->second;
     }
     tm[ti++] = now();
     // the staging buffer holds every distinct world's blobs back to back; no blob is larger than the capacity world's

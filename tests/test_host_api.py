@@ -426,6 +426,39 @@ def test_batched_rng_primitives_equal_numpy():
     assert np.array_equal(got, np.array([PhysicsVariables.sample(r) for r in refs]))
 
 
+def test_batched_rng_primitives_on_the_host_pool_equal_numpy():
+    """The same primitives at a batch size that is spread over the host pool (>= 1024 streams per call, mgx_api.hip rng_batch):
+    every stream still draws what numpy draws, and an error in one env is reported."""
+    from magical_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        pytest.skip('HIP library not built')
+    from magical_amd.batch_rng import BatchRng
+    m = 2500
+    rngs = [np.random.RandomState(5000 + k) for k in range(m)]
+    refs = [np.random.RandomState(5000 + k) for k in range(m)]
+    brng = BatchRng(rngs)
+    rs = np.random.RandomState(0)
+    for rnd in range(3):
+        counts = rs.randint(0, 5, size=m)
+        out = brng.randint(7, counts=counts)
+        d = brng.random_sample(2)
+        items = rs.randint(0, 9, size=m)
+        perm = brng.shuffle(items)
+        for k, r in enumerate(refs):
+            assert list(out[k, :counts[k]]) == list(r.randint(0, 7, size=counts[k]) if counts[k] else [])
+            assert np.array_equal(d[k], r.random_sample(2))
+            lst = list(range(items[k])); r.shuffle(lst)
+            assert lst == list(perm[k, :items[k]])
+    assert all(a.randint(1 << 30) == b.randint(1 << 30) for a, b in zip(rngs, refs))
+    with pytest.raises(AssertionError):
+        BatchRng(rngs + rngs[:1])                        # the same stream twice in one batch
+    L = _native.lib()
+    bad = brng.addrs.copy(); bad[m // 2] = 0
+    out = np.zeros((m, 1), dtype=np.int32)
+    rc = L.mgx_rng_bounded_batch(m, bad.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), None, 1, 3, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), 1)
+    assert rc < 0 and b'MT19937' in L.mgx_last_error()
+
+
 def test_bench_window_plan_gives_every_window_its_share_of_episode_ends():
     """bench.py: a K-step timed window shorter than an episode contains the episode end of n * K / ep envs (their clocks set
     ahead so that the end falls in the middle of the window) and no end of the others, neither in the window nor in the
