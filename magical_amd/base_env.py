@@ -155,7 +155,18 @@ class BaseEnv(abc.ABC):
             seed = np.random.randint(0, (1 << 31) - 1)
         self.rngs = [np.random.RandomState(seed=(seed + k) % (1 << 32)) for k in range(self.n_envs)]
         self.rng = self.rngs[0]
+        self._rng_addr_cache = None
         return [seed]
+
+    def _rng_addrs(self, env_idx):
+        """uint64[len(env_idx)]: where the MT19937 states of the envs' generators live (batch_rng.state_addresses), looked up once
+        per generator: a RandomState keeps its state where it is for life (set_state copies into it).  The cache holds the
+        generators it was made from, so an env whose generator was replaced (env.rngs[k] = ...) is seen and looked up again."""
+        from .batch_rng import state_addresses
+        c = getattr(self, '_rng_addr_cache', None)
+        if c is None or len(c[0]) != len(self.rngs) or not all(a is b for a, b in zip(c[0], self.rngs)):
+            c = self._rng_addr_cache = (tuple(self.rngs), state_addresses(self.rngs))
+        return np.ascontiguousarray(c[1][np.asarray(env_idx, dtype=np.int64)])
 
     def _make_robot(self, init_pos, init_angle):
         return en.Robot(radius=self.ROBOT_RAD, init_pos=init_pos, init_angle=init_angle, mass=self.ROBOT_MASS)
@@ -481,7 +492,7 @@ class BaseEnv(abc.ABC):
         if batched:
             # every kind of draw for all envs of this reset at once, in the reference's order per env: physics variables first
             from .batch_rng import BatchRng
-            brng = BatchRng([self.rngs[k] for k in env_idx], self._lib)
+            brng = BatchRng([self.rngs[k] for k in env_idx], self._lib, addrs=self._rng_addrs(env_idx))
             rng_addrs = brng.addrs          # where the envs' MT19937 states live: the placement below draws from the same streams
             if self.rand_dynamics:
                 pvs = PhysicsVariables.sample_batch(brng)
@@ -559,6 +570,7 @@ class BaseEnv(abc.ABC):
                 # geom.py pm_randomise_all_poses for all envs being reset, each on its own stream, natively
                 from . import geom
                 rngs = [self.rngs[k] for k in env_idx]
+                rng_addrs = self._rng_addrs(env_idx) if rng_addrs is None else rng_addrs
                 stages = pose_spec if isinstance(pose_spec, list) else [pose_spec]
                 for stage in stages:
                     if callable(stage):
@@ -569,7 +581,7 @@ class BaseEnv(abc.ABC):
                     else:
                         ents, kwargs = stage
                         geom.pm_randomise_all_poses_batch(self, batch, ents, self.ARENA_BOUNDS_LRBT, rngs, ent_hw=ent_hw, env_idx=env_idx, addrs=rng_addrs, **kwargs)
-            pose_rows = list(batch)
+            pose_rows = batch             # (float64[M, n_entities, 3] as it is: a list of M rows would be re-assembled below)
             if len(self._goal_ent_idx):
                 # the goal regions' rectangles of these envs, back in GoalRegion(x, y, h, w) form: x, y = top-left corner
                 hw = ent_hw[:, self._goal_ent_idx] if ent_hw is not None else np.tile(self._goal_xyhw0[:, 2:], (len(env_idx), 1, 1))
@@ -577,7 +589,7 @@ class BaseEnv(abc.ABC):
                 self.set_goal_rects(np.stack([c[..., 0] - hw[..., 1] / 2, c[..., 1] + hw[..., 0] / 2, hw[..., 0], hw[..., 1]], axis=-1), env_idx)
         sp, sf, si = self.state_p.data_ptr(), self.state_f.data_ptr(), self.state_i.data_ptr()
         mask = None if mask_dev is None else mask_dev.data_ptr()
-        if pose_rows:
+        if len(pose_rows):
             self.entity_poses[env_idx] = np.asarray(pose_rows)
             if self._ent_pose is None:
                 self._ent_pose = torch.as_tensor(np.ascontiguousarray(self.entity_poses.reshape(self.n_envs, -1).T),
