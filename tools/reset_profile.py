@@ -5,6 +5,7 @@ import numpy as np, torch
 import magical_amd
 name = sys.argv[1] if len(sys.argv) > 1 else 'MatchRegions-TestCountPlus-LoRes4E-v0'
 N = 4096
+GAP = int(sys.argv[2]) if len(sys.argv) > 2 else 10        # env-steps between two resets (an episode is 40 - 240)
 env = magical_amd.make(name, n_envs=N, device='cuda:0')
 env.seed(3); env.reset(); torch.cuda.synchronize()
 for _ in range(3):          # steady state: the first resets of a process also warm the allocator and the staging buffers up
@@ -27,14 +28,14 @@ env._lib = _Timed(env._lib)
 # steady state, without the profiler: seven resets (ten env-steps between them), wall time and native calls of each
 walls = []
 for rep in range(7):
-    for _ in range(10): env.step(torch.zeros(N, dtype=torch.int32, device='cuda:0'))
+    for _ in range(GAP): env.step(torch.zeros(N, dtype=torch.int32, device='cuda:0'))
     torch.cuda.synchronize()
     native_ms.clear()
     t0 = time.perf_counter()
     env._reset_envs(idx, None); torch.cuda.synchronize()
     walls.append((time.perf_counter() - t0) * 1e3)
     print('  reset %d: %.1f ms' % (rep, walls[-1]), 'native calls (ms):', {k: round(v, 1) for k, v in native_ms.items()})
-print(name, 'steady-state reset of %d envs: median %.1f ms, min %.1f, max %.1f over %d resets' % (N, np.median(walls), min(walls), max(walls), len(walls)))
+print(name, 'steady-state reset of %d envs, %d env-steps apart: median %.1f ms, min %.1f, max %.1f over %d resets' % (N, GAP, np.median(walls), min(walls), max(walls), len(walls)))
 native_ms.clear()
 pr = cProfile.Profile()
 t0 = time.perf_counter()
