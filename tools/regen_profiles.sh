@@ -97,6 +97,13 @@ cd $GRAFT_REPO_ROOT
 for t in ClusterColour-TestAll-LoRes4E-v0 MatchRegions-TestCountPlus-LoRes4E-v0; do
   timeout 300 python tools/reset_profile.py $t 2>&1 | grep -v amdgpu.ids > $O/${R}_reset_profile_$t.txt
 done
+# resets ten env-steps apart (the profile above) against an episode's spacing; against the size of the host pool
+for t in ClusterColour-TestAll-LoRes4E-v0 MatchRegions-TestCountPlus-LoRes4E-v0; do for gap in 10 80; do
+  MGX_DEBUG_VARIANTS=1 timeout 300 python tools/reset_profile.py $t $gap 2>&1 | grep "steady\|reset [0-9]:\|mgx: set_env" | tail -15 | cut -c1-215
+done; done > $O/${R}_reset_spacing_10_vs_80_steps.txt 2>&1
+for T in 32 48 64 96 128; do for t in ClusterColour-TestAll-LoRes4E-v0 MatchRegions-TestCountPlus-LoRes4E-v0; do
+  echo "== MGX_HOST_THREADS=$T $t"; MGX_HOST_THREADS=$T timeout 300 python tools/reset_profile.py $t 2>&1 | grep "steady-state\|under cProfile"
+done; done > $O/${R}_reset_threads_pool.txt 2>&1
 timeout 600 python tools/window20_probe.py 2>&1 | grep -v amdgpu.ids > $O/${R}_window20_probe.txt
 timeout 600 python tools/raster_consistency_sweep.py 2>&1 | tail -20 > $O/${R}_raster_consistency_sweep_tail.txt
 head -30 $O/${R}_step_phase_cycles_mtc.txt
