@@ -1601,6 +1601,38 @@ def test_batched_draws_equal_the_per_env_loop(env_name, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('env_name', ['ClusterColour-TestAll-LoRes4E-v0', 'MatchRegions-TestCountPlus-LoRes4E-v0'])
+def test_per_env_world_resets_back_to_back_equal_a_fresh_reset(env_name):
+    """mgx_engine_set_env_variants returns without waiting for its uploads (the staging buffers are the engine's; the next call
+    waits for the recorded event before it reuses them) and the builds, the placement sampling and the batched draws run on a
+    persistent host pool: three resets issued back to back, nothing in between, must leave the engine where ONE reset of a
+    fresh env leaves it whose streams were put where the first env's streams stood before its third reset -- same worlds,
+    poses, state blobs and first observation, bit for bit -- and the env must then step like it."""
+    import torch
+    n = 2048
+    a = _make(env_name, n); a.seed(17)
+    a.reset(); a.reset()
+    states = [r.get_state() for r in a.rngs]
+    oa = a.reset().clone()
+    torch.cuda.synchronize()
+    b = _make(env_name, n); b.seed(99)
+    for r, st in zip(b.rngs, states):
+        r.set_state(st)
+    ob = b.reset().clone()
+    torch.cuda.synchronize()
+    assert np.array_equal(a.entity_shape_types, b.entity_shape_types) and np.array_equal(a.entity_enabled, b.entity_enabled)
+    assert np.array_equal(a.entity_poses, b.entity_poses) and np.array_equal(a.entity_colours, b.entity_colours)
+    assert torch.equal(a.state_p, b.state_p) and torch.equal(a.state_f, b.state_f) and torch.equal(a.state_i, b.state_i)
+    assert torch.equal(oa, ob)
+    tape = _tape(5, 6, n)
+    for t in range(6):
+        xa, _, _, _ = a.step(tape[t]); xb, _, _, _ = b.step(tape[t])
+    assert torch.equal(xa, xb) and torch.equal(a.state_p, b.state_p)
+    assert all(x.randint(1 << 30) == y.randint(1 << 30) for x, y in zip(a.rngs, b.rngs))
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_fused_step_schedules_are_interchangeable():
     """The switches that change HOW the fused env-step is issued (the join on the rasteriser's own completion signal / on a marker
     event behind it; the two kernels one after the other; the step launch's envs in index order instead of costliest first, round 4)
