@@ -307,7 +307,9 @@ static int host_threads(bool allocating = true) {
     // MGX_PLACE_THREADS (placement alone) still exists and defaults to MGX_HOST_THREADS; a pool larger than a burst wakes threads for nothing.
     static const int cap = [] { const char *v = getenv("MGX_HOST_THREADS"); const int c = v ? atoi(v) : 64; return c < 1 ? 1 : (c > 256 ? 256 : c); }();
     static const int cap_place = [] { const char *v = getenv("MGX_PLACE_THREADS"); const int c = v ? atoi(v) : cap; return c < 1 ? 1 : (c > 256 ? 256 : c); }();
-    const int hw = (int)std::thread::hardware_concurrency(), c = allocating ? cap : cap_place;
+    // (one process per GPU: the ranks of a node share its cores -- torchrun's LOCAL_WORLD_SIZE says how many there are)
+    static const int ranks_here = [] { const char *v = getenv("LOCAL_WORLD_SIZE"); const int r = v ? atoi(v) : 1; return r < 1 ? 1 : r; }();
+    const int hw = (int)std::thread::hardware_concurrency() / ranks_here, c = allocating ? cap : cap_place;
     return hw < 1 ? 1 : (hw > c ? c : hw);
 }
 // A few persistent host threads for the batch work of a reset (world builds, placement sampling): a reset of 4096 per-env worlds is
