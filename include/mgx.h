@@ -194,7 +194,9 @@ int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world)
 /* the worlds of the m envs env_idx[k] (HOST arrays): enabled[m][n_entities] (NULL: as in the engine's world),
  * shape_types[m][n_entities] (mgx_shape_type; NULL or < 0: as in the engine's world; ignored for non-blocks).
  * Builds / shares the variants, uploads their templates in stream order; call before the reset of those envs.
- * Returns the number of distinct worlds in the call (>= 0). */
+ * Returns the number of distinct worlds in the call (>= 0).  The uploads are enqueued on `stream` and not waited for (like every
+ * other call's device work: later calls on the same stream see the new worlds); the arguments are copied before the call returns, and
+ * the next mgx_engine_set_env_variants / mgx_engine_destroy waits for the uploads before the engine's staging buffers are reused. */
 int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, const uint8_t *enabled, const int32_t *shape_types, void *stream);
 /* mgx_world_randomise_all_poses_batch with env env_idx[k] placed in ITS world */
 int mgx_engine_env_randomise_all_poses_batch(const mgx_engine *e, int m, const int32_t *env_idx, double *poses, const int *ents, int n,
