@@ -1261,17 +1261,20 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         }
     }
     tm[ti++] = now();
-    // the staging buffer holds every distinct world's blobs back to back; no blob is larger than the capacity world's
-    // (sized for one world per env from the start: the number of distinct worlds differs from reset to reset, and every regrowth would
-    // be another pinned allocation of a few hundred MB)
-    const size_t stage_bound = std::max(uniq.size(), (size_t)e->n_envs) * ((size_t)e->step_stride + (size_t)e->raster_stride);
-    if (stage_bound > 0x7fffffffull) return fail(MGX_ERR_CAPACITY, "too many distinct worlds in one call");
+    // the staging buffer holds every distinct world's blobs back to back; no blob is larger than the capacity world's, so this call needs
+    // at most (distinct worlds) x (both strides) words -- and its word offsets are int32 (BlobMeta::off_s / off_r): that is what the
+    // 2^31 check is about.  The buffer grows geometrically up to one world per env (a whole-batch reset of a crowded task reaches that
+    // at once; a one-env auto-reset pins one world's worth, not the batch's: 160 MB for 4096 Cluster worlds, GBs at 64k envs)
+    const size_t per_world = (size_t)e->step_stride + (size_t)e->raster_stride;
+    const size_t stage_need = uniq.size() * per_world;
+    if (stage_need > 0x7fffffffull) return fail(MGX_ERR_CAPACITY, "too many distinct worlds in one call (staging offsets are 32-bit words): split the call");
     // (pinned staging: a pageable copy of this size -- 160 MB for 4096 distinct Cluster worlds -- would dominate the reset)
-    if (e->h_stage_words < stage_bound) {
+    if (e->h_stage_words < stage_need) {
+        const size_t cap = std::max(stage_need, std::min(2 * e->h_stage_words, (size_t)e->n_envs * per_world));
         if (e->h_stage) (void)hipHostFree(e->h_stage);
         e->h_stage = nullptr; e->h_stage_words = 0;
-        HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&e->h_stage), stage_bound * 4 + 4096, hipHostMallocDefault));
-        e->h_stage_words = stage_bound + 1024;
+        HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&e->h_stage), cap * 4 + 4096, hipHostMallocDefault));
+        e->h_stage_words = cap + 1024;
     }
     uint32_t *host = e->h_stage;
     std::atomic<size_t> cursor{0};
@@ -1335,6 +1338,13 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
         e->stage_idx_n = rows.size();
     }
     hipStream_t st = (hipStream_t)stream;
+    // From the first asynchronous copy on, the engine's staging buffers are being read by the DMA engine: WHATEVER path leaves this
+    // function (an error return between two enqueues included) records the event behind what has been enqueued and marks the uploads
+    // pending, so that the next call / mgx_engine_destroy waits before it reuses or frees them (advisor, round 4)
+    struct PendingGuard {
+        mgx_engine *e; hipStream_t st;
+        ~PendingGuard() { if (hipEventRecord(e->ev_variants, st) == hipSuccess) e->variants_pending = true; else (void)hipStreamSynchronize(st); }
+    } pending_guard{e, st};
     HIP_OK(hipMemcpyAsync(e->d_stage, host, total * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(e->d_stage_idx, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_place_blobs, dim3(m), dim3(256), 0, st, e->d_step, (long)e->step_stride, e->d_raster, (long)e->raster_stride, e->d_stage, e->d_stage_idx);
@@ -1366,8 +1376,8 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     hipLaunchKernelGGL(k_scatter_ent_rows, dim3(m), dim3(64), 0, st, e->d_ent_type_env, e->d_ent_present_env, e->d_v_ty, e->d_v_on, (const int32_t *)e->d_v_idx, ne, (long)e->n_envs);
     HIP_OK(hipGetLastError());
     // (no wait here: the copies and the two small kernels run while the caller goes on to the placement sampling, which is host
-    // work; the staging buffer, the row table and the entity rows are the engine's and stay as they are until the next call)
-    HIP_OK(hipEventRecord(e->ev_variants, st)); e->variants_pending = true;
+    // work; the staging buffer, the row table and the entity rows are the engine's and stay as they are until the next call:
+    // pending_guard records the event when this function returns)
     tm[ti++] = now();
     std::vector<std::shared_ptr<World>> retired(m);      // the envs' previous worlds: freed below, a few threads wide
     for (int k = 0; k < m; k++) {
@@ -1385,16 +1395,23 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     }
     // worlds stay findable by signature for later calls -- where signatures repeat at all: with nearly every env its own world
     // (ClusterColour-TestAll: ~4000 distinct of 4096) the table only cost its inserts and, every few resets, a 10 ms purge
-    if (uniq.size() * 4 <= (size_t)m) for (auto &U : uniq) e->world_by_sig[U.sig] = U.world;
+    // (small calls -- per-env auto-resets -- register theirs too: otherwise a world that is alive in another env is rebuilt every time)
+    if (uniq.size() * 4 <= (size_t)m || m < 64) for (auto &U : uniq) e->world_by_sig[U.sig] = U.world;
     tm[ti++] = now();
     const int n_uniq = (int)uniq.size();
     {
         // a World is a few hundred small allocations, and ~4000 of them retire per reset: they (and this call's blob buffers) are
         // dropped by a detached helper thread while the caller goes on (round 3 freed them here, a few threads wide: 5-14 ms of the
         // call).  The helper owns what it frees -- shared_ptrs and vectors, nothing of the engine.
-        auto *bin_worlds = new std::vector<std::shared_ptr<World>>(std::move(retired));
-        auto *bin_uniq = new std::vector<Uniq>(std::move(uniq));
-        std::thread([bin_worlds, bin_uniq] { delete bin_worlds; delete bin_uniq; }).detach();
+        // A handful of worlds (per-env auto-resets) are freed here: a thread per call would cost more than the frees.  No exception
+        // crosses the C ABI: if the helper cannot be started (std::system_error) the bins are freed inline.
+        if (m < 64) { retired.clear(); uniq.clear(); }
+        else {
+            auto *bin_worlds = new (std::nothrow) std::vector<std::shared_ptr<World>>(std::move(retired));
+            auto *bin_uniq = new (std::nothrow) std::vector<Uniq>(std::move(uniq));
+            try { std::thread([bin_worlds, bin_uniq] { delete bin_worlds; delete bin_uniq; }).detach(); }
+            catch (...) { delete bin_worlds; delete bin_uniq; }
+        }
     }
     if (e->world_by_sig.size() > (size_t)4 * e->n_envs + 64)
         for (auto it = e->world_by_sig.begin(); it != e->world_by_sig.end();) it = it->second.expired() ? e->world_by_sig.erase(it) : std::next(it);

@@ -108,21 +108,21 @@ __device__ __forceinline__ void step_body(const TmplDev &t, P *__restrict__ sp, 
 #endif
     if (t.order) wg = (int)t.order[wg];
     else if (!t.env_order && (gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
-    long env = (long)wg * EPB + env_local;
-    const bool valid = env < n_envs;
-    if (!valid) env = n_envs - 1;   // tail lanes shadow the last env (no stores) so barriers stay uniform
-    if (t.env_order) {                                  // (position -> env: a permutation of 0 .. n_envs - 1, heaviest first)
 #ifndef MGX_STEP_CU_COLOCATE
 #define MGX_STEP_CU_COLOCATE 1
 #endif
-        // The dispatcher deals workgroups b, b + 256, b + 512, ... onto the SAME CU (round robin over 8 XCDs x 4 SEs x 8 CUs, measured:
-        // tools/dev/placement_probe.py).  A step wavefront that is still running holds 224 registers of its SIMD, and a rasteriser
-        // workgroup needs a wavefront on each of the CU's four SIMDs: ONE late step workgroup costs its CU two of five rasteriser
-        // workgroups.  So the heaviest positions go to workgroups of one CU: the late ones then block a quarter as many CUs.
-        int pos_wg = wg;
-        if (MGX_STEP_CU_COLOCATE && (gridDim.x & 255) == 0) pos_wg = (wg & 255) * (int)(gridDim.x >> 8) + (wg >> 8);
-        env = (long)t.env_order[valid ? (long)pos_wg * EPB + env_local : env];
-    }
+    // The dispatcher deals workgroups b, b + 256, b + 512, ... onto the SAME CU (round robin over 8 XCDs x 4 SEs x 8 CUs, measured:
+    // tools/dev/placement_probe.py).  A step wavefront that is still running holds 224 registers of its SIMD, and a rasteriser
+    // workgroup needs a wavefront on each of the CU's four SIMDs: ONE late step workgroup costs its CU two of five rasteriser
+    // workgroups.  So the heaviest positions of the cost-sorted env order go to workgroups of one CU: the late ones then block a
+    // quarter as many CUs.
+    int pos_wg = wg;
+    if (t.env_order && MGX_STEP_CU_COLOCATE && (gridDim.x & 255) == 0) pos_wg = (wg & 255) * (int)(gridDim.x >> 8) + (wg >> 8);
+    // validity follows from the POSITION this lane serves, whatever permutation produced it (advisor, round 4)
+    long env = (long)pos_wg * EPB + env_local;
+    const bool valid = env < n_envs;
+    if (!valid) env = n_envs - 1;   // tail lanes shadow another env (no stores) so barriers stay uniform
+    if (t.env_order) env = (long)t.env_order[env];      // (position -> env: a permutation of 0 .. n_envs - 1, heaviest first)
     // the template in LDS.  Per-env worlds run one env per workgroup (L = 64), so the copy -- this env's own -- is still
     // shared by all lanes and every template address stays wave-uniform
     const bool per_env = L == 64 && t.tmpl_stride_words != 0;

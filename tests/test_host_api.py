@@ -38,6 +38,30 @@ def test_registry_names_equal_the_reference_source():
     assert base_names <= set(m.ALL_REGISTERED_ENVS)
 
 
+def test_package_top_level_names_are_the_references(tmp_path):
+    """`import magical_amd as magical` offers every name magical/__init__.py:2-8 exports, and the demo-file helpers behave as the
+    reference's do (saved_trajectories.py:52-60: the preprocessor name goes before the version; reference_demos.py:27-33: a
+    directory that holds the download marker is accepted as it is)."""
+    import magical_amd as magical
+    ref_names = ['ALL_REGISTERED_ENVS', 'AVAILABLE_PREPROCESSORS', 'DEMO_ENVS_TO_TEST_ENVS_MAP', 'register_envs', 'try_download_demos',
+                 'load_demos', 'preprocess_demos_with_wrapper', 'splice_in_preproc_name', '__version__']
+    if os.path.isdir('/root/reference/magical'):         # (build container only: the list above is what the reference's source says)
+        import ast
+        tree = ast.parse(open('/root/reference/magical/__init__.py').read())
+        imported = {a.asname or a.name for node in tree.body if isinstance(node, ast.ImportFrom) for a in node.names}
+        assert imported == set(ref_names), imported ^ set(ref_names)
+    for name in ref_names:
+        assert hasattr(magical, name) and name in magical.__all__, name
+    assert magical.splice_in_preproc_name('MoveToCorner-Demo-v0', 'LoRes4E') == 'MoveToCorner-Demo-LoRes4E-v0'
+    from magical_amd import saved_trajectories as st
+    assert magical.load_demos is st.load_demos and magical.preprocess_demos_with_wrapper is st.preprocess_demos_with_wrapper
+    from magical_amd.reference_demos import DONE_FILE, DownloadError
+    with pytest.raises(DownloadError):
+        magical.try_download_demos(str(tmp_path / 'demos'))           # nothing is fetched (no networking in this engine) ...
+    (tmp_path / 'have').mkdir(); (tmp_path / 'have' / DONE_FILE).write_text('x')
+    assert magical.try_download_demos(str(tmp_path / 'have')) is None      # ... a directory the reference has filled is taken as it is
+
+
 def test_action_table():
     from magical_amd import entities as en
     A = en.RobotAction

@@ -81,4 +81,9 @@ for k, m in merged.items():
                 der[n.lower()[3:] + '_per_wave'] = g(n) / g('SQ_WAVES')
     out['derived'] = der
     res[k] = out
+# the stamp bench.py checks before it quotes this file: the kernel sources these counters were measured on (tools/csrc_hash.py)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.csrc_hash import csrc_sha16
+res['_stamp'] = {'csrc_sha16': csrc_sha16()}
 print(json.dumps(res, indent=1))

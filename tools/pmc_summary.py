@@ -28,4 +28,9 @@ for k in ('k_raster', 'k_step'):
 if 'fill_u8' in write:
     res['calibration'] = {'kernel': 'at::native FillFunctor<unsigned char> over the [N,96,96,12] u8 tensor',
                           'WRITE_SIZE_bytes': max(write['fill_u8'])}
+# the stamp bench.py checks before it quotes this file: the kernel sources these counters were measured on (tools/csrc_hash.py)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.csrc_hash import csrc_sha16
+res['_stamp'] = {'csrc_sha16': csrc_sha16()}
 print(json.dumps(res, indent=1))

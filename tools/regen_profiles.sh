@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-measure the round's profile set on the GPU box (run through gpurun from the repo root:
 #   gpurun --timeout 3600 -- 'bash tools/regen_profiles.sh r03'); results land in gpurun_out/final/, to be copied into profiles/.
-R=${1:-r04}
+R=${1:-r05}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/final; rm -rf $O; mkdir -p $O
@@ -70,7 +70,7 @@ for f in sorted(glob.glob('*kernel_stats.csv')):
     for r in csv.DictReader(open(f)):
         if 'mgx::' in r['Name']: print(f[:40], r['Name'][10:36], r['Calls'], r['AverageNs'])
 for f in sorted(glob.glob('*pmc_traffic*.json')):
-    d=json.load(open(f)); print(f, {k:(round(v['FETCH_SIZE_x2_bytes']/1e6,1), round(v['WRITE_SIZE_bytes_median']/1e6,1), round(v['hbm_traffic_bytes_per_launch']/1e6,1)) for k,v in d.items() if k!='calibration'})
+    d=json.load(open(f)); print(f, {k:(round(v['FETCH_SIZE_x2_bytes']/1e6,1), round(v['WRITE_SIZE_bytes_median']/1e6,1), round(v['hbm_traffic_bytes_per_launch']/1e6,1)) for k,v in d.items() if k not in ('calibration', '_stamp')})
 PY
 cat ${R}_task_step_times.txt; wc -l ${R}_rollout_all_60_variants_4096x1gpu.jsonl
 # development builds (python -c "import os; from magical_amd import _native; r = os.getcwd();
