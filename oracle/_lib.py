@@ -71,6 +71,8 @@ def lib():
         'ref_episode_steps': (_I, [_P]),
         'ref_render': (None, [_P, _I, _I, C.c_void_p]),
         'ref_area_downsample': (None, [C.c_void_p, _I, _I, _I, C.c_void_p]),
+        'ref_set_unknowns': (None, [_I]),          # sensitivity study only (tools/oracle_unknowns.py)
+        'ref_get_unknowns': (_I, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

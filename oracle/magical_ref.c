@@ -162,6 +162,26 @@ typedef struct {
     int gjk_warm;   /* use cached GJK ids like Chipmunk (1) or cold start (0) */
 } World;
 
+/* ------------------------------------------------------------ unknowns (sensitivity study only)
+ *
+ * The choices this restatement makes "from recollection" where the third-party engines cannot be consulted (header: PARITY
+ * UNPINNED).  tools/oracle_unknowns.py flips them one at a time and measures what moves (profiles/r05_oracle_unknowns_sensitivity.txt,
+ * DESIGN.md section 6).  Process-global, default 0 = the oracle as every test uses it; never set by tests/, smoke() or bench.py. */
+enum {
+    UNK_ARB_DESCENDING = 1,    /* arbiters solved in descending (shape_i, shape_j) order instead of ascending (Chipmunk: BBTree order) */
+    UNK_PERSISTENCE_1 = 2,     /* collision_persistence 1 instead of Chipmunk's documented default 3 */
+    UNK_PERSISTENCE_5 = 4,     /* ... 5 */
+    UNK_MATCH_BY_INDEX = 8,    /* cached contact impulses matched by point index instead of by feature hash (cpArbiterUpdate) */
+    UNK_NO_WARM_CONTACTS = 16, /* cached contact impulses never carried over */
+    UNK_POLY_RADIUS = 32,      /* polygons bevelled by 1e-3 instead of pymunk's documented default radius 0 */
+    UNK_FILL_EXCLUSIVE = 64,   /* a sample exactly ON a polygon edge is outside (GL: top-left rule; here: inclusive) */
+    UNK_RESIZE_HALF_UP = 128,  /* INTER_AREA block mean rounded half up instead of cvRound's ties-to-even */
+    UNK_GJK_COLD = 256,        /* narrowphase started cold every step instead of from the arbiter's cached feature pair */
+};
+static int g_unknowns = 0;
+void ref_set_unknowns(int flags) { g_unknowns = flags; }
+int ref_get_unknowns(void) { return g_unknowns; }
+
 /* ------------------------------------------------------------ world build */
 
 World *ref_new(void) {
@@ -169,7 +189,7 @@ World *ref_new(void) {
     w->iterations = 10;
     w->collision_slop = 0.1;               /* Chipmunk default; reference overrides to 0.01 */
     w->collision_bias = pow(1.0 - 0.1, 60.0);
-    w->collision_persistence = 3;
+    w->collision_persistence = 3;          /* (UNK_PERSISTENCE_*: read at step time) */
     w->damping = 1.0;
     w->robot_body = w->control_body = -1;
     w->gjk_warm = 1;
@@ -240,7 +260,7 @@ int ref_add_circle(World *w, int body, double radius, double friction, int group
 }
 int ref_add_poly(World *w, int body, int n, const double *xy, double radius, double friction, int group, int sensor) {
     Shape *s = &w->shapes[w->nshapes]; memset(s, 0, sizeof(*s));
-    s->type = SH_POLY; s->body = body; s->r = radius;
+    s->type = SH_POLY; s->body = body; s->r = radius + ((g_unknowns & UNK_POLY_RADIUS) && !sensor ? 1e-3 : 0.0);
     poly_set_verts(s, n, xy);
     s->u = friction; s->group = group; s->sensor = sensor;
     return w->nshapes++;
@@ -613,7 +633,7 @@ static void collide_pair(World *w, int i, int j) {
     Arbiter *arb = arb_find(w, i, j);
     CollisionInfo info; memset(&info, 0, sizeof(info));
     info.id = arb ? arb->gjk_id : 0;
-    collide(&w->shapes[sa], &w->shapes[sb], &info, w->gjk_warm);
+    collide(&w->shapes[sa], &w->shapes[sb], &info, w->gjk_warm && !(g_unknowns & UNK_GJK_COLD));
     if (info.count == 0) { if (arb) arb->gjk_id = info.id; return; }
     if (!arb) { arb = arb_alloc(w); if (!arb) return; arb->key_lo = i; arb->key_hi = j; arb->state = ARB_FIRST; arb->count = 0; }
     arb->gjk_id = info.id;
@@ -623,6 +643,8 @@ static void collide_pair(World *w, int i, int j) {
         memset(&nc[k], 0, sizeof(Contact));
         nc[k].r1 = vsub(info.p1[k], A->p); nc[k].r2 = vsub(info.p2[k], B->p);
         nc[k].hash = info.hash[k];
+        if (g_unknowns & UNK_NO_WARM_CONTACTS) continue;
+        if (g_unknowns & UNK_MATCH_BY_INDEX) { if (k < arb->count) { nc[k].jn_acc = arb->c[k].jn_acc; nc[k].jt_acc = arb->c[k].jt_acc; } continue; }
         for (int q = 0; q < arb->count; q++)
             if (arb->c[q].hash == nc[k].hash) { nc[k].jn_acc = arb->c[q].jn_acc; nc[k].jt_acc = arb->c[q].jt_acc; }
     }
@@ -819,13 +841,15 @@ void ref_space_step(World *w, double dt) {
             Arbiter *arb = arb_find(w, i, j);
             if (arb && arb->active) { w->order[w->norder++] = (int)(arb - w->arbs); }
         }
+    if (g_unknowns & UNK_ARB_DESCENDING)
+        for (int lo = 0, hi = w->norder - 1; lo < hi; lo++, hi--) { int tmp = w->order[lo]; w->order[lo] = w->order[hi]; w->order[hi] = tmp; }
     /* 3. cache filter (cpSpaceArbiterSetFilter) */
     for (int i = 0; i < MAX_ARB; i++) {
         Arbiter *arb = &w->arbs[i];
         if (!arb->used) continue;
         int ticks = w->stamp - arb->stamp;
         if (ticks >= 1 && arb->state != ARB_CACHED) arb->state = ARB_CACHED;
-        if (ticks >= w->collision_persistence) arb->used = 0;
+        if (ticks >= ((g_unknowns & UNK_PERSISTENCE_1) ? 1 : ((g_unknowns & UNK_PERSISTENCE_5) ? 5 : w->collision_persistence))) arb->used = 0;
     }
     /* 4. prestep arbiters then joints */
     double slop = w->collision_slop;
@@ -1097,7 +1121,8 @@ void ref_render(const World *w, int view, int res, unsigned char *out) {
                 int inside = 1;
                 for (int i = 0; i < n && inside; i++) {
                     v2 a = sv[i], b = sv[(i + 1) % n];
-                    if (sgn * vcross(vsub(b, a), vsub(p, a)) < 0.0) inside = 0;
+                    double ef = sgn * vcross(vsub(b, a), vsub(p, a));
+                    if (ef < 0.0 || ((g_unknowns & UNK_FILL_EXCLUSIVE) && ef == 0.0)) inside = 0;
                 }
                 if (inside) { unsigned char *o = out + 3 * ((res - 1 - py) * res + px); o[0] = col[0]; o[1] = col[1]; o[2] = col[2]; }
             }
@@ -1139,6 +1164,6 @@ void ref_area_downsample(const unsigned char *in, int res_in, int factor, int ch
         for (int dy = 0; dy < factor; dy++) for (int dx = 0; dx < factor; dx++)
             sum += in[((y * factor + dy) * res_in + (x * factor + dx)) * channels + c];
         double v = (double)sum / (double)area;
-        out[(y * res_out + x) * channels + c] = (unsigned char)nearbyint(v);
+        out[(y * res_out + x) * channels + c] = (unsigned char)((g_unknowns & UNK_RESIZE_HALF_UP) ? floor(v + 0.5) : nearbyint(v));
     }
 }
