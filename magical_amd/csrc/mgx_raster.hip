@@ -248,7 +248,11 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
         if (run == rem) {
             // the primitive (or one convex part of it) is complete: verdict for this lane's block
             const bool open = !st.decided;
-            const bool touch = kind == IT_SEG ? lo >= 0.0f : !(lo < -1.0f);
+            // (one compare against a wave-uniform threshold: `lo` is never NaN -- finite coefficients at finite coordinates --, so
+            // lo >= 0 for a line loop and !(lo < -1) for the others are both lo >= thr; six vector instructions less per primitive
+            // than selecting between the two compares' results)
+            const float thr = __builtin_bit_cast(float, kind == IT_SEG ? 0u : 0xBF800000u);
+            const bool touch = lo >= thr;
             const bool all = kind != IT_SEG && lo > 1.0f;
             const bool mix = open && touch && !all, cover = open && touch && all;
             const uint64_t bit = 1ull << k;
