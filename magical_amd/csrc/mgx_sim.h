@@ -243,10 +243,16 @@ template <typename R, typename P> MGX_HD void ph_shapes(Env<R, P> &e, int lane, 
 // overlapping pairs compacted IN PAIR ORDER (= arbiter solve order).  Device: the group's lanes test nl consecutive pairs at a
 // time; a wavefront ballot gives every lane the hits of its group, so a pair's place in the list is the running total plus the
 // hits of the lanes before it -- one phase, no LDS counters, no flags (round 2 counted per lane chunk, synchronised, then wrote).
-template <typename R, typename P> MGX_HD bool pair_boxes_overlap(const Env<R, P> &e, int p) {
-    const int pr = T_I(pair, p), a = pr & 0xFF, b = pr >> 8;
-    return E_R(bbl, a) <= E_R(bbr, b) && E_R(bbl, b) <= E_R(bbr, a) && E_R(bbb, a) <= E_R(bbt, b) && E_R(bbb, b) <= E_R(bbt, a);
+template <typename R, typename P> MGX_HD bool boxes_overlap(const Env<R, P> &e, int pr) {
+    const int a = pr & 0xFF, b = pr >> 8;
+    // (both boxes read before the first compare, the four results combined without short circuit: `&&` made four dependent LDS round
+    // trips of them -- read two sides, compare, branch, read the next two -- on a wavefront with nothing else to run.  Round 5:
+    // FindDupe's k_step 0.382 -> 0.365 ms, ClusterColour's 0.480 -> 0.471, profiles/r05_step_broadphase_ab.txt)
+    const R la = E_R(bbl, a), ba = E_R(bbb, a), ra = E_R(bbr, a), ta = E_R(bbt, a);
+    const R lb = E_R(bbl, b), bb = E_R(bbb, b), rb = E_R(bbr, b), tb = E_R(bbt, b);
+    return (la <= rb) & (lb <= ra) & (ba <= tb) & (bb <= ta);
 }
+template <typename R, typename P> MGX_HD bool pair_boxes_overlap(const Env<R, P> &e, int p) { return boxes_overlap(e, T_I(pair, p)); }
 template <typename R, typename P> MGX_HD void ph_broad(Env<R, P> &e, int lane, int nl) {
     const int np = e.h->n_pairs, cap = e.h->max_overlaps;
     int total = 0;
@@ -255,9 +261,12 @@ template <typename R, typename P> MGX_HD void ph_broad(Env<R, P> &e, int lane, i
     const int wave_lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int shift = wave_lane - lane;
     const unsigned long long group_mask = nl >= 64 ? ~0ull : ((1ull << nl) - 1ull);
+    // (the next round's pairs are read while this round's boxes are: one dependent LDS round trip per round instead of two)
+    int pr_next = lane < np ? T_I(pair, lane) : 0;
     for (int base = 0; base < np; base += nl) {
-        const int p = base + lane;
-        const bool hit = p < np && pair_boxes_overlap(e, p);
+        const int p = base + lane, pr = pr_next;
+        pr_next = p + nl < np ? T_I(pair, p + nl) : 0;
+        const bool hit = boxes_overlap(e, pr) & (p < np);
         const unsigned long long hits = (__builtin_amdgcn_ballot_w64(hit) >> shift) & group_mask;
         const int pos = total + __builtin_popcountll(hits & ((1ull << lane) - 1ull));
         if (hit && pos < cap) E_I(ov, pos) = p;
