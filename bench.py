@@ -65,7 +65,7 @@ def kernel_resources():
     return _RESOURCES
 
 
-def scratch_bytes(kernel, n_envs, lanes_per_env, dtype='f32', raster_lds=None, layout=1):
+def scratch_bytes(kernel, n_envs, lanes_per_env, dtype='f32', raster_lds=None, layout=1, narrow=True):
     """Static scratch footprint of one launch: private segment bytes per lane x lanes launched (step: n_envs x lanes_per_env;
     raster: 256 per env) of the instantiation this workload runs -- k_step<R,P,L> / k_step_wide (all-fp64) / k_step_env (one env per
     wavefront); k_raster<P,LAYOUT,WAVES> with WAVES from the LDS footprint as the host picks it; None if the code object cannot be read."""
@@ -75,7 +75,7 @@ def scratch_bytes(kernel, n_envs, lanes_per_env, dtype='f32', raster_lds=None, l
         want = ('k_step_envI%sE' % rp) if lanes_per_env == 64 else (('k_step_wideI%sLi%dE' if dtype == 'f64' else 'k_stepI%sLi%dE') % (rp, lanes_per_env))
     else:
         fit = 5 if not raster_lds else max(3, min(5, (160 * 1024) // ((int(raster_lds) + 511) // 512 * 512)))
-        want = 'k_rasterI%sLi%dELi%dE' % (rp[1], layout, fit)
+        want = 'k_rasterI%sLi%dELi%dE%s' % (rp[1], layout, fit, 'm' if narrow is False else 'j')      # (j / m: 32- / 64-bit primitive sets)
     for name, r in res.items():
         if want in name and 'deferred' not in name:
             return r['scratch_bytes_per_lane'] * (n_envs * lanes_per_env if kernel == 'k_step' else n_envs * 256)

@@ -556,11 +556,20 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     // another round like any other)
     int n_goals_w = 0, n_blocks_w = 0;
     for (const auto &en : e->w.entities) { n_goals_w += en.kind == 2; n_blocks_w += en.kind == 1; }
-    const int qcap_lds = (!e->env_worlds && n_goals_w == 0 && n_blocks_w <= 1 && !getenv("MGX_QCAP_FULL")) ? QCAP_SMALL : QCAP;
+    // primitive sets as 32-bit words where no world the engine holds has more than 32 primitives (every Demo / Jitter / Colour / Layout /
+    // Dynamics world; per-env worlds are sized by their capacity world and stay at 64): half the words of the pixel queue and of the
+    // per-tile sets -- 8 KB of ClusterColour's 40 KB, a FIFTH rasteriser workgroup per CU for the mid-size worlds
+    const bool narrow = !e->env_worlds && e->h.n_prims <= 32 && !getenv("MGX_RASTER_WIDE");
+    e->rdev.narrow = narrow ? 1 : 0;
+    const int mw = narrow ? 1 : 2;      // words per primitive set
+    const int qcap_lds = (narrow && n_goals_w == 0 && n_blocks_w <= 1 && !getenv("MGX_QCAP_FULL")) ? QCAP_SMALL : QCAP;
     e->rdev.qcap_lds = qcap_lds;
     // (the layout may grow when per-env worlds are enabled: the entries in use follow it, unless a test has set them)
     e->rdev.qcap = e->qcap_debug > 0 && e->qcap_debug < qcap_lds ? e->qcap_debug : qcap_lds;
-    const int extra = N_TILES * 3 + qcap_lds * 4 + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2;
+    // per-tile (set + i32 base colour + u8 base index) + queue (set + i32 position | base index) + counters + overflow bitmap + phase E
+    // records (u64 sums, u16 entry); phase C's partial verdicts (4 x 144 x 2 mw words) lie in the queue's arrays
+    const int extra = N_TILES * (mw + 1) + N_TILES / 4 + qcap_lds * (mw + 1) + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2 + 16;      // (+ 16: the wavefront table)
+    static_assert(4 * N_TILES * 2 <= QCAP_SMALL * 2 && 4 * N_TILES * 4 <= QCAP * 3, "phase C's partial verdicts fit the pixel queue's arrays");
     // As many rasteriser workgroups per CU as LDS allows (allocations round up to 512 B), between 3 and 5; a step is worth 13-15 % of
     // the launch.  Two economies are taken only where they buy such a step, the cheaper one first:
     //  - the draw list's fp64 part (local vertices, radii: read once per frame, by the set-up) stays in HBM instead of being staged
@@ -573,12 +582,12 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
         const int fit = (int)((size_t)MAX_LDS_BYTES / ((lds + 511) & ~(size_t)511));
         return fit > 5 ? 5 : fit;
     };
-    // (a fifth workgroup means the 96-register variant, whose edge-by-edge polygon coverage is slow on stars, §3.2: worlds that can
-    // hold multi-part polygons do not economise their way to it -- MatchRegions 1.115 -> 1.154 ms per env-step when they did, while
-    // FixColour, which has none, gains: 1.188 -> 1.126)
+    // (rounds 2-4 kept worlds with multi-part polygons at four workgroups per CU: the 96-register variant's coverage code was slow on
+    // stars then.  With the two-pass coverage in every variant and 32-bit primitive sets the fifth workgroup pays there too:
+    // ClusterColour 3.99 -> 4.21 M env-steps/s, ClusterShape 3.90 -> 4.11, MakeLine 5.16 -> 5.59 (MGX_RASTER_CAP4=1: the old rule))
     bool stars = e->env_worlds;
     for (const auto &pr : e->w.prims) stars = stars || pr.parts.size() > 1;
-    const int cap = stars ? 4 : 5;
+    const int cap = (stars && getenv("MGX_RASTER_CAP4")) ? 4 : 5;
     bool tq_hbm = false, compact = false;
     if (!getenv("MGX_RASTER_STORED")) {
         int best = raster_fit(false, false);
@@ -911,8 +920,11 @@ static int launch_raster(mgx_engine *e, const void *sp, uint8_t *out, int64_t en
     };
     auto by_layout = [&](auto waves) -> int {
         constexpr int W = decltype(waves)::value;
-        return layout == MGX_OBS_FRAME ? go(k_raster<P, 0, W>) : layout == MGX_OBS_STACK4 ? go(k_raster<P, 1, W>)
-             : layout == MGX_OBS_STACK3_HI ? go(k_raster<P, 2, W>) : layout == MGX_OBS_SLOT_LO ? go(k_raster<P, 3, W>) : go(k_raster<P, 4, W>);
+        if (e->rdev.narrow)
+            return layout == MGX_OBS_FRAME ? go(k_raster<P, 0, W, uint32_t>) : layout == MGX_OBS_STACK4 ? go(k_raster<P, 1, W, uint32_t>)
+                 : layout == MGX_OBS_STACK3_HI ? go(k_raster<P, 2, W, uint32_t>) : layout == MGX_OBS_SLOT_LO ? go(k_raster<P, 3, W, uint32_t>) : go(k_raster<P, 4, W, uint32_t>);
+        return layout == MGX_OBS_FRAME ? go(k_raster<P, 0, W, uint64_t>) : layout == MGX_OBS_STACK4 ? go(k_raster<P, 1, W, uint64_t>)
+             : layout == MGX_OBS_STACK3_HI ? go(k_raster<P, 2, W, uint64_t>) : layout == MGX_OBS_SLOT_LO ? go(k_raster<P, 3, W, uint64_t>) : go(k_raster<P, 4, W, uint64_t>);
     };
     int rc = e->raster_waves >= 5 ? by_layout(std::integral_constant<int, 5>{})
            : e->raster_waves == 4 ? by_layout(std::integral_constant<int, 4>{}) : by_layout(std::integral_constant<int, 3>{});
@@ -929,8 +941,11 @@ static int launch_raster_deferred(mgx_engine *e, const void *sp, uint8_t *out, i
         hipLaunchKernelGGL(kern, dim3(e->n_envs), dim3(256), lds, st, e->rdev, (const P *)sp, out, (long)env_stride, view, e->n_envs, ho);
         return MGX_OK;
     };
-    int rc = layout == MGX_OBS_FRAME ? go(k_raster_deferred<P, 0>) : layout == MGX_OBS_STACK4 ? go(k_raster_deferred<P, 1>)
-           : layout == MGX_OBS_STACK3_HI ? go(k_raster_deferred<P, 2>) : layout == MGX_OBS_SLOT_LO ? go(k_raster_deferred<P, 3>) : go(k_raster_deferred<P, 4>);
+    int rc = e->rdev.narrow
+           ? (layout == MGX_OBS_FRAME ? go(k_raster_deferred<P, 0, uint32_t>) : layout == MGX_OBS_STACK4 ? go(k_raster_deferred<P, 1, uint32_t>)
+              : layout == MGX_OBS_STACK3_HI ? go(k_raster_deferred<P, 2, uint32_t>) : layout == MGX_OBS_SLOT_LO ? go(k_raster_deferred<P, 3, uint32_t>) : go(k_raster_deferred<P, 4, uint32_t>))
+           : (layout == MGX_OBS_FRAME ? go(k_raster_deferred<P, 0, uint64_t>) : layout == MGX_OBS_STACK4 ? go(k_raster_deferred<P, 1, uint64_t>)
+              : layout == MGX_OBS_STACK3_HI ? go(k_raster_deferred<P, 2, uint64_t>) : layout == MGX_OBS_SLOT_LO ? go(k_raster_deferred<P, 3, uint64_t>) : go(k_raster_deferred<P, 4, uint64_t>));
     if (rc) return rc;
     HIP_OK(hipGetLastError());
     return MGX_OK;

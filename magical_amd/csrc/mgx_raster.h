@@ -382,11 +382,18 @@ MGX_HD double lineloop_alpha_masked(const Raster &rs, int k, double x, double y,
     return best;
 }
 
+// Primitive sets are bit masks (bit k = prim k): 64 bits in general, 32 where every world the engine holds has at most 32 primitives
+// (all Demo worlds: half the words of the pixel queue and of the per-tile tables in LDS, one instruction instead of two per mask
+// operation; the host's choice, configure_launch)
+MGX_HD int mask_top(uint64_t m) { return 63 - __builtin_clzll(m); }
+MGX_HD int mask_top(uint32_t m) { return 31 - __builtin_clz(m); }
+MGX_HD int mask_low(uint64_t m) { return __builtin_ctzll(m); }
+MGX_HD int mask_low(uint32_t m) { return __builtin_ctz(m); }
 // one 384-grid sample, painter's order over the primitives in `mask` (bit k = prim k), starting from `base_rgb`
-MGX_HD int raster_sample(const Raster &rs, double x, double y, uint64_t mask, int base_rgb) {
+template <typename M> MGX_HD int raster_sample(const Raster &rs, double x, double y, M mask, int base_rgb) {
     int r = base_rgb & 0xFF, g = (base_rgb >> 8) & 0xFF, b = (base_rgb >> 16) & 0xFF;
     while (mask) {
-        int k = __builtin_ctzll(mask);
+        int k = mask_low(mask);
         mask &= mask - 1;
         int kind = rs.prim_kind(k), col = rs.prim_rgb(k);
         if (kind == PR_LINELOOP) {
@@ -411,11 +418,11 @@ MGX_HD int raster_total_items(const Raster &rs) {
 MGX_HD Item load_item(const Raster &rs, int idx) { return reinterpret_cast<const Item *>(&RI(items, 0))[idx]; }
 
 // item index of `slot` in the concatenation (front to back) of the items of the prims in `mask`; -1 past the end
-MGX_HD int masked_item_index(const Raster &rs, uint64_t mask, int slot, int &n_total) {
+template <typename M> MGX_HD int masked_item_index(const Raster &rs, M mask, int slot, int &n_total) {
     int acc = 0, found = -1;
     while (mask) {
-        int k = 63 - __builtin_clzll(mask);
-        mask &= ~(1ull << k);
+        int k = mask_top(mask);
+        mask &= ~(M(1) << k);
         int pi = RI(pitem, k), start = pi & 0xFFFF, cnt = pi >> 16;
         if (slot >= acc && slot < acc + cnt) found = start + (slot - acc);
         acc += cnt;
@@ -670,18 +677,18 @@ MGX_HD void lineloop_alpha16(const Raster &rs, int k, int X, int Y, uint32_t seg
 // (Round 3 evaluated the primitives below a line from inside the line's branch -- the coverage code inlined twice -- remembered four of them and
 // tested all sixteen samples against every crossing segment first; the rasteriser's 96-register variant pays for every instruction and every
 // live value of phase Q in spilled registers, and each of the three cuts made it faster: profiles/r04_raster_phase_q_shrink_ab.txt.)
-MGX_HD uint64_t pixel_resolve_fast(const Raster &rs, int X, int Y, uint64_t mixed, int base, uint32_t &uncertain) {
+template <typename M> MGX_HD uint64_t pixel_resolve_fast(const Raster &rs, int X, int Y, M mixed, int base, uint32_t &uncertain) {
     constexpr int MAXL = MGX_Q_MAXL;
     uint32_t remaining = 0xFFFFu, unc = 0;
     int sr = 0, sg = 0, sb = 0;
     int pk = -1;                              // the pending line loop, the samples it claimed, its segments that cross the block
     uint32_t pcov = 0, psegmask = 0, pneed = 0, lunc = 0;
     uint32_t lcov[MAXL]; int lcol[MAXL]; int nlow = 0;
-    uint64_t m = mixed;
-    MGX_RSTAT(0, 1); MGX_RSTAT(1, __builtin_popcountll(mixed));
+    M m = mixed;
+    MGX_RSTAT(0, 1); MGX_RSTAT(1, __builtin_popcountll((uint64_t)mixed));
     while (m && (remaining | pneed)) {
-        const int k = 63 - __builtin_clzll(m);
-        m &= ~(1ull << k);
+        const int k = mask_top(m);
+        m &= ~(M(1) << k);
         const int kind = rs.prim_kind(k);
         if (kind == PR_LINELOOP) {
 #ifdef MGX_Q_NO_LINE      // development probe: ... without the line loops
@@ -764,7 +771,7 @@ MGX_HD int pixel_finish(uint64_t sums) {
     return r | (g << 8) | (b << 16);
 }
 // add the samples in `uncertain` with the fp64 painter (what k_raster_native and the oracle do for every sample)
-MGX_HD uint64_t pixel_add_exact(const Raster &rs, int X, int Y, uint64_t mixed, int base, uint64_t sums, uint32_t uncertain) {
+template <typename M> MGX_HD uint64_t pixel_add_exact(const Raster &rs, int X, int Y, M mixed, int base, uint64_t sums, uint32_t uncertain) {
     for (; uncertain; uncertain &= uncertain - 1) {
         const int sidx = __builtin_ctz(uncertain);
         const double x = 4.0 * X + (sidx & 3) + 0.5, y = (double)NATIVE_RES - 0.5 - 4.0 * Y - (sidx >> 2);
@@ -773,7 +780,7 @@ MGX_HD uint64_t pixel_add_exact(const Raster &rs, int X, int Y, uint64_t mixed, 
     }
     return sums;
 }
-MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, uint64_t mixed, int base) {
+template <typename M> MGX_HD int pixel_resolve(const Raster &rs, int X, int Y, M mixed, int base) {
     uint32_t unc;
     uint64_t sums = pixel_resolve_fast(rs, X, Y, mixed, base, unc);
     if (unc) sums = pixel_add_exact(rs, X, Y, mixed, base, sums, unc);

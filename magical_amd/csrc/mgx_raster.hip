@@ -35,6 +35,7 @@ struct RasterDev {
     int qcap;                      // queue entries in use (<= qcap_lds; tests shrink it to exercise the overflow rounds)
     int qcap_lds;                  // queue entries the LDS layout holds (<= QCAP; the host's choice by world, configure_launch)
     int ecap;                      // phase E records in use (<= ECAP; likewise)
+    int narrow;                    // primitive sets are 32-bit words (every world loaded has <= 32 primitives): the uint32_t instantiations
 };
 
 // Consumer side of the step -> raster hand-off (mgx_engine_step_render; producer: StepHandoff in mgx_step.hip).
@@ -168,13 +169,17 @@ __device__ __forceinline__ void store_frame_px(uint8_t *frame, int X, int Y, int
 
 // masked_item_index for a prim set that is the same in every lane (a tile's): the walk over the set runs on the scalar
 // unit, each lane only compares its slot against the running item count
-__device__ __forceinline__ int masked_item_index_uniform(const Raster &rs, uint64_t mask_v, int slot, int &n_total) {
-    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)mask_v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(mask_v >> 32));
-    uint64_t mask = ((uint64_t)hi << 32) | lo;
+template <typename M> __device__ __forceinline__ M mask_uniform(M v);
+template <> __device__ __forceinline__ uint64_t mask_uniform<uint64_t>(uint64_t v) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+template <> __device__ __forceinline__ uint32_t mask_uniform<uint32_t>(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); }
+template <typename M> __device__ __forceinline__ int masked_item_index_uniform(const Raster &rs, M mask_v, int slot, int &n_total) {
+    M mask = mask_uniform<M>(mask_v);
     int acc = 0, found = -1;
     while (mask) {
-        const int k = 63 - __builtin_clzll(mask);
-        mask &= ~(1ull << k);
+        const int k = mask_top(mask);
+        mask &= ~(M(1) << k);
         const int pi = __builtin_amdgcn_readfirstlane(RI(pitem, k)), start = pi & 0xFFFF, cnt = pi >> 16;
         if (slot >= acc && slot < acc + cnt) found = start + (slot - acc);
         acc += cnt;
@@ -182,6 +187,16 @@ __device__ __forceinline__ int masked_item_index_uniform(const Raster &rs, uint6
     n_total = acc;
     return found;
 }
+
+// The device's classification state: like ClassState (mgx_raster.h), with the covering primitive's INDEX in place of its colour -- the
+// colour is looked up once per tile / pixel at the end instead of once per primitive of the walk, and a queued pixel's entry holds
+// the index (7 bits) beside its position (14), which makes the entry 8 bytes with a 32-bit primitive set.  BK_BG = the background.
+constexpr int BK_BG = 64, BK_TILE = 255;       // (BK_TILE: phase T's walk has met no covering primitive yet -- the tile's own base holds)
+template <typename M> struct PixState {
+    M mixed; int bk; int decided; float lo; int line;
+    __device__ __forceinline__ void init(int bk0) { mixed = 0; bk = bk0; decided = 0; lo = 1e30f; line = 0; }
+};
+__device__ __forceinline__ int rgb_of(const Raster &rs, int bk, int bg_rgb) { return bk >= BK_BG ? bg_rgb : rs.prim_rgb(bk < BK_BG ? bk : 0); }
 
 // v_min_f32 as it is: fminf first canonicalises an operand the compiler cannot prove quiet (NaNs cannot arise where this is used:
 // finite coefficients, finite coordinates)
@@ -205,9 +220,9 @@ struct RegItems {
 // consume items [0, n) held one per lane; stops at a primitive boundary once every lane of the wave is decided.
 // Same arithmetic as classify_item, organised as runs of one primitive's items so that the polygon-edge loop is
 // branch-free (3 broadcasts + 2 fma + 1 min per edge) and the per-primitive verdict is computed without divergence.
-template <bool TILE>
+template <bool TILE, typename M>
 __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegItems &src, int n, float xc, float yc,
-                                                    ClassState &st, bool active) {
+                                                    PixState<M> &st, bool active) {
     auto bc = [&](float v, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); };
     const float hx = TILE ? TILE_HX : 1.5f, hy = TILE ? TILE_HY : 1.5f;
     int i = 0;
@@ -215,7 +230,6 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
         const int meta = __builtin_amdgcn_readlane(src.my.meta, i);
         const int kind = meta & 3, rem = (meta >> IT_REM_SHIFT) & IT_REM_MASK, k = meta >> IT_K_SHIFT;
         const int run = rem < n - i ? rem : n - i;
-        const int rgb = rs.prim_rgb(k);                 // uniform LDS read, issued before the run so that it is free
         float lo = st.lo;
         if (kind == IT_EDGE) {
             for (int j = i; j < i + run; j++) {
@@ -255,10 +269,10 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
             const bool touch = lo >= thr;
             const bool all = kind != IT_SEG && lo > 1.0f;
             const bool mix = open && touch && !all, cover = open && touch && all;
-            const uint64_t bit = 1ull << k;
-            st.mixed |= mix ? bit : 0ull;
+            const M bit = M(1) << k;
+            st.mixed |= mix ? bit : M(0);
             st.line |= (mix && kind == IT_SEG) ? 1 : 0;
-            st.base = cover ? rgb : st.base;
+            st.bk = cover ? k : st.bk;
             st.decided |= cover ? 1 : 0;
             lo = BIG_F;
             st.lo = lo;
@@ -272,9 +286,9 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
 // Phase C's form: NT tiles per lane (144 tiles = 48 lanes x 3), so that every wavefront sees the whole tile grid and the ITEM LIST can be
 // dealt out over the workgroup's four wavefronts instead (mgx_raster_body.inc).  Per item three broadcasts + (2 FMA + 1 min) per tile.
 // Same arithmetic per tile as classify_items_regs<true>; consumes items [0, n) of `src`, which never end inside a convex part.
-template <int NT>
+template <int NT, typename M>
 __device__ __forceinline__ void classify_items_regs_tiles(const Raster &rs, const RegItems &src, int n, const float (&xc)[NT], const float (&yc)[NT],
-                                                          ClassState (&st)[NT], bool active) {
+                                                          PixState<M> (&st)[NT], bool active) {
     auto bc = [&](float v, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); };
     const float hx = TILE_HX, hy = TILE_HY;
     int i = 0;
@@ -282,7 +296,6 @@ __device__ __forceinline__ void classify_items_regs_tiles(const Raster &rs, cons
         const int meta = __builtin_amdgcn_readlane(src.my.meta, i);
         const int kind = meta & 3, rem = (meta >> IT_REM_SHIFT) & IT_REM_MASK, k = meta >> IT_K_SHIFT;
         const int run = rem < n - i ? rem : n - i;
-        const int rgb = rs.prim_rgb(k);
         float lo[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) lo[t] = st[t].lo;
@@ -328,9 +341,9 @@ __device__ __forceinline__ void classify_items_regs_tiles(const Raster &rs, cons
                 const bool touch = kind == IT_SEG ? lo[t] >= 0.0f : !(lo[t] < -1.0f);
                 const bool all = kind != IT_SEG && lo[t] > 1.0f;
                 const bool mix = open && touch && !all, cover = open && touch && all;
-                const uint64_t bit = 1ull << k;
-                st[t].mixed |= mix ? bit : 0ull;
-                st[t].base = cover ? rgb : st[t].base;
+                const M bit = M(1) << k;
+                st[t].mixed |= mix ? bit : M(0);
+                st[t].bk = cover ? k : st[t].bk;
                 st[t].decided |= cover ? 1 : 0;
                 st[t].lo = BIG_F;
                 all_decided = all_decided && st[t].decided;
@@ -343,7 +356,7 @@ __device__ __forceinline__ void classify_items_regs_tiles(const Raster &rs, cons
     }
 }
 
-template <typename P, int LAYOUT, int WAVES>
+template <typename P, int LAYOUT, int WAVES, typename M>
 __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
                                                 long env_stride, int view, const uint8_t *__restrict__ fill_mask, int n_envs, RasterHandoff ho) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -391,7 +404,7 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
     if (!t.tmpl_stride_words) { const int n = raster_staged_words(t, t.words); for (int i = tid; i < n; i += 256) lds[i] = t.words[i]; }
     if (ho.mode) {
         // one lane waits / decides, one agent-scope acquire per workgroup, then plain loads (cdna guide, G16)
-        int32_t *slot = reinterpret_cast<int32_t *>(lds + t.lds_tmpl_words + t.off_tiles) + (N_TILES * 3 + t.qcap_lds * 4 + 5);    // = q_count[5], unused below
+        int32_t *slot = reinterpret_cast<int32_t *>(lds + t.lds_tmpl_words + t.off_tiles) + (N_TILES * (1 + (int)(sizeof(M) / 4)) + N_TILES / 4 + t.qcap_lds * (1 + (int)(sizeof(M) / 4)) + 5);    // = q_count[5], unused below
         if (tid == 0) {
             long got = -1;
             if (ho.mode == 1) {
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
 // variant serves every world).  One workgroup per entry: where several engines share the GPU (the task fleet of BASELINE.json's
 // configs[4]) consumers give up by the hundred, and a launch of 16 workgroups that each walk 256 entries -- tried: no faster when
 // there is nothing to do -- rasterised them one after the other (8 x 1024 envs on one GPU: 3.59 -> 2.74 M env-steps/s)
-template <typename P, int LAYOUT>
+template <typename P, int LAYOUT, typename M>
 __global__ __launch_bounds__(256, 3) void k_raster_deferred(RasterDev t, const P *__restrict__ sp, uint8_t *__restrict__ out,
                                                    long env_stride, int view, int n_envs, RasterHandoff ho) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(256, MGX_RASTER_WAVES) void k_raster_native(RasterD
     if (pix >= NATIVE_RES * NATIVE_RES) return;
     const int col = pix % NATIVE_RES, row = pix / NATIVE_RES;
     const uint64_t all = h->n_prims >= 64 ? ~0ull : ((1ull << h->n_prims) - 1ull);
-    const int c = raster_sample(rs, col + 0.5, (double)(NATIVE_RES - 1 - row) + 0.5, all, t.bg_rgb);
+    const int c = raster_sample<uint64_t>(rs, col + 0.5, (double)(NATIVE_RES - 1 - row) + 0.5, all, t.bg_rgb);
     out[3 * pix] = c & 0xFF; out[3 * pix + 1] = (c >> 8) & 0xFF; out[3 * pix + 2] = (c >> 16) & 0xFF;
 }
 
