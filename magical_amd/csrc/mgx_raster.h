@@ -150,10 +150,16 @@ constexpr int IT_LAST = 4;      // meta bit: last item of its convex part
 // meta = kind | IT_LAST | (items left in the part, this one included) << 3 | prim << 12
 constexpr int IT_REM_SHIFT = 3, IT_REM_MASK = 0x1FF, IT_K_SHIFT = 12;
 struct Item {
+    // (two 16-byte halves: a polygon edge's PIXEL-level classification reads the second one only -- g0 g1 g2 + meta --, its tile-level
+    // one the first -- a b c g3)
     float a, b, c;              // EDGE/SEG: normalised line a x + b y + c;  NGON: centre x, y, apothem
-    float g0, g1, g2, g3;       // EDGE: g0 / g1 = extent over a 4x4 block / a tile;  SEG: start x, y, length, half width;  NGON: g0 = circumradius
-    int meta;                   // kind | IT_LAST | prim << 8
+    float g3;
+    float g0, g1, g2;           // EDGE: g0 .. g2 = edge function over its extent over a 4x4 block, g3 = 1 / extent over a tile;  SEG: start x, y, length, g3 = half width;  NGON: g0 = circumradius
+    int meta;                   // kind | IT_LAST | items left in the part << 3 | prim << 12
 };
+static_assert(sizeof(Item) == 32, "two 16-byte halves");
+// per-primitive word of the item list (RasterOff::pitem): first item | items << 16 | primitive kind << 24 | (several convex parts) << 26
+constexpr int PI_CNT_MASK = 0xFF;
 constexpr int TILE_W = 16, TILE_H = 4, TILES_X = LORES / TILE_W, TILES_Y = LORES / TILE_H;
 constexpr float TILE_HX = 2.0f * TILE_W - 0.5f, TILE_HY = 2.0f * TILE_H - 0.5f;
 
@@ -174,7 +180,8 @@ MGX_HD void raster_setup_prims(Raster &rs, int lane, int nl, const int32_t *env_
         }
         // the prim's slice of the item list: front (top) prims first (the world builder did the sum)
         const int start = rs.prim_item_start(k);
-        RI(pitem, k) = start | (prim_item_count(rs, k) << 16);
+        RI(pitem, k) = start | (prim_item_count(rs, k) << 16) | (rs.prim_kind(k) << 24) |
+                       ((rs.prim_kind(k) == PR_POLY && (rs.prim_ends(k) & ~(1u << (rs.prim_nv(k) - 1))) != 0) ? 1 << 26 : 0);
         const int kind = rs.prim_kind(k);
         if (kind == PR_LINELOOP) RD(prad, k) = rs.prim_r(k, 4);
         if (kind != PR_NGON) continue;
@@ -413,7 +420,7 @@ template <typename M> MGX_HD int raster_sample(const Raster &rs, double x, doubl
 
 MGX_HD int raster_total_items(const Raster &rs) {
     int pi = RI(pitem, 0);                      // prim 0 is the rearmost: its items end the list
-    return (pi & 0xFFFF) + (pi >> 16);
+    return (pi & 0xFFFF) + ((pi >> 16) & PI_CNT_MASK);
 }
 MGX_HD Item load_item(const Raster &rs, int idx) { return reinterpret_cast<const Item *>(&RI(items, 0))[idx]; }
 
@@ -423,7 +430,7 @@ template <typename M> MGX_HD int masked_item_index(const Raster &rs, M mask, int
     while (mask) {
         int k = mask_top(mask);
         mask &= ~(M(1) << k);
-        int pi = RI(pitem, k), start = pi & 0xFFFF, cnt = pi >> 16;
+        int pi = RI(pitem, k), start = pi & 0xFFFF, cnt = (pi >> 16) & PI_CNT_MASK;
         if (slot >= acc && slot < acc + cnt) found = start + (slot - acc);
         acc += cnt;
     }
@@ -493,6 +500,57 @@ MGX_HD void tile_centre(int tile, float &xc, float &yc) {
     xc = 0.5f * (gx0 + gx0 + 4 * TILE_W); yc = 0.5f * (gy0 + gy1 + 1);
 }
 // ---------------------------------------------------------------- resolving an undecided pixel (one lane per pixel)
+// Phase Q's sixteen-sample loops, written for their instruction count (a wavefront's time is its instruction count, and these loops are a
+// quarter of the rasteriser's): a sample's yes / no is the SIGN of a difference, shifted into a bit mask by one v_alignbit_b32 -- instead of
+// compare + select + or -- in reverse sample order (q_rev16 turns the mask round at the end).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float float2_t __attribute__((ext_vector_type(2)));       // (a pair the compiler keeps in two adjacent registers: v_pk_add_f32)
+#else
+struct float2_t { float x, y; };
+inline float2_t operator-(float2_t a, float2_t b) { return {a.x - b.x, a.y - b.y}; }
+inline float2_t &operator+=(float2_t &a, float2_t b) { a.x += b.x; a.y += b.y; return a; }
+#endif
+MGX_HD uint32_t q_push_sign(uint32_t acc, float v) {          // (acc << 1) | (v < 0 or v == -0)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(acc, __builtin_bit_cast(uint32_t, v), 31);
+#else
+    return (acc << 1) | (__builtin_bit_cast(uint32_t, v) >> 31);
+#endif
+}
+MGX_HD uint32_t q_rev16(uint32_t acc) {                         // sixteen pushes: sample q sits at bit 15 - q
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(acc) >> 16;
+#else
+    uint32_t r = 0;
+    for (int q = 0; q < 16; q++) r |= ((acc >> (15 - q)) & 1u) << q;
+    return r;
+#endif
+}
+MGX_HD int q_bit_mask(uint32_t word, uint32_t pos) {            // all ones when bit (pos & 31) of word is set, else 0: one v_bfe_i32
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sbfe((int)word, pos, 1u);
+#else
+    return -(int)((word >> (pos & 31u)) & 1u);
+#endif
+}
+MGX_HD float q_sqrt(float x) {                                  // v_sqrt_f32, 1 ulp (the library's correctly rounded sqrtf is 17 instructions)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+MGX_HD float q_fract(float x) {                                 // x - floor(x), exact for 0 <= x < 2^23
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fractf(x);
+#else
+    return x - floorf(x);
+#endif
+}
+MGX_HD float q_abs(float x) { return __builtin_fabsf(x); }      // (an operand modifier on the device, where r_abs is compare + select)
+MGX_HD float q_and(float x, int mask) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & mask);
+}
 // 16-bit coverage of the 4x4 sample block whose top-left sample is (x0, y0); bit 4*j + i = sample (x0 + i, y0 - j).
 // fp32 first: a sample is decided in fp32 when |E| > CLASS_EPS_F, otherwise that one sample is re-evaluated in fp64
 // against the fp64 edge function -- the result equals the all-fp64 test.
@@ -548,17 +606,27 @@ MGX_HD uint32_t poly_coverage16(const Raster &rs, int k, int X, int Y, uint32_t 
             part = 0xFFFFu; cur_end = pe;
         }
         const float a = items[e].a, b = items[e].b;
-        float row = a * x0 + b * y0 + items[e].c;
-        uint32_t in = 0, amb = 0;
+        const float row = a * x0 + b * y0 + items[e].c;
+        // w = (E - eps, E + eps) of the sample, stepped along the row by one packed add: inside (with the margin) = E - eps >= 0;
+        // too close to call = E - eps < 0 <= E + eps
+        uint32_t nin = 0, nlow = 0;
+        const float2_t step = {a, a};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
         for (int j = 0; j < 4; j++) {
-            float v = row;
+            const float rj = row - b * (float)j;
+            float2_t w = {rj - CLASS_EPS_F, rj + CLASS_EPS_F};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
             for (int i = 0; i < 4; i++) {
-                in |= (v >= CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
-                amb |= (r_abs(v) < CLASS_EPS_F ? 1u : 0u) << (4 * j + i);
-                v += a;
+                nin = q_push_sign(nin, w.x);
+                nlow = q_push_sign(nlow, w.y);
+                w += step;
             }
-            row -= b;
         }
+        const uint32_t out = q_rev16(nin), in = out ^ 0xFFFFu, amb = out & ~q_rev16(nlow);
         unc |= amb & part;                                                 // samples too close to call in fp32
         part &= in;
     }
@@ -573,13 +641,28 @@ MGX_HD uint32_t ngon_coverage16(const Raster &rs, int k, int X, int Y, uint32_t 
     const Item &it = reinterpret_cast<const Item *>(&RI(items, 0))[RI(pitem, k) & 0xFFFF];
     const float x0 = 4.0f * X + 0.5f - it.a, y0 = (float)NATIVE_RES - 0.5f - 4.0f * Y - it.b;
     const float apo = it.c - CLASS_EPS_F, rad = it.g0 + CLASS_EPS_F, apo2 = apo > 0.0f ? apo * apo : -1.0f, rad2 = rad * rad;
-    uint32_t cov = 0, ann = 0;
-    for (int j = 0; j < 4; j++)
+    // (apo2 - d2, rad2 - d2) by one packed subtraction per sample: outside the in-circle = the first one negative, beyond the circum-circle =
+    // the second (a difference of two floats has the sign of the comparison, exactly)
+    uint32_t nout = 0, nfar = 0;
+    const float2_t lim = {apo2, rad2};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 4; j++) {
+        const float qy = y0 - (float)j, qy2 = qy * qy;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
         for (int i = 0; i < 4; i++) {
-            float qx = x0 + i, qy = y0 - j, d2 = qx * qx + qy * qy;
-            cov |= (d2 <= apo2 ? 1u : 0u) << (4 * j + i);
-            ann |= (d2 > apo2 && d2 <= rad2 ? 1u : 0u) << (4 * j + i);
+            const float qx = x0 + (float)i, d2 = qx * qx + qy2;
+            const float2_t dd = {d2, d2};
+            const float2_t t = lim - dd;
+            nout = q_push_sign(nout, t.x);
+            nfar = q_push_sign(nfar, t.y);
         }
+    }
+    const uint32_t outside = q_rev16(nout);
+    uint32_t cov = outside ^ 0xFFFFu, ann = outside & ~q_rev16(nfar);
     if (ann) {
         const int n = rs.prim_nv(k);
         const float step = 6.283185307179586f / (float)n, phi = (float)RD(pphi, k);
@@ -630,10 +713,15 @@ MGX_HD void lineloop_alpha16(const Raster &rs, int k, int X, int Y, uint32_t seg
     const int nv = rs.prim_nv(k), vo = rs.prim_voff(k), lvo = rs.prim_lvoff(k), stipple = rs.prim_stipple(k);
     const float hw = (float)RD(prad, k);
     const double x0 = 4.0 * X + 0.5, y0 = (double)NATIVE_RES - 0.5 - 4.0 * Y;
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
+#endif
     for (int q = 0; q < 16; q++) alpha[q] = 0.0f;
+    // the dash pattern twice over, so that bit (n & 31) is the pattern's bit (n & 15); for a solid line the stipple arithmetic below is skipped
+    const uint32_t pattern = (uint32_t)stipple | ((uint32_t)stipple << 16);
     for (; segmask; segmask &= segmask - 1) {
         const int i = __builtin_ctz(segmask);
+        uint32_t namb = 0, nzero = 0;
         double a, b, c;
         edge_coeffs_of(rs, vo, i, 0, i == nv - 1, a, b, c);
         const double ax = RDV(svx, vo + i), ay = RDV(svy, vo + i), len = RD(elen, lvo + i);
@@ -641,24 +729,32 @@ MGX_HD void lineloop_alpha16(const Raster &rs, int k, int X, int Y, uint32_t seg
         const float af = (float)a, bf = (float)b, e0 = (float)E0, s0 = (float)S0, s1 = (float)(S0 - len), lenf = (float)len;
         float u0 = 0.0f;
         if (stipple) { const double arc = RD(earc, lvo + i); u0 = (float)(arc - 16.0 * rz_floor(arc * 0.0625)); }
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
+#endif
         for (int j = 0; j < 4; j++) {
+            const float ej = e0 - bf * (float)j, dj = af * (float)j;
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
+#endif
             for (int ii = 0; ii < 4; ii++) {
-                const float fi = (float)ii, fj = (float)j;
-                const float e = e0 + (af * fi - bf * fj);
-                const float ds = bf * fi + af * fj;
+                const float e = ej + af * (float)ii;
+                const float ds = dj + bf * (float)ii;
                 const float s = s0 + ds, sb = s1 + ds;                         // arclength from the start / beyond the end
                 const float t = r_max(r_max(-s, sb), 0.0f);
-                float al = r_clamp01(hw - sqrtf(e * e + t * t));
+                float al = r_clamp01(hw - q_sqrt(e * e + t * t));
                 if (stipple) {
-                    const float u = u0 + r_clamp(s, 0.0f, lenf), fl = floorf(u);
-                    if (al > 0.0f && (u - fl < STIPPLE_TOL_F || fl + 1.0f - u < STIPPLE_TOL_F)) amb |= 1u << (4 * j + ii);
-                    if (!((stipple >> (((int)fl) & 15)) & 1)) al = 0.0f;
+                    // no branches: position along the pattern, its fraction within STIPPLE_TOL_F of a whole number = undecidable in fp32 (where
+                    // the line has any alpha at all), the pattern's bit as an all-ones / zero mask over alpha
+                    const float u = u0 + r_clamp(s, 0.0f, lenf);
+                    namb = q_push_sign(namb, (0.5f - STIPPLE_TOL_F) - q_abs(q_fract(u) - 0.5f));
+                    nzero = q_push_sign(nzero, al - 1e-30f);
+                    al = q_and(al, q_bit_mask(pattern, (uint32_t)u));
                 }
                 alpha[4 * j + ii] = r_max(alpha[4 * j + ii], al);
             }
         }
+        amb |= q_rev16(namb & ~nzero);
     }
 }
 
@@ -740,24 +836,31 @@ template <typename M> MGX_HD uint64_t pixel_resolve_fast(const Raster &rs, int X
         lineloop_alpha16(rs, pk, X, Y, psegmask, alpha, lunc);
         const float lrf = (float)(col & 0xFF), lgf = (float)((col >> 8) & 0xFF), lbf = (float)((col >> 16) & 0xFF);
         constexpr float TAU = 255.0f * ALPHA_ERR_F + 5e-4f;
+        // Sixteen samples, no branches: a sample that is not the line's to blend (claimed above it, or already uncertain) takes colour 0 and
+        // alpha 0 and adds nothing; one whose blended channel lies within TAU of a rounding boundary is flagged and its share multiplied
+        // away (`keep`).  Whole parts of the channels are summed in fp32 (exact: <= 4080).  v = c (1 - a) + (a l + 0.5); floor(v) = v - fract(v).
+        static_assert(MAXL == 1, "one remembered primitive under a line loop");
+        const uint32_t valid = pcov & ~lunc, under = nlow ? lcov[0] : 0u;
+        const int ucol = nlow ? lcol[0] : base;
+        float fsr = 0.0f, fsg = 0.0f, fsb = 0.0f;
+        uint32_t nunc = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
         for (int sidx = 0; sidx < 16; sidx++) {
-            if (!(((pcov & ~lunc) >> sidx) & 1u)) continue;
-            int c = base;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int q = MAXL - 1; q >= 0; q--) if (q < nlow && ((lcov[q] >> sidx) & 1u)) c = lcol[q];   // back to front: the frontmost wins
-            const float a = alpha[sidx];
+            const int vm = q_bit_mask(valid, sidx), um = q_bit_mask(under, sidx);
+            const int c = ((ucol & um) | (base & ~um)) & vm;
+            const float a = q_and(alpha[sidx], vm), om = 1.0f - a;
             const float cr = (float)(c & 0xFF), cg = (float)((c >> 8) & 0xFF), cb = (float)((c >> 16) & 0xFF);
-            const float vr = cr + a * (lrf - cr) + 0.5f, vg = cg + a * (lgf - cg) + 0.5f, vb = cb + a * (lbf - cb) + 0.5f;
-            const float fr = floorf(vr), fg = floorf(vg), fb = floorf(vb);
-            const float dr = r_abs(vr - fr - 0.5f), dg = r_abs(vg - fg - 0.5f), db = r_abs(vb - fb - 0.5f);
-            if (r_max(r_max(dr, dg), db) > 0.5f - TAU) { lunc |= 1u << sidx; continue; }
-            sr += (int)fr; sg += (int)fg; sb += (int)fb;
+            const float vr = cr * om + (a * lrf + 0.5f), vg = cg * om + (a * lgf + 0.5f), vb = cb * om + (a * lbf + 0.5f);
+            const float qr = q_fract(vr), qg = q_fract(vg), qb = q_fract(vb);
+            const float margin = (0.5f - TAU) - r_max(r_max(q_abs(qr - 0.5f), q_abs(qg - 0.5f)), q_abs(qb - 0.5f));   // < 0: too close to call
+            nunc = q_push_sign(nunc, margin);
+            const float keep = margin < 0.0f ? 0.0f : 1.0f;
+            fsr += keep * (vr - qr); fsg += keep * (vg - qg); fsb += keep * (vb - qb);
         }
+        sr += (int)fsr; sg += (int)fsg; sb += (int)fsb;
+        lunc |= q_rev16(nunc);
         unc |= lunc & pcov;
     }
     MGX_RSTAT(6, unc ? 1 : 0); MGX_RSTAT(7, __builtin_popcount(unc));

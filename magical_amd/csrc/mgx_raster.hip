@@ -180,7 +180,7 @@ template <typename M> __device__ __forceinline__ int masked_item_index_uniform(c
     while (mask) {
         const int k = mask_top(mask);
         mask &= ~(M(1) << k);
-        const int pi = __builtin_amdgcn_readfirstlane(RI(pitem, k)), start = pi & 0xFFFF, cnt = pi >> 16;
+        const int pi = __builtin_amdgcn_readfirstlane(RI(pitem, k)), start = pi & 0xFFFF, cnt = (pi >> 16) & PI_CNT_MASK;
         if (slot >= acc && slot < acc + cnt) found = start + (slot - acc);
         acc += cnt;
     }
@@ -201,6 +201,7 @@ __device__ __forceinline__ int rgb_of(const Raster &rs, int bk, int bg_rgb) { re
 // v_min_f32 as it is: fminf first canonicalises an operand the compiler cannot prove quiet (NaNs cannot arise where this is used:
 // finite coefficients, finite coordinates)
 __device__ __forceinline__ float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float raw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 // one Item per lane; get(i) broadcasts lane i's record to the whole wave as scalar operands
 struct RegItems {
     Item my;
@@ -279,6 +280,72 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
             if (__all(st.decided || !active)) break;
         } else {
             st.lo = lo;                                  // the primitive continues in the next 64-item chunk
+        }
+    }
+}
+
+// Phase T's classification of a mixed tile's 64 pixels WITHOUT gathering the items into lanes first (round 5): a scalar walk down the
+// tile's primitive set, the items read straight from LDS at wave-uniform addresses (one 16-byte read per polygon edge: the second half of
+// its record), the values used as vector operands.  Against the gather + v_readlane form above: no per-lane index computation per
+// primitive (8 vector + 10 scalar instructions), no item load into lanes, no meta decode per run, 3 v_readlane + v_mov less per edge
+// -- a wavefront's time follows its instruction count.  Same arithmetic per item and the same verdict per convex part, in the same order.
+template <typename M>
+__device__ __forceinline__ void classify_tile_direct(const Raster &rs, M tmixed, float xc, float yc, PixState<M> &st) {
+    const float4 *items4 = reinterpret_cast<const float4 *>(&RI(items, 0));       // (two float4 per item)
+    M m = mask_uniform<M>(tmixed);
+    auto verdict = [&](int kind, int k, float lo) -> bool {
+        const bool open = !st.decided;
+        const float thr = __builtin_bit_cast(float, kind == IT_SEG ? 0u : 0xBF800000u);
+        const bool touch = lo >= thr;
+        const bool all = kind != IT_SEG && lo > 1.0f;
+        const bool mix = open && touch && !all, cover = open && touch && all;
+        const M bit = M(1) << k;
+        st.mixed |= mix ? bit : M(0);
+        st.line |= (mix && kind == IT_SEG) ? 1 : 0;
+        st.bk = cover ? k : st.bk;
+        st.decided |= cover ? 1 : 0;
+        return __all(st.decided);
+    };
+    while (m) {
+        const int k = mask_top(m);
+        m &= ~(M(1) << k);
+        const int pi = __builtin_amdgcn_readfirstlane(RI(pitem, k));
+        const int start = pi & 0xFFFF, cnt = (pi >> 16) & PI_CNT_MASK, pkind = (pi >> 24) & 3, multi = (pi >> 26) & 1;
+        if (pkind == PR_POLY && !multi) {
+            // one convex part: cnt edges, two per turn
+            float lo = BIG_F;
+            int e = 0;
+            for (; e + 1 < cnt; e += 2) {
+                const float4 g = items4[2 * (start + e) + 1], h = items4[2 * (start + e) + 3];
+                lo = raw_min(lo, __builtin_fmaf(g.x, xc, __builtin_fmaf(g.y, yc, g.z)));
+                lo = raw_min(lo, __builtin_fmaf(h.x, xc, __builtin_fmaf(h.y, yc, h.z)));
+            }
+            if (e < cnt) { const float4 g = items4[2 * (start + e) + 1]; lo = raw_min(lo, __builtin_fmaf(g.x, xc, __builtin_fmaf(g.y, yc, g.z))); }
+            if (verdict(IT_EDGE, k, lo)) break;
+        } else if (pkind == PR_NGON) {
+            const float4 u = items4[2 * start], g = items4[2 * start + 1];          // a b c g3 | g0 ...
+            const float qx = r_abs(xc - u.x), qy = r_abs(yc - u.y);
+            const float nx = r_max(qx - 1.5f, 0.0f), ny = r_max(qy - 1.5f, 0.0f);
+            const float fx = qx + 1.5f, fy = qy + 1.5f;
+            const float apo = u.z - CLASS_EPS_F, rad = g.x + CLASS_EPS_F;
+            const float l = rad * rad - (nx * nx + ny * ny);
+            const float hh = apo > 0.0f ? apo * apo - (fx * fx + fy * fy) : -1.0f;
+            const float lo = l < 0.0f ? -2.0f : (hh > 0.0f ? 2.0f : 0.0f);
+            if (verdict(IT_NGON, k, lo)) break;
+        } else {
+            // several convex parts (a star): a verdict at every part's last edge, as the item stream's IT_LAST marks them
+            // (line loops never come here: a tile with one among its primitives takes the gather form, mgx_raster_body.inc)
+            float lo = BIG_F;
+            bool stop = false;
+            for (int e = 0; e < cnt; e++) {
+                const float4 g = items4[2 * (start + e) + 1];
+                lo = raw_min(lo, __builtin_fmaf(g.x, xc, __builtin_fmaf(g.y, yc, g.z)));
+                if (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, g.w)) & IT_LAST) {
+                    if (verdict(IT_EDGE, k, lo)) { stop = true; break; }
+                    lo = BIG_F;
+                }
+            }
+            if (stop) break;
         }
     }
 }

@@ -84,6 +84,9 @@ if [ -f magical_amd/libmagical_hip_probe.so ]; then
   done
 fi
 if [ -f magical_amd/libmagical_hip_clocks.so ]; then
+  for t in ClusterColour MoveToCorner MatchRegions; do
+    MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so timeout 300 python tools/dev/fused_occupancy.py $t-Demo-LoRes4E-v0 2>&1 | grep -v amdgpu > $O/${R}_fused_occupancy_$t.txt
+  done
   MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so python tools/dev/fused_timeline.py 2>&1 | grep -v amdgpu > $O/${R}_fused_timeline_mtc_lores4e.txt
   MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so python tools/dev/raster_phase_clocks.py 2>&1 | grep -v amdgpu > $O/${R}_raster_phase_clocks_mtc.txt
   MGX_LIB_PATH=$PWD/magical_amd/libmagical_hip_clocks.so python tools/dev/nq_stats.py 2>&1 | grep -v amdgpu > $O/${R}_raster_queue_load_by_task.txt
@@ -107,3 +110,4 @@ done; done > $O/${R}_reset_threads_pool.txt 2>&1
 timeout 600 python tools/window20_probe.py 2>&1 | grep -v amdgpu.ids > $O/${R}_window20_probe.txt
 timeout 600 python tools/raster_consistency_sweep.py 2>&1 | tail -20 > $O/${R}_raster_consistency_sweep_tail.txt
 head -30 $O/${R}_step_phase_cycles_mtc.txt
+ls $GRAFT_REPO_ROOT/gpurun_out/final $GRAFT_REPO_ROOT/gpurun_out/extra | head -80
