@@ -568,7 +568,7 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     e->rdev.qcap = e->qcap_debug > 0 && e->qcap_debug < qcap_lds ? e->qcap_debug : qcap_lds;
     // per-tile (set + i32 base colour + u8 base index) + queue (set + i32 position | base index) + counters + overflow bitmap + phase E
     // records (u64 sums, u16 entry); phase C's partial verdicts (4 x 144 x 2 mw words) lie in the queue's arrays
-    const int extra = N_TILES * (mw + 1) + N_TILES / 4 + qcap_lds * (mw + 1) + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2 + 16;      // (+ 16: the wavefront table)
+    const int extra = N_TILES * (mw + 1) + N_TILES / 4 + qcap_lds * (mw + 1) + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2;
     static_assert(4 * N_TILES * 2 <= QCAP_SMALL * 2 && 4 * N_TILES * 4 <= QCAP * 3, "phase C's partial verdicts fit the pixel queue's arrays");
     // As many rasteriser workgroups per CU as LDS allows (allocations round up to 512 B), between 3 and 5; a step is worth 13-15 % of
     // the launch.  Two economies are taken only where they buy such a step, the cheaper one first:
@@ -997,8 +997,8 @@ int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t 
     if (!e->st2) {
         HIP_OK(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
         HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&e->ev_join, getenv("MGX_JOIN_MARKER") ? hipEventDisableTiming : hipEventDefault));
-        HIP_OK(hipMalloc(&e->d_queue, (size_t)e->n_envs * 8)); HIP_OK(hipMalloc(&e->d_deferred, (size_t)e->n_envs * 4)); HIP_OK(hipMalloc(&e->d_hand, 16));
-        HIP_OK(hipMemset(e->d_queue, 0, (size_t)e->n_envs * 8)); HIP_OK(hipMemset(e->d_deferred, 0, (size_t)e->n_envs * 4)); HIP_OK(hipMemset(e->d_hand, 0, 16));
+        HIP_OK(hipMalloc(&e->d_queue, (size_t)e->n_envs * 8)); HIP_OK(hipMalloc(&e->d_deferred, (size_t)e->n_envs * 4)); HIP_OK(hipMalloc(&e->d_hand, 64));
+        HIP_OK(hipMemset(e->d_queue, 0, (size_t)e->n_envs * 8)); HIP_OK(hipMemset(e->d_deferred, 0, (size_t)e->n_envs * 4)); HIP_OK(hipMemset(e->d_hand, 0, 64));
         HIP_OK(hipDeviceSynchronize());
         e->hand_tail = e->hand_started = e->hand_epoch = 0;
     }
@@ -1011,7 +1011,7 @@ int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t 
     // mirrors themselves move only once both launches are in flight.
     auto recover = [&](int rc) {
         (void)hipStreamSynchronize(e->st2); (void)hipStreamSynchronize(st);
-        (void)hipMemset(e->d_hand, 0, 16); (void)hipMemset(e->d_queue, 0, (size_t)e->n_envs * 8); (void)hipMemset(e->d_deferred, 0, (size_t)e->n_envs * 4);
+        (void)hipMemset(e->d_hand, 0, 64); (void)hipMemset(e->d_queue, 0, (size_t)e->n_envs * 8); (void)hipMemset(e->d_deferred, 0, (size_t)e->n_envs * 4);
         (void)hipDeviceSynchronize();
         e->hand_tail = e->hand_started = 0;
         return rc;
@@ -1053,6 +1053,34 @@ int mgx_engine_handoff_stats(mgx_engine *e, unsigned *deferred, unsigned *timeou
     if (e->d_hand) { ON_DEVICE(e); HIP_OK(hipMemcpy(h, e->d_hand, 16, hipMemcpyDeviceToHost)); }
     if (deferred) *deferred = h[2];
     if (timeouts) *timeouts = h[3];
+    return MGX_OK;
+}
+// development: the hand-off's counters read on a stream of their own (works while the caller's streams are stuck).  out[0..3] = the device's
+// tail / started / deferred / timeouts, [4..6] = the host's mirrors of tail, started, epoch, [7] = queue entries that carry the current epoch,
+// [8..15] = the device's words 4..11 (-DMGX_HANG_DEBUG builds count there: rasteriser workgroups begun / past the hand-off / at phase Q / ended,
+// clean-up workgroups begun / ended)
+int mgx_engine_debug_handoff_peek(mgx_engine *e, unsigned *out) {
+    if (!e || !out) return fail(MGX_ERR_ARG, "NULL argument");
+    for (int i = 0; i < 16; i++) out[i] = 0;
+    if (!e->d_hand) return MGX_OK;
+    ON_DEVICE(e);
+    static hipStream_t st_dbg = nullptr;
+    static unsigned long long *h_q = nullptr; static unsigned *h_h = nullptr; static size_t cap = 0;
+    if (!st_dbg) HIP_OK(hipStreamCreateWithFlags(&st_dbg, hipStreamNonBlocking));
+    if (cap < (size_t)e->n_envs) {
+        if (h_q) (void)hipHostFree(h_q);
+        HIP_OK(hipHostMalloc(&h_q, (size_t)e->n_envs * 8)); cap = (size_t)e->n_envs;
+        if (!h_h) HIP_OK(hipHostMalloc(&h_h, 64));
+    }
+    HIP_OK(hipMemcpyAsync(h_h, e->d_hand, 64, hipMemcpyDeviceToHost, st_dbg));
+    HIP_OK(hipMemcpyAsync(h_q, e->d_queue, (size_t)e->n_envs * 8, hipMemcpyDeviceToHost, st_dbg));
+    HIP_OK(hipStreamSynchronize(st_dbg));
+    for (int i = 0; i < 4; i++) out[i] = h_h[i];
+    out[4] = e->hand_tail; out[5] = e->hand_started; out[6] = e->hand_epoch;
+    unsigned n = 0;
+    for (int i = 0; i < e->n_envs; i++) if ((unsigned)(h_q[i] >> 32) == e->hand_epoch) n++;
+    out[7] = n;
+    for (int i = 0; i < 8; i++) out[8 + i] = h_h[4 + i];
     return MGX_OK;
 }
 int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_t *out, int view, void *stream) {

@@ -53,7 +53,16 @@ struct RasterHandoff {
     unsigned *stats;                       // [0] deferred workgroups so far (diagnostic), [1] bounded waits that ran out
     int mode;
 };
-constexpr unsigned HANDOFF_POLL_LIMIT = 1u << 20;      // x (s_sleep 16 + an L2 round trip) ~ 1 s: far beyond any step kernel
+#ifdef MGX_HANG_DEBUG     // development: monotonic counters behind the hand-off's words (mgx_engine_debug_handoff_peek)
+#define HDBG(i) if (ho.mode && threadIdx.x == 0) atomicAdd(&ho.stats[2 + (i)], 1u);
+#else
+#define HDBG(i)
+#endif
+// x (s_sleep 16 + an L2 round trip) ~ 0.1 s: far beyond any step kernel.  It does run out: the two kernels sit on two hardware queues, and
+// the system context-switches wavefronts (queues) now and then -- with the producers' queue switched out the consumers spin for nothing.
+// One 20 000-step run in ten sees a burst of ~2000 such waits; at 2^20 polls (round 4) that burst cost 2 s, now 0.15 s.  The envs are
+// then rasterised by the clean-up launch like any other deferred one.
+constexpr unsigned HANDOFF_POLL_LIMIT = 1u << 16;
 
 MGX_HD int raster_off_q(const TmplHeader &h, int off_i) { return (off_i + h.n_words_i + 1) & ~1; }
 MGX_HD int raster_blob_words(const TmplHeader &h, int off_i) { return raster_off_q(h, off_i) + 2 * (h.n_prims * PRIM_RWORDS + 2 * h.n_pverts); }
@@ -293,18 +302,18 @@ template <typename M>
 __device__ __forceinline__ void classify_tile_direct(const Raster &rs, M tmixed, float xc, float yc, PixState<M> &st) {
     const float4 *items4 = reinterpret_cast<const float4 *>(&RI(items, 0));       // (two float4 per item)
     M m = mask_uniform<M>(tmixed);
-    auto verdict = [&](int kind, int k, float lo) -> bool {
-        const bool open = !st.decided;
-        const float thr = __builtin_bit_cast(float, kind == IT_SEG ? 0u : 0xBF800000u);
-        const bool touch = lo >= thr;
-        const bool all = kind != IT_SEG && lo > 1.0f;
-        const bool mix = open && touch && !all, cover = open && touch && all;
-        const M bit = M(1) << k;
-        st.mixed |= mix ? bit : M(0);
-        st.line |= (mix && kind == IT_SEG) ? 1 : 0;
+    // A lane's verdict on primitive k from lo, the smallest of its edge functions over the lane's 4x4 block (in units where +-1 is the
+    // block's reach): > 1 the primitive covers the block, < -1 it misses it, between them the pixel is undecided.  A lane that a
+    // primitive has covered is done: `gate` (0, then -inf) pushes every later lo of that lane far outside, so that no verdict has to ask
+    // first -- seven vector instructions and a scalar compare where the lane-mask form had twelve and ten.
+    float gate = 0.0f;
+    auto verdict = [&](int, int k, float lo) -> bool {
+        const float l2 = lo + gate;
+        const bool cover = l2 > 1.0f;
         st.bk = cover ? k : st.bk;
-        st.decided |= cover ? 1 : 0;
-        return __all(st.decided);
+        gate = cover ? -__builtin_inff() : gate;
+        st.mixed |= __builtin_fabsf(l2) <= 1.0f ? M(1) << k : M(0);
+        return __all(gate < 0.0f);
     };
     while (m) {
         const int k = mask_top(m);
@@ -467,6 +476,10 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
         t.dbg_clk[blockIdx.x * 16 + ((tid >> 6) < 3 ? 6 + (tid >> 6) : 10)] = __builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
 #endif
 #endif
+#if defined(MGX_HANG_DEBUG)
+    const unsigned hwid_at_start = __builtin_amdgcn_s_getreg(10244);
+#endif
+    HDBG(0)
     // the shared draw list does not depend on the env: stage it before waiting for the hand-off
     if (!t.tmpl_stride_words) { const int n = raster_staged_words(t, t.words); for (int i = tid; i < n; i += 256) lds[i] = t.words[i]; }
     if (ho.mode) {
@@ -500,6 +513,7 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
         if (env < 0) return;
         __syncthreads();           // (the slot is reused as a counter below)
     }
+    HDBG(1)
 #ifndef MGX_T_DYNAMIC
 #define MGX_T_DYNAMIC 1
 #endif
@@ -508,6 +522,10 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
 #endif
     constexpr bool SCALAR_WAVE = WAVES < 5, T_UNIFORM_FAST = WAVES >= 5, E_SPLIT = WAVES < 5, T_DYNAMIC = MGX_T_DYNAMIC, Q_DYNAMIC = MGX_Q_DYNAMIC;
 #include "mgx_raster_body.inc"
+    HDBG(3)
+#if defined(MGX_HANG_DEBUG)
+    if (ho.mode && (threadIdx.x & 63) == 0 && __builtin_amdgcn_s_getreg(10244) != hwid_at_start) atomicAdd(&ho.stats[2 + 7], 1u);      // a wavefront that moved
+#endif
 #undef CLK
 }
 
@@ -525,7 +543,8 @@ __global__ __launch_bounds__(256, 3) void k_raster_deferred(RasterDev t, const P
 #ifdef MGX_RASTER_PROBE
     const unsigned long long clk0 = wall_clock64();     // (the body's PROBE lines refer to it)
 #endif
-    if (ho.deferred[blockIdx.x] != ho.epoch) return;                        // (workgroup-uniform)
+    HDBG(4)
+    if (ho.deferred[blockIdx.x] != ho.epoch) { HDBG(5) return; }                        // (workgroup-uniform)
     const long env = (long)(ho.queue[blockIdx.x] & 0xFFFFFFFFull);         // written by a kernel that has completed
     const uint8_t *fill_mask = nullptr;
     if (!t.tmpl_stride_words) { const int n = raster_staged_words(t, t.words); for (int i = tid; i < n; i += 256) lds[i] = t.words[i]; }

@@ -1462,9 +1462,36 @@ def test_fused_step_render_equals_the_two_calls(name, n):
         assert np.array_equal(da, db) and np.array_equal(ia['eval_score'], ib['eval_score'])
     assert torch.equal(a.state_p, b.state_p) and torch.equal(a.state_f, b.state_f) and torch.equal(a.state_i, b.state_i)
     deferred, timeouts = a.handoff_stats()
-    assert timeouts == 0, (deferred, timeouts)
-    print(f'{name}: consumer workgroups deferred to the clean-up launch: {deferred} of {n * (2 * ep + 1)}')
+    # (a bounded wait that runs out is legitimate -- the system context-switches hardware queues now and then, DESIGN.md section 3.3 -- and
+    # ends in the clean-up launch like any deferred env: the observations above are what is asserted)
+    print(f'{name}: consumer workgroups deferred to the clean-up launch: {deferred} of {n * (2 * ep + 1)} (bounded waits that ran out: {timeouts})')
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300, method='thread')
+def test_fused_step_long_run_ends_and_equals_the_two_calls():
+    """6000 fused env-steps at 4096 envs without a host synchronisation in between, then the same tape through the two calls: the same
+    final observation and state.  Wavefronts are context-switched on this system and come back in another hardware slot; round 5's
+    first form of k_raster looked its wavefront number up by HW_ID and hung one env-step in ~20 000 (found with
+    tools/dev/hang_hunt.py).  A hang here ends in the test's timeout."""
+    import torch
+    n, T = 4096, 6000
+    name = 'MoveToCorner-Demo-LoRes4E-v0'
+    tape = torch.as_tensor(np.random.RandomState(7).randint(0, 18, size=(256, n)).astype(np.int32), device='cuda:0')
+    outs = []
+    for overlap in (True, False):
+        env = _make(name, n, max_episode_steps=None, overlap=overlap)
+        env.seed(5)
+        env.reset()
+        for s in range(T):
+            obs = env.step(tape[s & 255])[0]
+        torch.cuda.synchronize()
+        outs.append((obs.clone(), env.state_p.clone(), env.state_f.clone(), env.state_i.clone(), env.handoff_stats()))
+        env.close()
+    (oa, pa, fa, ia, st), (ob, pb, fb, ib, _) = outs
+    assert torch.equal(oa, ob) and torch.equal(pa, pb) and torch.equal(fa, fb) and torch.equal(ia, ib)
+    print(f'{T} fused env-steps: consumers deferred {st[0]}, bounded waits that ran out {st[1]}')
 
 
 @pytest.mark.gpu

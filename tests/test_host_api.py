@@ -532,3 +532,30 @@ def test_numpy_dot_modes_probe_is_self_consistent():
         assert [cand(mm_mode, a[i, 0], a[i, 1], b[i // n, 0], b[i // n, 1]) for i in range(rows)] == got.tolist(), n
     differ = sum(len({cand(m, x[0], x[1], y[0], y[1]) for m in range(3)}) > 1 for x, y in zip(a, b))
     assert differ > 10
+
+
+def test_kernels_never_ask_where_a_wavefront_sits():
+    """Wavefronts are context-switched on the target system and come back in another slot (round 5: an LDS table indexed by HW_ID's
+    SIMD and slot bits hung one env-step in ~20 000, tools/dev/hang_hunt.py).  Product code must not read HW_ID / XCC_ID: every
+    s_getreg in csrc/ has to sit under a development-build guard."""
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'magical_amd', 'csrc')
+    dev_guards = ('MGX_RASTER_CLOCKS', 'MGX_RASTER_PROBE', 'MGX_STEP_PROBE', 'MGX_HANG_DEBUG')
+    offenders = []
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith(('.hip', '.h', '.inc', '.cpp')):
+            continue
+        stack = []          # one entry per open #if: True when that block is a development-only one
+        for no, line in enumerate(open(os.path.join(csrc, name), encoding='utf-8'), 1):
+            s = line.strip()
+            if re.match(r'#\s*if', s):
+                stack.append(any(g in s for g in dev_guards) and not s.startswith('#ifndef'))
+            elif re.match(r'#\s*elif', s) and stack:
+                stack[-1] = any(g in s for g in dev_guards)
+            elif re.match(r'#\s*else', s) and stack:
+                stack[-1] = False
+            elif re.match(r'#\s*endif', s) and stack:
+                stack.pop()
+            elif 's_getreg' in s and not s.startswith('//') and not any(stack):
+                offenders.append('%s:%d' % (name, no))
+    assert not offenders, offenders
