@@ -41,6 +41,9 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 constexpr int BG_RGB = 231 | (231 << 8) | (234 << 16);   // lighten_rgb(grey, 4), base_env.py:186
 constexpr int MAX_LDS_BYTES = 160 * 1024;
+// gfx950 hands LDS out in pieces of 320 dwords (160 KB / 128): five workgroups per CU fit below 32 000 bytes each, not 32 768 (measured:
+// a 32 352-byte rasteriser layout ran four per CU -- ClusterColour's k_raster 0.514 -> 0.556 ms)
+static size_t lds_alloc_bytes(size_t lds) { return (lds + 1279) / 1280 * 1280; }
 constexpr int TIMING_RING = 4096;
 constexpr int MAX_DEVICES = 64;
 
@@ -570,7 +573,7 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     // records (u64 sums, u16 entry); phase C's partial verdicts (4 x 144 x 2 mw words) lie in the queue's arrays
     const int extra = N_TILES * (mw + 1) + N_TILES / 4 + qcap_lds * (mw + 1) + 8 + OVF_WORDS + ECAP * 2 + ECAP / 2;
     static_assert(4 * N_TILES * 2 <= QCAP_SMALL * 2 && 4 * N_TILES * 4 <= QCAP * 3, "phase C's partial verdicts fit the pixel queue's arrays");
-    // As many rasteriser workgroups per CU as LDS allows (allocations round up to 512 B), between 3 and 5; a step is worth 13-15 % of
+    // As many rasteriser workgroups per CU as LDS allows (allocations round up to 1280 B, lds_alloc_bytes), between 3 and 5; a step is worth 13-15 % of
     // the launch.  Two economies are taken only where they buy such a step, the cheaper one first:
     //  - the draw list's fp64 part (local vertices, radii: read once per frame, by the set-up) stays in HBM instead of being staged
     //    with the header and ints (4 KB in ClusterColour; FixColour 36.4 -> 31.4 KB: five per CU, env-step 1.19 -> 1.12 ms; the per-env
@@ -579,7 +582,7 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     //    fp64 operations per edge (MatchRegions' env-step 1.10 -> 1.17 ms when forced; ClusterColour 45.9 -> 40.6 KB: 1.59 -> 1.48 ms)
     auto raster_fit = [&](bool tq_hbm, bool cmp) {
         const size_t lds = (size_t)(even(tq_hbm ? raster_lds_words : raster_full_words) + even(2 * (cmp ? scratch_d_compact : scratch_d_stored) + raster_n_i) + extra) * 4;
-        const int fit = (int)((size_t)MAX_LDS_BYTES / ((lds + 511) & ~(size_t)511));
+        const int fit = (int)((size_t)MAX_LDS_BYTES / lds_alloc_bytes(lds));
         return fit > 5 ? 5 : fit;
     };
     // (rounds 2-4 kept worlds with multi-part polygons at four workgroups per CU: the 96-register variant's coverage code was slow on
@@ -625,7 +628,7 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     e->L = L; e->lds_step = step_lds_bytes(e, L);
     e->rdev.off_i = HDR_WORDS; e->rdev.lds_tmpl_words = even(raster_words); e->rdev.scratch_d = scratch_d; e->rdev.off_tiles = off_tiles;
     e->lds_raster = (size_t)(e->rdev.lds_tmpl_words + off_tiles + extra) * 4;
-    int fit = (int)((size_t)MAX_LDS_BYTES / ((e->lds_raster + 511) & ~(size_t)511));
+    int fit = (int)((size_t)MAX_LDS_BYTES / lds_alloc_bytes(e->lds_raster));
     e->raster_waves = fit >= 5 ? 5 : (fit == 4 ? 4 : 3);
     if (getenv("MGX_DEBUG_LAUNCH"))
         fprintf(stderr, "mgx: k_raster LDS bytes %zu (draw list %d words, per-env scratch %d words%s, tiles / queues %d words): %d workgroups per CU\n",
@@ -693,7 +696,7 @@ static int step_blocks(const mgx_engine *e) { const int epb = 64 / e->L; return 
 static long step_slots(mgx_engine *e) {
     if (!e->n_cus) { if (hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || e->n_cus <= 0) e->n_cus = 256; }
     const size_t lds = step_lds_bytes(e, e->L);
-    const int by_lds = (int)((size_t)MAX_LDS_BYTES / ((lds + 511) & ~(size_t)511)), by_regs = 4 * (e->L == 64 ? MGX_L64_WAVES : MGX_LN_WAVES);
+    const int by_lds = (int)((size_t)MAX_LDS_BYTES / lds_alloc_bytes(lds)), by_regs = 4 * (e->L == 64 ? MGX_L64_WAVES : MGX_LN_WAVES);
     return (long)e->n_cus * (by_lds < by_regs ? by_lds : by_regs);
 }
 template <typename R, typename P>

@@ -203,7 +203,8 @@ template <typename M> __device__ __forceinline__ int masked_item_index_uniform(c
 constexpr int BK_BG = 64, BK_TILE = 255;       // (BK_TILE: phase T's walk has met no covering primitive yet -- the tile's own base holds)
 template <typename M> struct PixState {
     M mixed; int bk; int decided; float lo; int line;
-    __device__ __forceinline__ void init(int bk0) { mixed = 0; bk = bk0; decided = 0; lo = 1e30f; line = 0; }
+    float gate;        // pixel-level walks: 0, then -inf once a primitive has covered the lane's block (added to every later lo: far outside)
+    __device__ __forceinline__ void init(int bk0) { mixed = 0; bk = bk0; decided = 0; lo = 1e30f; line = 0; gate = 0.0f; }
 };
 __device__ __forceinline__ int rgb_of(const Raster &rs, int bk, int bg_rgb) { return bk >= BK_BG ? bg_rgb : rs.prim_rgb(bk < BK_BG ? bk : 0); }
 
@@ -227,12 +228,20 @@ struct RegItems {
         return r;
     }
 };
+// A tile's line-loop SEGMENTS (round 5): phase C notes, per tile, which segments of the tile's line loops can touch it -- bit 8 s + e for
+// segment e of the s-th line-loop primitive (s < 4, loops of at most 8 segments; others: no note, never skipped) -- and phase T's pixels
+// test only those.  The arena's boundary runs through two tiles in three of MoveToCorner's mixed ones, and one of its four segments does.
+__device__ __forceinline__ int seg_note_base(const Raster &rs, uint64_t lm, int k) {      // 8 s, or -1: this primitive's segments are not noted
+    const int s = __builtin_popcountll(lm & ((1ull << k) - 1ull));
+    const int cnt = (RI(pitem, k) >> 16) & PI_CNT_MASK;
+    return (s < 4 && cnt <= 8) ? 8 * s : -1;
+}
 // consume items [0, n) held one per lane; stops at a primitive boundary once every lane of the wave is decided.
 // Same arithmetic as classify_item, organised as runs of one primitive's items so that the polygon-edge loop is
 // branch-free (3 broadcasts + 2 fma + 1 min per edge) and the per-primitive verdict is computed without divergence.
 template <bool TILE, typename M>
 __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegItems &src, int n, float xc, float yc,
-                                                    PixState<M> &st, bool active) {
+                                                    PixState<M> &st, bool active, uint32_t segw = ~0u, uint64_t lm = 0) {
     auto bc = [&](float v, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); };
     const float hx = TILE ? TILE_HX : 1.5f, hy = TILE ? TILE_HY : 1.5f;
     int i = 0;
@@ -250,7 +259,7 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
                 lo = raw_min(lo, e);
             }
         } else if (kind == IT_NGON) {
-            const float qx = r_abs(xc - bc(src.my.a, i)), qy = r_abs(yc - bc(src.my.b, i));
+            const float qx = __builtin_fabsf(xc - bc(src.my.a, i)), qy = __builtin_fabsf(yc - bc(src.my.b, i));
             const float nx = r_max(qx - hx, 0.0f), ny = r_max(qy - hy, 0.0f);
             const float fx = qx + hx, fy = qy + hy;
             const float apo = bc(src.my.c, i) - CLASS_EPS_F, rad = bc(src.my.g0, i) + CLASS_EPS_F;
@@ -258,35 +267,58 @@ __device__ __forceinline__ void classify_items_regs(const Raster &rs, const RegI
             const float h = apo > 0.0f ? apo * apo - (fx * fx + fy * fy) : -1.0f;
             lo = l < 0.0f ? -2.0f : (h > 0.0f ? 2.0f : 0.0f);
         } else {
+            // (pixel level: only the segments that phase C found touching this tile)
+            const int nb = TILE ? -1 : seg_note_base(rs, lm, k);
+            const int e0 = ((RI(pitem, k) >> 16) & PI_CNT_MASK) - rem;           // the run's first segment within its loop
             for (int j = i; j < i + run; j++) {
+                if (!TILE && nb >= 0 && !((segw >> (nb + e0 + (j - i))) & 1u)) continue;
                 const float a = bc(src.my.a, j), b = bc(src.my.b, j);
                 const float hw = bc(src.my.g3, j) + CLASS_EPS_F;
                 const float e = a * xc + (b * yc + bc(src.my.c, j));
                 const float sl = (xc - bc(src.my.g0, j)) * b - (yc - bc(src.my.g1, j)) * a;
-                const float el = hx * r_abs(a) + hy * r_abs(b), es = hx * r_abs(b) + hy * r_abs(a);
-                const float t = r_min(r_min(hw + el - r_abs(e), sl + es + hw), bc(src.my.g2, j) + hw + es - sl);
+                const float el = hx * __builtin_fabsf(a) + hy * __builtin_fabsf(b), es = hx * __builtin_fabsf(b) + hy * __builtin_fabsf(a);
+                const float t = r_min(r_min(hw + el - __builtin_fabsf(e), sl + es + hw), bc(src.my.g2, j) + hw + es - sl);
                 lo = lo >= BIG_F ? t : r_max(lo, t);
             }
         }
         i += run;
         if (run == rem) {
             // the primitive (or one convex part of it) is complete: verdict for this lane's block
-            const bool open = !st.decided;
-            // (one compare against a wave-uniform threshold: `lo` is never NaN -- finite coefficients at finite coordinates --, so
-            // lo >= 0 for a line loop and !(lo < -1) for the others are both lo >= thr; six vector instructions less per primitive
-            // than selecting between the two compares' results)
-            const float thr = __builtin_bit_cast(float, kind == IT_SEG ? 0u : 0xBF800000u);
-            const bool touch = lo >= thr;
-            const bool all = kind != IT_SEG && lo > 1.0f;
-            const bool mix = open && touch && !all, cover = open && touch && all;
-            const M bit = M(1) << k;
-            st.mixed |= mix ? bit : M(0);
-            st.line |= (mix && kind == IT_SEG) ? 1 : 0;
-            st.bk = cover ? k : st.bk;
-            st.decided |= cover ? 1 : 0;
-            lo = BIG_F;
-            st.lo = lo;
-            if (__all(st.decided || !active)) break;
+            if (TILE) {
+                const bool open = !st.decided;
+                // (one compare against a wave-uniform threshold: `lo` is never NaN -- finite coefficients at finite coordinates --, so
+                // lo >= 0 for a line loop and !(lo < -1) for the others are both lo >= thr; six vector instructions less per primitive
+                // than selecting between the two compares' results)
+                const float thr = __builtin_bit_cast(float, kind == IT_SEG ? 0u : 0xBF800000u);
+                const bool touch = lo >= thr;
+                const bool all = kind != IT_SEG && lo > 1.0f;
+                const bool mix = open && touch && !all, cover = open && touch && all;
+                const M bit = M(1) << k;
+                st.mixed |= mix ? bit : M(0);
+                st.line |= (mix && kind == IT_SEG) ? 1 : 0;
+                st.bk = cover ? k : st.bk;
+                st.decided |= cover ? 1 : 0;
+                lo = BIG_F;
+                st.lo = lo;
+                if (__all(st.decided || !active)) break;
+            } else {
+                // pixel level: the gate form (classify_tile_direct) -- a covered lane's later lo are far outside; the kind is wave-uniform
+                const float l2 = lo + st.gate;
+                const M bit = M(1) << k;
+                if (kind == IT_SEG) {
+                    const bool mix = l2 >= 0.0f;
+                    st.mixed |= mix ? bit : M(0);
+                    st.line |= mix ? 1 : 0;
+                } else {
+                    const bool cover = l2 > 1.0f;
+                    st.bk = cover ? k : st.bk;
+                    st.gate = cover ? -__builtin_inff() : st.gate;
+                    st.mixed |= __builtin_fabsf(l2) <= 1.0f ? bit : M(0);
+                }
+                lo = BIG_F;
+                st.lo = lo;
+                if (__all(st.gate < 0.0f || !active)) break;
+            }
         } else {
             st.lo = lo;                                  // the primitive continues in the next 64-item chunk
         }
@@ -306,14 +338,13 @@ __device__ __forceinline__ void classify_tile_direct(const Raster &rs, M tmixed,
     // block's reach): > 1 the primitive covers the block, < -1 it misses it, between them the pixel is undecided.  A lane that a
     // primitive has covered is done: `gate` (0, then -inf) pushes every later lo of that lane far outside, so that no verdict has to ask
     // first -- seven vector instructions and a scalar compare where the lane-mask form had twelve and ten.
-    float gate = 0.0f;
     auto verdict = [&](int, int k, float lo) -> bool {
-        const float l2 = lo + gate;
+        const float l2 = lo + st.gate;
         const bool cover = l2 > 1.0f;
         st.bk = cover ? k : st.bk;
-        gate = cover ? -__builtin_inff() : gate;
+        st.gate = cover ? -__builtin_inff() : st.gate;
         st.mixed |= __builtin_fabsf(l2) <= 1.0f ? M(1) << k : M(0);
-        return __all(gate < 0.0f);
+        return __all(st.gate < 0.0f);
     };
     while (m) {
         const int k = mask_top(m);
@@ -333,7 +364,7 @@ __device__ __forceinline__ void classify_tile_direct(const Raster &rs, M tmixed,
             if (verdict(IT_EDGE, k, lo)) break;
         } else if (pkind == PR_NGON) {
             const float4 u = items4[2 * start], g = items4[2 * start + 1];          // a b c g3 | g0 ...
-            const float qx = r_abs(xc - u.x), qy = r_abs(yc - u.y);
+            const float qx = __builtin_fabsf(xc - u.x), qy = __builtin_fabsf(yc - u.y);
             const float nx = r_max(qx - 1.5f, 0.0f), ny = r_max(qy - 1.5f, 0.0f);
             const float fx = qx + 1.5f, fy = qy + 1.5f;
             const float apo = u.z - CLASS_EPS_F, rad = g.x + CLASS_EPS_F;
@@ -364,7 +395,7 @@ __device__ __forceinline__ void classify_tile_direct(const Raster &rs, M tmixed,
 // Same arithmetic per tile as classify_items_regs<true>; consumes items [0, n) of `src`, which never end inside a convex part.
 template <int NT, typename M>
 __device__ __forceinline__ void classify_items_regs_tiles(const Raster &rs, const RegItems &src, int n, const float (&xc)[NT], const float (&yc)[NT],
-                                                          PixState<M> (&st)[NT], bool active) {
+                                                          PixState<M> (&st)[NT], bool active, uint32_t *tile_seg, uint64_t lm, int lane) {
     auto bc = [&](float v, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); };
     const float hx = TILE_HX, hy = TILE_HY;
     int i = 0;
@@ -386,7 +417,7 @@ __device__ __forceinline__ void classify_items_regs_tiles(const Raster &rs, cons
             const float apo = bc(src.my.c, i) - CLASS_EPS_F, rad = bc(src.my.g0, i) + CLASS_EPS_F;
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                const float qx = r_abs(xc[t] - ca), qy = r_abs(yc[t] - cb);
+                const float qx = __builtin_fabsf(xc[t] - ca), qy = __builtin_fabsf(yc[t] - cb);
                 const float nx = r_max(qx - hx, 0.0f), ny = r_max(qy - hy, 0.0f);
                 const float fx = qx + hx, fy = qy + hy;
                 const float l = rad * rad - (nx * nx + ny * ny);
@@ -394,17 +425,20 @@ __device__ __forceinline__ void classify_items_regs_tiles(const Raster &rs, cons
                 lo[t] = l < 0.0f ? -2.0f : (h > 0.0f ? 2.0f : 0.0f);
             }
         } else {
+            const int nb = seg_note_base(rs, lm, k);
+            const int e0 = ((RI(pitem, k) >> 16) & PI_CNT_MASK) - rem;
             for (int j = i; j < i + run; j++) {
                 const float a = bc(src.my.a, j), b = bc(src.my.b, j);
                 const float hw = bc(src.my.g3, j) + CLASS_EPS_F;
                 const float c = bc(src.my.c, j), g0 = bc(src.my.g0, j), g1 = bc(src.my.g1, j), g2 = bc(src.my.g2, j);
-                const float el = hx * r_abs(a) + hy * r_abs(b), es = hx * r_abs(b) + hy * r_abs(a);
+                const float el = hx * __builtin_fabsf(a) + hy * __builtin_fabsf(b), es = hx * __builtin_fabsf(b) + hy * __builtin_fabsf(a);
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
                     const float e = a * xc[t] + (b * yc[t] + c);
                     const float sl = (xc[t] - g0) * b - (yc[t] - g1) * a;
-                    const float tt = r_min(r_min(hw + el - r_abs(e), sl + es + hw), g2 + hw + es - sl);
+                    const float tt = r_min(r_min(hw + el - __builtin_fabsf(e), sl + es + hw), g2 + hw + es - sl);
                     lo[t] = lo[t] >= BIG_F ? tt : r_max(lo[t], tt);
+                    if (nb >= 0 && active && tt >= 0.0f) atomicOr(&tile_seg[lane + t * (N_TILES / NT)], 1u << (nb + e0 + (j - i)));
                 }
             }
         }
