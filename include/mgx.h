@@ -251,8 +251,6 @@ int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t 
                            uint8_t *out, int64_t env_stride, int view, int layout, void *stream);
 /* diagnostics of the hand-off (synchronises): consumer workgroups that gave up and were served by the clean-up launch */
 int mgx_engine_handoff_stats(mgx_engine *e, unsigned *deferred, unsigned *timeouts);
-/* development: the same counters, their host mirrors, the number of current queue entries and the debug words (out[16]), read on a stream of its own */
-int mgx_engine_debug_handoff_peek(mgx_engine *e, unsigned *out);
 /* native-resolution (384x384x3, no box filter) render of ONE env, for tests against the oracle/images */
 int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_t *out, int view, void *stream);
 /* HIP-event timing: set_timing(e, n) with n > 0 brackets every n-th step (which=0) / render (which=1) launch with

@@ -27,6 +27,10 @@ int mgx_engine_debug_step_clocks(mgx_engine *e, void *buf);
 int mgx_engine_debug_raster_waves(mgx_engine *e, int n);
 /* k_step: override the solver iteration count (-1 = the reference's 10).  tools/step_probe.py */
 int mgx_engine_debug_iterations(mgx_engine *e, int it);
+/* the fused env-step's hand-off counters read on a stream of its own -- works while the caller's streams are stuck (tools/dev/hang_hunt.py).
+ * out[16]: [0..3] the device's tail / started / deferred / timeouts, [4..6] the host's mirrors of tail, started, epoch, [7] queue entries
+ * that carry the current epoch, [8..15] per-phase workgroup counters of -DMGX_HANG_DEBUG builds (0 otherwise) */
+int mgx_engine_debug_handoff_peek(mgx_engine *e, unsigned *out);
 
 #ifdef __cplusplus
 }

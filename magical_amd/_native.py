@@ -146,6 +146,6 @@ EXPORTED_SYMBOLS = [
     'mgx_engine_create', 'mgx_engine_destroy', 'mgx_engine_set_entity_colours', 'mgx_engine_set_goal_rects', 'mgx_engine_score_overlaps', 'mgx_engine_n_goals', 'mgx_engine_score_points',
     'mgx_world_variant', 'mgx_engine_enable_env_worlds', 'mgx_engine_set_env_variants', 'mgx_engine_env_randomise_all_poses_batch', 'mgx_engine_env_world_info',
     'mgx_engine_state_shape', 'mgx_engine_lanes_per_env', 'mgx_engine_lds_bytes', 'mgx_engine_reset', 'mgx_engine_reset_poses',
-    'mgx_engine_step', 'mgx_engine_substeps', 'mgx_engine_render', 'mgx_engine_step_render', 'mgx_engine_handoff_stats', 'mgx_engine_debug_handoff_peek', 'mgx_engine_render_native',
+    'mgx_engine_step', 'mgx_engine_substeps', 'mgx_engine_render', 'mgx_engine_step_render', 'mgx_engine_handoff_stats', 'mgx_engine_render_native',
     'mgx_engine_set_timing', 'mgx_engine_timing_read',
 ]
