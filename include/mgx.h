@@ -147,7 +147,8 @@ int mgx_world_palette(int colour, int role);
  * dtype: MGX_F32 = fp32 velocities/impulses/contacts with fp64 poses (the shipped engine: the
  * reference's zero-length pin joints difference nearly equal world positions), MGX_F64 = all fp64
  * (validation), MGX_F32_PURE = all fp32 (ablation).
- * lanes_per_env: lanes of a wavefront that step one env together: 0 = the engine's choice, else 16, 32 or 64 (whole DPP
+ * lanes_per_env: lanes of a wavefront that step one env together: 0 = the engine's choice, -1 = its choice for an engine whose env-steps
+ * are rendered (mgx_engine_step_render: the crowded worlds then keep 16 lanes, which is slower for k_step alone), else 16, 32 or 64 (whole DPP
  * rows: the solver keeps the robot's joint j on lane j of each row); the result does not depend on it.  Other values (4 and 8 were
  * accepted up to round 2) return MGX_ERR_ARG; a world with more than 15 blocks returns MGX_ERR_CAPACITY (each block's joints take a
  * lane of the group's first row; every task of the reference has at most 10). */

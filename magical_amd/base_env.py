@@ -223,7 +223,12 @@ class BaseEnv(abc.ABC):
                 nat.check(L.mgx_world_goal_bb(w, ent.ent_id, bb))
                 ent.bb = tuple(bb)       # l b r t
         eng = C.c_void_p()
-        nat.check(L.mgx_engine_create(w, self.n_envs, self.device.index, self._dtype, self._lanes, C.byref(eng)))
+        # lanes per env: the caller's, else the engine's choice -- told (-1) when this env's steps are rendered by the fused env-step, where
+        # the crowded worlds do better with narrow groups (include/mgx.h)
+        lanes = self._lanes
+        if lanes == 0 and self.overlap and type(self)._fused_target is not BaseEnv._fused_target:
+            lanes = -1
+        nat.check(L.mgx_engine_create(w, self.n_envs, self.device.index, self._dtype, lanes, C.byref(eng)))
         self._engine = eng
         ne = len(self._entities)
         self._default_shape_types = np.array([en.SHAPE_TYPE_ID[e.shape_type] if isinstance(e, en.Shape) else -1 for e in self._entities], dtype=np.int32)

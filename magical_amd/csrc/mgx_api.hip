@@ -606,7 +606,9 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     e->tdev.off_i = HDR_WORDS; e->tdev.lds_tmpl_words = even(step_words); e->tdev.env_stride_words = step_env_stride;
     // lanes per env: caller's choice, else the widest group (most narrowphase parallelism) that still lets
     // two workgroups share a CU's LDS; worlds too big for that take the narrowest group that fits at all
-    int L = e->L_request;
+    // (-1: the engine's choice for an engine whose env-steps are rendered -- the fused env-step, mgx_engine_step_render)
+    const bool rendered_hint = e->L_request == -1;
+    int L = rendered_hint ? 0 : e->L_request;
     if (L == 0 && !e->env_worlds) {
         L = 16;
         while (L < 64 && step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES / 2) L *= 2;
@@ -614,12 +616,18 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
         // resident anyway (54 KB: three workgroups per CU) take 32 lanes per env: the broadphase and narrowphase, a third of their
         // step, run twice as wide.  Measured at 4096 envs: ClusterColour k_step 0.88 -> 0.77 ms, env-step 1.80 -> 1.66 ms; the
         // smaller worlds lose (FindDupe 1.48 -> 1.68 ms, MatchRegions 1.05 -> 1.31, MakeLine 1.16 -> 1.41, FixColour 1.12 -> 1.41)
-        if (L == 16 && e->h.n_pairs > 256 && step_lds_bytes(e, 16) > (size_t)40 * 1024) L = 32;
+        // ... on its own.  In the FUSED env-step the narrow groups win there too (fewer, longer step workgroups leave the rasteriser more
+        // of the CU): ClusterColour 4.53 -> 4.66 M env-steps/s, ClusterShape 4.40 -> 4.55 with 16 lanes although k_step alone is 12 %
+        // slower (round 5, tools/dev/lanes_ab.sh) -- so the rule applies to engines that are not rendered (lanes_per_env 0), not to -1
+        if (L == 16 && !rendered_hint && e->h.n_pairs > 256 && step_lds_bytes(e, 16) > (size_t)40 * 1024) L = 32;
+        // FindDupe's worlds (45 KB at 16 lanes: three workgroups per CU; <= 256 candidate pairs): 32 lanes either way -- k_step alone
+        // 0.36 -> 0.30 ms, fused env-step 4.73 -> 4.80 M env-steps/s (round 5; in round 2 it was the other way round)
+        else if (L == 16 && e->h.n_pairs <= 256 && step_lds_bytes(e, 16) > (size_t)40 * 1024) L = 32;
     } else if (L == 0) {
         L = 64;      // per-env templates: one env per wavefront, so that its template copy in LDS is shared by all lanes
     }
     // (a group is one or more whole DPP rows: the solver keeps robot joint j on lane j of every row, mgx_sim.h)
-    if (L != 16 && L != 32 && L != 64) return fail(MGX_ERR_ARG, "lanes_per_env must be 0, 16, 32 or 64");
+    if (L != 16 && L != 32 && L != 64) return fail(MGX_ERR_ARG, "lanes_per_env must be 0, -1, 16, 32 or 64");
     if (e->h.n_islands > 15) return fail(MGX_ERR_CAPACITY, "more than 15 blocks: every block's joints need a lane of the group's first row");
     if (step_lds_bytes(e, L) > (size_t)MAX_LDS_BYTES) return fail(MGX_ERR_CAPACITY, "world working set does not fit LDS at this lanes_per_env");
     if (getenv("MGX_DEBUG_LAUNCH"))
