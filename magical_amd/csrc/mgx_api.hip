@@ -657,7 +657,12 @@ static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const i
     // one-env-per-wavefront instantiation): they are dispatched longest first, by the durations of the previous launch.
     // Measured at 4096 envs: ClusterColour (2048 workgroups on 1024 slots) k_step 0.89 -> 0.6x ms.
     const long slots = step_slots(e);
-    const bool lpt = blocks > slots && blocks <= (1 << 20) && !getenv("MGX_NO_LPT");
+    // (in the fused env-step, where a wavefront holds several envs, the env order below does the same job -- costliest envs first -- and
+    // more: ClusterColour 4.65 -> 4.88 M env-steps/s, ClusterShape 4.55 -> 4.77 with the envs packed instead of the workgroups
+    // re-ordered, although k_step alone is 12 % slower that way; round 5, tools/dev/ab_env.sh)
+    static const bool no_pack_env = getenv("MGX_NO_ENV_PACK") != nullptr;
+    const bool pack_wanted = 64 / L > 1 && count_step && !no_pack_env && ho.queue != nullptr && e->n_envs >= 8 * (64 / L);
+    const bool lpt = blocks > slots && blocks <= (1 << 20) && !getenv("MGX_NO_LPT") && !pack_wanted;
     TmplDev t = e->tdev;
     t.order = nullptr; t.dur = nullptr;
     if (lpt) {
