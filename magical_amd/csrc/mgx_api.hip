@@ -619,6 +619,9 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
         // ... on its own.  In the FUSED env-step the narrow groups win there too (fewer, longer step workgroups leave the rasteriser more
         // of the CU): ClusterColour 4.53 -> 4.66 M env-steps/s, ClusterShape 4.40 -> 4.55 with 16 lanes although k_step alone is 12 %
         // slower (round 5, tools/dev/lanes_ab.sh) -- so the rule applies to engines that are not rendered (lanes_per_env 0), not to -1
+        // (Since the working set shrank -- manifold slots, packed flags: WorkOff, mgx_tmpl.h -- the reference's crowded worlds are 40.7 KB at
+        // 16 lanes, four workgroups per CU and every step workgroup resident at once: neither rule fires for them any more, and 16 lanes
+        // are faster for k_step alone too: ClusterColour state-only 8.74 -> 9.76 M env-steps/s.  The rules stay for bigger worlds.)
         if (L == 16 && !rendered_hint && e->h.n_pairs > 256 && step_lds_bytes(e, 16) > (size_t)40 * 1024) L = 32;
         // FindDupe's worlds (45 KB at 16 lanes: three workgroups per CU; <= 256 candidate pairs): 32 lanes either way -- k_step alone
         // 0.36 -> 0.30 ms, fused env-step 4.73 -> 4.80 M env-steps/s (round 5; in round 2 it was the other way round)
@@ -633,6 +636,12 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     if (getenv("MGX_DEBUG_LAUNCH"))
         fprintf(stderr, "mgx: lanes_per_env %d, k_step LDS bytes at 16 / 32 / 64 lanes: %zu / %zu / %zu\n", L,
                 step_lds_bytes(e, 16), step_lds_bytes(e, 32), step_lds_bytes(e, 64));
+    if (getenv("MGX_DEBUG_LAUNCH")) {
+        const WorkOff wo(e->h);
+        fprintf(stderr, "mgx: bodies %d verts %d shapes %d joints %d contacts %d overlaps %d cache %d pairs %d; working set words: P %d (x%d) R %d I %d; template %d words, env stride %d words\n",
+                e->h.n_bodies, e->h.n_verts, e->h.n_shapes, e->h.n_joints, e->h.max_contacts, e->h.max_overlaps, e->h.cache_slots, e->h.n_pairs,
+                wo.n_p, 2, wo.n_r, wo.n_i, e->tdev.lds_tmpl_words, e->tdev.env_stride_words);
+    }
     e->L = L; e->lds_step = step_lds_bytes(e, L);
     e->rdev.off_i = HDR_WORDS; e->rdev.lds_tmpl_words = even(raster_words); e->rdev.scratch_d = scratch_d; e->rdev.off_tiles = off_tiles;
     e->lds_raster = (size_t)(e->rdev.lds_tmpl_words + off_tiles + extra) * 4;

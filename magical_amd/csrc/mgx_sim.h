@@ -172,6 +172,8 @@ template <typename R, typename P> struct Env {
 #define E_R(field, i) e.wr[e.wo.field + (i) * WorkOff::S_##field]
 #define E_P(field, i) e.wp[e.wo.field + (i) * WorkOff::S_##field]
 #define E_I(field, i) e.wi[e.wo.field + (i) * WorkOff::S_##field]
+#define E_OV(i) (reinterpret_cast<uint16_t *>(e.wi + e.wo.ov)[i])                 // overlap list: 16-bit candidate-pair numbers
+#define E_MATCHED(i) (reinterpret_cast<uint8_t *>(e.wi + e.wo.cmatched)[i])     // cache entry matched this substep
 #define T_R(field, i) e.tr[e.to.field + (i) * TmplOff::S_##field]
 #define T_P(field, i) e.tp[e.to.field + (i) * TmplOff::S_##field]
 #define T_I(field, i) e.ti[e.to.field + (i) * TmplOff::S_##field]
@@ -269,18 +271,19 @@ template <typename R, typename P> MGX_HD void ph_broad(Env<R, P> &e, int lane, i
         const bool hit = boxes_overlap(e, pr) & (p < np);
         const unsigned long long hits = (__builtin_amdgcn_ballot_w64(hit) >> shift) & group_mask;
         const int pos = total + __builtin_popcountll(hits & ((1ull << lane) - 1ull));
-        if (hit && pos < cap) E_I(ov, pos) = p;
+        if (hit && pos < cap) E_OV(pos) = (uint16_t)p;
         total += __builtin_popcountll(hits);
     }
 #else
     // host emulation (lanes run one after the other): lane 0 does the whole list
     if (lane != 0) return;
     for (int p = 0; p < np; p++)
-        if (pair_boxes_overlap(e, p)) { if (total < cap) E_I(ov, total) = p; total++; }
+        if (pair_boxes_overlap(e, p)) { if (total < cap) E_OV(total) = (uint16_t)p; total++; }
 #endif
     if (lane == 0) {
         if (total > cap) { E_I(misc, M_OVERFLOW) += 1; total = cap; }
         E_I(misc, M_NOV) = total;
+        E_I(misc, M_NMAN) = 0;          // ph_narrow's manifold slots
     }
 }
 
@@ -556,17 +559,37 @@ template <typename R, typename P> MGX_HD void collide_pair(const Env<R, P> &e, i
     }
 }
 
+// a counter in the env's LDS working set taken by lanes side by side (the host emulation runs the lanes one after the other)
+MGX_HD int lds_fetch_inc(int32_t *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p, 1);
+#else
+    return (*p)++;
+#endif
+}
 // ---------------------------------------------------------------- phase: narrowphase
 template <typename R, typename P> MGX_HD void ph_narrow(Env<R, P> &e, int lane, int nl) {
     int nov = E_I(misc, M_NOV);
     for (int q = lane; q < nov; q += nl) {
-        int pr = T_I(pair, E_I(ov, q));
+        int pr = T_I(pair, (int)E_OV(q));
         ManifoldOut<R> m;
         collide_pair(e, pr & 0xFF, pr >> 8, m);
-        E_I(mcnt, q) = m.count | ((m.h0 | (m.h1 << 8)) << 8);        // point count (0..2) | the two point hashes
-        E_R(mn, 2 * q) = m.nx; E_R(mn, 2 * q + 1) = m.ny;
-        if (m.count > 0) { E_R(mp, 8 * q + 0) = m.p[0]; E_R(mp, 8 * q + 1) = m.p[1]; E_R(mp, 8 * q + 2) = m.p[2]; E_R(mp, 8 * q + 3) = m.p[3]; }
-        if (m.count > 1) { E_R(mp, 8 * q + 4) = m.p[4]; E_R(mp, 8 * q + 5) = m.p[5]; E_R(mp, 8 * q + 6) = m.p[6]; E_R(mp, 8 * q + 7) = m.p[7]; }
+        // point count (0..2) | the two point hashes << 8 | the manifold's slot << 24.  A touching pair takes the next slot (any order: the
+        // slot only says where normal and points lie); more touching pairs than arbiters can be is an overflow like any other
+        int word = 0;
+        if (m.count > 0) {
+            const bool slots = manifold_slots(*e.h);
+            const int slot = slots ? lds_fetch_inc(&E_I(misc, M_NMAN)) : q;
+            if (!slots || slot < e.h->cache_slots) {
+                word = m.count | ((m.h0 | (m.h1 << 8)) << 8) | (slot << 24);
+                E_R(mn, 2 * slot) = m.nx; E_R(mn, 2 * slot + 1) = m.ny;
+                E_R(mp, 8 * slot + 0) = m.p[0]; E_R(mp, 8 * slot + 1) = m.p[1]; E_R(mp, 8 * slot + 2) = m.p[2]; E_R(mp, 8 * slot + 3) = m.p[3];
+                if (m.count > 1) { E_R(mp, 8 * slot + 4) = m.p[4]; E_R(mp, 8 * slot + 5) = m.p[5]; E_R(mp, 8 * slot + 6) = m.p[6]; E_R(mp, 8 * slot + 7) = m.p[7]; }
+            } else {
+                (void)lds_fetch_inc(&E_I(misc, M_OVERFLOW));
+            }
+        }
+        E_I(mcnt, q) = word;
     }
 }
 
@@ -700,25 +723,25 @@ template <typename R, typename P> MGX_HD void ph_arbiters_joints(Env<R, P> &e, S
         scanned = q + 1;                                      // this entry is accounted for right below
         if (cnt == 0) continue;
         if (koff + cnt > kcap || rank >= ccap) continue;     // dropped: counted by lane 0 below
-        int p = E_I(ov, q), pr = T_I(pair, p), sa = pr & 0xFF, sb = pr >> 8;
+        int p = (int)E_OV(q), pr = T_I(pair, p), sa = pr & 0xFF, sb = pr >> 8;
         int A = T_I(shape_body, sa), B = T_I(shape_body, sb);
         // cached arbiter for this shape pair?
         int ci = -1; uint32_t old = 0;
         for (int c = 0; c < ncache; c++) { uint32_t hd = (uint32_t)E_I(chead, c); if ((int)(hd & 0xFFFu) == p) { ci = c; old = hd; } }
         bool first = true;
-        if (ci >= 0) { first = ((old >> 12) & 3u) != 0u; E_I(cmatched, ci) = 1; }
+        if (ci >= 0) { first = ((old >> 12) & 3u) != 0u; E_MATCHED(ci) = 1; }
         int ocnt = ci >= 0 ? (int)((old >> 14) & 3u) : 0;
         int oh[2] = {(int)((old >> 16) & 0xFFu), (int)((old >> 24) & 0xFFu)};
-        int mh = mc >> 8;
+        const int mh = (mc >> 8) & 0xFFFF, ms = (mc >> 24) & 0xFF;      // point hashes, manifold slot
         int nh[2] = {mh & 0xFF, (mh >> 8) & 0xFF};
-        R nx = E_R(mn, 2 * q), ny = E_R(mn, 2 * q + 1);
+        R nx = E_R(mn, 2 * ms), ny = E_R(mn, 2 * ms + 1);
         R mu = T_R(shape_u, sa) * T_R(shape_u, sb);
         R ma = T_R(body_minv, A), ia = T_R(body_iinv, A), mb = T_R(body_minv, B), ib = T_R(body_iinv, B);
         R pax = R(E_P(px, A)), pay = R(E_P(py, A)), pbx = R(E_P(px, B)), pby = R(E_P(py, B));
         for (int i = 0; i < cnt; i++) {
             int k = koff + i;
-            R r1x = E_R(mp, 8 * q + 4 * i) - pax, r1y = E_R(mp, 8 * q + 4 * i + 1) - pay;
-            R r2x = E_R(mp, 8 * q + 4 * i + 2) - pbx, r2y = E_R(mp, 8 * q + 4 * i + 3) - pby;
+            R r1x = E_R(mp, 8 * ms + 4 * i) - pax, r1y = E_R(mp, 8 * ms + 4 * i + 1) - pay;
+            R r2x = E_R(mp, 8 * ms + 4 * i + 2) - pbx, r2y = E_R(mp, 8 * ms + 4 * i + 3) - pby;
             R jn = 0, jt = 0;
             for (int o = 0; o < ocnt; o++) if (oh[o] == nh[i]) { jn = E_R(cj, 4 * ci + 2 * o); jt = E_R(cj, 4 * ci + 2 * o + 1); }
             R rcn1 = r1x * ny - r1y * nx, rcn2 = r2x * ny - r2y * nx;          // cross(r, n)
@@ -726,7 +749,7 @@ template <typename R, typename P> MGX_HD void ph_arbiters_joints(Env<R, P> &e, S
             R kn = ma + ia * rcn1 * rcn1 + mb + ib * rcn2 * rcn2;
             R kt = ma + ia * rct1 * rct1 + mb + ib * rct2 * rct2;
             R dist = ((r2x - r1x) + (pbx - pax)) * nx + ((r2y - r1y) + (pby - pay)) * ny;
-            E_I(kab, k) = A | (B << 8); E_I(kfirst, k) = first ? 1 : 0;
+            E_I(kab, k) = A | (B << 8) | (first ? 1 << 16 : 0);
             E_R(knx, k) = nx; E_R(kny, k) = ny;
             E_R(kr1x, k) = r1x; E_R(kr1y, k) = r1y; E_R(kr2x, k) = r2x; E_R(kr2y, k) = r2y;
             E_R(knm, k) = r_rcp<R>(kn); E_R(ktm, k) = r_rcp<R>(kt);
@@ -763,7 +786,7 @@ template <typename R> struct ContactK {
 template <typename R, typename P> MGX_HD ContactK<R> contact_load(const Env<R, P> &e, int k) {
     ContactK<R> c;
     int ab = E_I(kab, k);
-    c.a = ab & 0xFF; c.b = ab >> 8;
+    c.a = ab & 0xFF; c.b = (ab >> 8) & 0xFF;
     c.nx = E_R(knx, k); c.ny = E_R(kny, k);
     c.r1x = E_R(kr1x, k); c.r1y = E_R(kr1y, k); c.r2x = E_R(kr2x, k); c.r2y = E_R(kr2y, k);
     c.ma = T_R(body_minv, c.a); c.ia = T_R(body_iinv, c.a); c.mb = T_R(body_minv, c.b); c.ib = T_R(body_iinv, c.b);
@@ -895,8 +918,8 @@ template <typename R, typename P> MGX_HD void solve_ctx_flush(Env<R, P> &e, cons
 template <typename R, typename P> MGX_HD void contacts_warm_start(Env<R, P> &e) {
     int nk = E_I(misc, M_NK);
     for (int k = 0; k < nk; k++) {
-        if (E_I(kfirst, k)) continue;
-        int ab = E_I(kab, k), a = ab & 0xFF, b = ab >> 8;
+        int ab = E_I(kab, k), a = ab & 0xFF, b = (ab >> 8) & 0xFF;
+        if (ab >> 16) continue;                   // (the arbiter's first substep: no cached impulse)
         R nx = E_R(knx, k), ny = E_R(kny, k), jn = E_R(kjn, k), jt = E_R(kjt, k);
         R jx = nx * jn - ny * jt, jy = nx * jt + ny * jn;
         R r1x = E_R(kr1x, k), r1y = E_R(kr1y, k), r2x = E_R(kr2x, k), r2y = E_R(kr2y, k);
@@ -916,7 +939,7 @@ template <typename R, typename P> MGX_HD void solve_begin(Env<R, P> &e, SolveCtx
         // untouched cached arbiters age; they survive collision_persistence = 3 steps (cpSpaceArbiterSetFilter)
         int n = narb;
         for (int q = 0; q < ncache; q++) {
-            if (E_I(cmatched, q)) { E_I(cmatched, q) = 0; continue; }
+            if (E_MATCHED(q)) { E_MATCHED(q) = 0; continue; }
             uint32_t hd = (uint32_t)E_I(chead, q);
             uint32_t age = ((hd >> 12) & 3u) + 1u;
             if (age <= 2u && n < h.cache_slots) {
@@ -1155,7 +1178,7 @@ MGX_HD void ph_init_work(Env<R, P> &e, int lane, int nl) {
         E_R(vx, b) = R(0); E_R(vy, b) = R(0); E_R(w, b) = R(0); E_R(vbx, b) = R(0); E_R(vby, b) = R(0); E_R(wb, b) = R(0);
     }
     for (int j = lane; j < e.h->n_joints; j += nl) { E_R(ja0, j) = R(0); E_R(ja1, j) = R(0); E_R(jrate, j) = R(0); }
-    for (int c = lane; c < e.h->cache_slots; c += nl) E_I(cmatched, c) = 0;
+    for (int c = lane; c < e.h->cache_slots; c += nl) E_MATCHED(c) = 0;
     if (lane == 0) for (int i = 0; i < M_N; i++) E_I(misc, i) = 0;
 }
 

@@ -129,7 +129,7 @@ struct TmplOff {
 };
 
 // misc int slots per env
-enum MiscIdx { M_NOV = 0, M_NK, M_NARB, M_NCACHE, M_NNCACHE, M_OVERFLOW, M_ACTION, M_STEPS, M_N };
+enum MiscIdx { M_NOV = 0, M_NK, M_NARB, M_NCACHE, M_NNCACHE, M_OVERFLOW, M_ACTION, M_STEPS, M_NMAN, M_N };      // (M_NMAN: manifold slots handed out this substep)
 
 // per-env LDS working set: offsets in real-sized words (R region) and 32-bit words (int region).
 // The per-body, per-joint and per-contact fields are RECORDS (array of structs): field f of element i sits at
@@ -137,6 +137,9 @@ enum MiscIdx { M_NOV = 0, M_NK, M_NARB, M_NCACHE, M_NNCACHE, M_OVERFLOW, M_ACTIO
 // address a whole record (the solver reads all 13 fields of a contact, all 6 velocities of a body), instead of one
 // scalar offset per field held live across the kernel.  Record strides are odd (or lanes walk them with distinct banks)
 // so that lanes working on consecutive elements do not collide in LDS.
+// the crowded worlds (six blocks and more: FindDupe, ClusterColour / ClusterShape) hand manifold slots out by a counter; the others keep one
+// per overlapping pair -- their working sets fit the CU either way, and the counter costs their step kernel 1.5 %
+MGX_HD bool manifold_slots(const TmplHeader &h) { return h.cache_slots > 25; }
 struct WorkOff {
     // bodies: poses live in the pose-precision region (P words), velocities in the R region
     int px, py, ang, c, s, n_p;
@@ -148,13 +151,13 @@ struct WorkOff {
     int ja0, ja1, jrate, jlim;
     // contact points
     int knx, kny, kr1x, kr1y, kr2x, kr2y, knm, ktm, kbias, kjb, kjn, kjt, kmu;
-    // manifold scratch per overlapping pair: n(2) + 2 x (p1, p2)(4)  [mn and mp are adjacent: ncj may lie over both]
+    // manifold scratch per TOUCHING pair (slot): n(2) + 2 x (p1, p2)(4)  [mn and mp are adjacent: ncj lies over both]
     int mn, mp;
     // persistent contact cache impulses (jn, jt per point) and the one being built
     int cj, ncj;
     int n_r;
     // int region
-    int ov, mcnt, koff, kab, kfirst, chead, nchead, cmatched, misc;
+    int ov, mcnt, koff, kab, chead, nchead, cmatched, misc;        // (ov: uint16[max_overlaps], cmatched: uint8[cache_slots], the rest int32)
     int n_i;
     // element strides of the fields (1 = plain array)
 #ifndef MGX_AOS
@@ -177,8 +180,8 @@ struct WorkOff {
     static constexpr int S_knx = CONTACT_R, S_kny = CONTACT_R, S_kr1x = CONTACT_R, S_kr1y = CONTACT_R, S_kr2x = CONTACT_R, S_kr2y = CONTACT_R,
                          S_knm = CONTACT_R, S_ktm = CONTACT_R, S_kbias = CONTACT_R, S_kjb = CONTACT_R, S_kjn = CONTACT_R, S_kjt = CONTACT_R, S_kmu = CONTACT_R;
     static constexpr int S_mn = 1, S_mp = 1, S_cj = 1, S_ncj = 1;
-    static constexpr int S_ov = OV_I, S_mcnt = OV_I, S_koff = 1, S_kab = KI_I, S_kfirst = KI_I, S_chead = C_I, S_nchead = C_I,
-                         S_cmatched = C_I, S_misc = 1;
+    // (round 5: the overlap list is 16-bit, the matched flags bytes, a contact's `first` flag a bit of its body word: plain arrays)
+    static constexpr int S_mcnt = 1, S_koff = 1, S_kab = 1, S_chead = 1, S_nchead = 1, S_misc = 1;
     MGX_HD explicit WorkOff(const TmplHeader &h) {
         int nb = h.n_bodies, nv = h.n_verts, ns = h.n_shapes, nj = h.n_joints;
         int nk = h.max_contacts, nov = h.max_overlaps, nc = h.cache_slots;
@@ -200,19 +203,25 @@ struct WorkOff {
         kbias = o + 8 * sk; kjb = o + 9 * sk; kjn = o + 10 * sk; kjt = o + 11 * sk; kmu = o + 12 * sk; o += 13 * nk;
         if (o < geom_end) o = geom_end;
         ja0 = o; ja1 = o + sj; jrate = o + 2 * sj; jlim = o + 3 * sj; o += 4 * nj;
-        mn = o; o += nov * 2; mp = o; o += nov * 8;
+        // manifolds: one slot per overlapping pair that TOUCHES (handed out by an LDS counter in ph_narrow, its number kept in the pair's
+        // count word) -- as many as there can be arbiters (nc), not as many as there can be overlapping boxes (nov: round 5, 420 words of
+        // ClusterColour's 2562 per env; with the three packings below the 16-lane working set fits a CU four times)
+        const int mcap = manifold_slots(h) ? nc : nov;
+        mn = o; o += mcap * 2; mp = o; o += mcap * 8;
         cj = o; o += nc * 4;
         // the cache being built is written from solve_begin on, when the manifolds (ph_narrow .. ph_arbiters_joints) are dead
-        if (ALIAS && 4 * nc <= 10 * nov) ncj = mn; else { ncj = o; o += nc * 4; }
+        if (ALIAS && 4 * nc <= 10 * mcap) ncj = mn; else { ncj = o; o += nc * 4; }
         n_r = o;
         o = 0;
-        const int sov = AOS_OV ? 1 : nov, ski = AOS_KI ? 1 : nk, sc = AOS_C ? 1 : nc;
-        // overlapping pairs: (candidate pair, manifold point count | point hashes << 8) per pair; first contact of each arbiter, by rank
-        ov = o; mcnt = o + sov; o += 2 * nov;
+        // overlapping pairs: candidate pair (16 bit) and manifold word (point count | point hashes << 8 | slot << 24) per pair; first contact
+        // of each arbiter, by rank; cache headers old / new; matched flags (bytes); per contact: body a | body b << 8 | first << 16
+        ov = o; o += (nov + 1) / 2;
+        mcnt = o; o += nov;
         koff = o; o += nc;
-        chead = o; nchead = o + sc; cmatched = o + 2 * sc; o += 3 * nc;
+        chead = o; o += nc; nchead = o; o += nc;
+        cmatched = o; o += (nc + 3) / 4;
         misc = o; o += M_N;
-        kab = o; kfirst = o + ski; o += 2 * nk;
+        kab = o; o += nk;
         n_i = o;
     }
 };

@@ -76,12 +76,12 @@ template <typename R, typename P> struct Emu : EmuBase {
         Env<R, P> e = env();
         int nk = e.wi[e.wo.misc + M_NK];
         for (int k = 0; k < nk && k < max_rows; k++) {
-            int ab = E_I(kab, k), a = ab & 0xFF, b = ab >> 8;
+            int ab = E_I(kab, k), a = ab & 0xFF, b = (ab >> 8) & 0xFF;
             double *o = out + 11 * k;
             o[0] = a; o[1] = b; o[2] = E_R(knx, k); o[3] = E_R(kny, k);
             o[4] = (double)E_P(px, a) + E_R(kr1x, k); o[5] = (double)E_P(py, a) + E_R(kr1y, k);
             o[6] = (double)E_P(px, b) + E_R(kr2x, k); o[7] = (double)E_P(py, b) + E_R(kr2y, k);
-            o[8] = E_R(kjn, k); o[9] = E_R(kjt, k); o[10] = E_I(kfirst, k);
+            o[8] = E_R(kjn, k); o[9] = E_R(kjt, k); o[10] = ab >> 16;
         }
         return nk;
     }
