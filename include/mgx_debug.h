@@ -32,6 +32,16 @@ int mgx_engine_debug_iterations(mgx_engine *e, int it);
  * that carry the current epoch, [8..15] per-phase workgroup counters of -DMGX_HANG_DEBUG builds (0 otherwise) */
 int mgx_engine_debug_handoff_peek(mgx_engine *e, unsigned *out);
 
+/* threads the host pool (world builds, placement sampling at a reset) takes in this process: hardware threads / LOCAL_WORLD_SIZE (the ranks
+ * that share the node), within [1, MGX_HOST_THREADS (64)]; `allocating` 0 = the placement-only bound MGX_PLACE_THREADS.  No GPU needed. */
+int mgx_debug_host_threads(int allocating);
+/* the fused env-step's hand-off, failure paths forced (tests/test_gpu_parity.py, tools/dev/hang_hunt.py --fleet): poll_limit > 0 = polls a
+ * consumer workgroup spends on its queue entry before it gives the env up to the clean-up launch (shipped: 2^16; 1 = every consumer that does
+ * not find its entry at once gives up: `deferred` and -- once all producers are resident -- `timeouts` of mgx_engine_handoff_stats count);
+ * delay_every > 0 = every delay_every-th step workgroup sleeps delay_sleeps x ~1 us before it publishes its envs (late producers).
+ * 0, 0, 0 restores the shipped behaviour.  The observations are the two-call result byte for byte whatever these are set to. */
+int mgx_engine_debug_handoff(mgx_engine *e, int poll_limit, int delay_every, int delay_sleeps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,8 @@ struct mgx_engine {
     hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long *d_queue = nullptr; unsigned *d_hand = nullptr, *d_deferred = nullptr;   // d_hand: tail, started, stats[2]
     unsigned hand_tail = 0, hand_started = 0, hand_epoch = 0;                                    // host mirrors of the monotonic counters
+    unsigned dbg_poll_limit = 0, dbg_delay_every = 0, dbg_delay_sleeps = 0;                      // tests: forced hand-off failures (mgx_engine_debug_handoff; 0 = shipped behaviour)
+    hipStream_t peek_stream = nullptr; unsigned long long *peek_q = nullptr; unsigned *peek_h = nullptr;   // mgx_engine_debug_handoff_peek's own stream and pinned buffers
     int timing = 0;             // 0 = off, n = bracket every n-th launch of each kind with HIP events
     int launch_count[2] = {0, 0};
     int dbg_iterations = -1;    // development probe: override the solver iteration count
@@ -688,10 +690,9 @@ static int launch_step_L(mgx_engine *e, void *sp, void *sf, int32_t *si, const i
     // Heavy envs together: where every step workgroup is resident at once and a wavefront holds several envs, the launch's envs are
     // ordered by the cost keys the previous launch left (contact points, overlapping pairs), costliest first -- envs in contact share
     // wavefronts, and most CUs hold light wavefronts only and hand their SIMDs to the rasteriser early (MGX_NO_ENV_PACK=1: off)
-    static const bool no_pack = getenv("MGX_NO_ENV_PACK") != nullptr;
     // (fused env-step only: on its own the step kernel gains nothing -- its longest wavefront gets longer -- and the sort would sit
     // between two step launches: state-only MoveToCorner 15.5 -> 12.6 M env-steps/s when it was tried there)
-    const bool pack = !lpt && epb > 1 && count_step && !no_pack && ho.queue != nullptr && e->n_envs >= 8 * epb;
+    const bool pack = !lpt && epb > 1 && count_step && !no_pack_env && ho.queue != nullptr && e->n_envs >= 8 * epb;
     t.env_order = nullptr; t.env_cost = nullptr;
     if (pack) {
         if (!e->d_env_cost) {
@@ -842,6 +843,9 @@ void mgx_engine_destroy(mgx_engine *e) {
     if (e->st2) { (void)hipStreamSynchronize(e->st2); (void)hipStreamDestroy(e->st2); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->peek_stream) { (void)hipStreamSynchronize(e->peek_stream); (void)hipStreamDestroy(e->peek_stream); }
+    if (e->peek_q) (void)hipHostFree(e->peek_q);
+    if (e->peek_h) (void)hipHostFree(e->peek_h);
     for (void *p : {(void *)e->d_queue, (void *)e->d_hand, (void *)e->d_deferred, (void *)e->d_dur, (void *)e->d_order, (void *)e->d_env_cost, (void *)e->d_env_order}) if (p) (void)hipFree(p);
     for (void *p : {(void *)e->d_score_lib, (void *)e->d_score_ent, (void *)e->d_score_prow, (void *)e->d_score_goal_ent,
                     (void *)e->d_score_goal_xyhw, (void *)e->d_ent_type_env, (void *)e->d_ent_present_env})
@@ -1029,8 +1033,9 @@ int mgx_engine_step_render(mgx_engine *e, void *state_p, void *state_f, int32_t 
     }
     e->hand_epoch++;
     if (e->hand_epoch == 0) e->hand_epoch = 1;        // 0 is what the zeroed tables hold
-    StepHandoff sh{e->d_queue, e->d_hand, e->d_hand + 1, e->hand_tail, e->hand_epoch};
-    RasterHandoff rh{e->d_queue, e->d_hand + 1, e->hand_started, (unsigned)step_blocks(e), e->hand_epoch, e->d_deferred, e->d_hand + 2, 1};
+    StepHandoff sh{e->d_queue, e->d_hand, e->d_hand + 1, e->hand_tail, e->hand_epoch, e->dbg_delay_every, e->dbg_delay_sleeps};
+    RasterHandoff rh{e->d_queue, e->d_hand + 1, e->hand_started, (unsigned)step_blocks(e), e->hand_epoch, e->d_deferred, e->d_hand + 2, 1,
+                     e->dbg_poll_limit ? e->dbg_poll_limit : HANDOFF_POLL_LIMIT};
     // A failure between here and the second launch leaves the device's hand-off counters and their host mirrors out of step (a
     // later call would hand the producers a wrong base): drain both streams, zero counters and tables, start over at 0.  The
     // mirrors themselves move only once both launches are in flight.
@@ -1089,14 +1094,12 @@ int mgx_engine_debug_handoff_peek(mgx_engine *e, unsigned *out) {
     for (int i = 0; i < 16; i++) out[i] = 0;
     if (!e->d_hand) return MGX_OK;
     ON_DEVICE(e);
-    static hipStream_t st_dbg = nullptr;
-    static unsigned long long *h_q = nullptr; static unsigned *h_h = nullptr; static size_t cap = 0;
+    // (stream and pinned buffers belong to the engine -- its device, freed with it; one caller at a time per engine, like every entry point)
+    hipStream_t &st_dbg = e->peek_stream;
+    unsigned long long *&h_q = e->peek_q; unsigned *&h_h = e->peek_h;
     if (!st_dbg) HIP_OK(hipStreamCreateWithFlags(&st_dbg, hipStreamNonBlocking));
-    if (cap < (size_t)e->n_envs) {
-        if (h_q) (void)hipHostFree(h_q);
-        HIP_OK(hipHostMalloc(&h_q, (size_t)e->n_envs * 8)); cap = (size_t)e->n_envs;
-        if (!h_h) HIP_OK(hipHostMalloc(&h_h, 64));
-    }
+    if (!h_q) HIP_OK(hipHostMalloc(&h_q, (size_t)e->n_envs * 8));
+    if (!h_h) HIP_OK(hipHostMalloc(&h_h, 64));
     HIP_OK(hipMemcpyAsync(h_h, e->d_hand, 64, hipMemcpyDeviceToHost, st_dbg));
     HIP_OK(hipMemcpyAsync(h_q, e->d_queue, (size_t)e->n_envs * 8, hipMemcpyDeviceToHost, st_dbg));
     HIP_OK(hipStreamSynchronize(st_dbg));
@@ -1125,6 +1128,11 @@ int mgx_engine_render_native(mgx_engine *e, const void *state_p, int env, uint8_
     if (e->dtype == MGX_F32_PURE) hipLaunchKernelGGL((k_raster_native<float>), dim3(blocks), dim3(256), lds, st, e->rdev, (const float *)state_p, out, view, (long)env, e->n_envs);
     else hipLaunchKernelGGL((k_raster_native<double>), dim3(blocks), dim3(256), lds, st, e->rdev, (const double *)state_p, out, view, (long)env, e->n_envs);
     HIP_OK(hipGetLastError());
+    return MGX_OK;
+}
+int mgx_debug_host_threads(int allocating) { return host_threads(allocating != 0); }
+int mgx_engine_debug_handoff(mgx_engine *e, int poll_limit, int delay_every, int delay_sleeps) {
+    if (e) { e->dbg_poll_limit = poll_limit > 0 ? (unsigned)poll_limit : 0u; e->dbg_delay_every = delay_every > 0 ? (unsigned)delay_every : 0u; e->dbg_delay_sleeps = delay_sleeps > 0 ? (unsigned)delay_sleeps : 0u; }
     return MGX_OK;
 }
 int mgx_engine_debug_raster_waves(mgx_engine *e, int n) { if (e && n >= 3 && n <= 5) e->raster_waves = n; return MGX_OK; }
@@ -1220,7 +1228,10 @@ int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world)
     WorldBlobs cb, db;
     make_blobs(e->dtype, capacity_world->w, cb);
     make_blobs(e->dtype, e->w, db);
-    if (db.step.size() > cb.step.size() || db.raster.size() > cb.raster.size() || db.step_env_stride > cb.step_env_stride ||
+    // (blob SIZES only: the per-env LDS working set -- step_env_stride -- is not monotone in the number of blocks, WorkOff hands manifold slots
+    // out by another rule from 26 cache slots on: a five-block world needs 1858 words, the six-block one 1698; the launch geometry follows the
+    // maximum over the envs' current worlds, configure_launch below and in set_env_variants, and that maximum is checked against the CU there)
+    if (db.step.size() > cb.step.size() || db.raster.size() > cb.raster.size() ||
         db.raster_lds_words > cb.raster_lds_words || db.raster_scratch_d > cb.raster_scratch_d || db.raster_scratch_dc > cb.raster_scratch_dc || db.raster_n_i > cb.raster_n_i)
         return fail(MGX_ERR_ARG, "the capacity world must be at least as large as the engine's world");
     if (cb.h.n_prims > 64) return fail(MGX_ERR_CAPACITY, "draw list longer than 64 primitives");

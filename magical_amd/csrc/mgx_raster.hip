@@ -52,6 +52,7 @@ struct RasterHandoff {
     unsigned *deferred;                    // [n_envs] = epoch where workgroup b gave up
     unsigned *stats;                       // [0] deferred workgroups so far (diagnostic), [1] bounded waits that ran out
     int mode;
+    unsigned poll_limit;                   // polls a consumer spends on its entry (HANDOFF_POLL_LIMIT; tests force the run-out: mgx_engine_debug_handoff)
 };
 #ifdef MGX_HANG_DEBUG     // development: monotonic counters behind the hand-off's words (mgx_engine_debug_handoff_peek)
 #define HDBG(i) if (ho.mode && threadIdx.x == 0) atomicAdd(&ho.stats[2 + (i)], 1u);
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(256, WAVES) void k_raster(RasterDev t, const P *__r
                 // the very resources this workgroup holds -- the wait is a short bounded one (the two kernels are released
                 // together and the producers need a microsecond to begin), after which the env is left to the clean-up launch.
                 bool all = false;
-                for (unsigned n = 0; n < HANDOFF_POLL_LIMIT; n++) {
+                for (unsigned n = 0; n < ho.poll_limit; n++) {
                     const unsigned long long ent = __hip_atomic_load(&ho.queue[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((unsigned)(ent >> 32) == ho.epoch) { got = (long)(ent & 0xFFFFFFFFull); break; }
                     if (!all) {

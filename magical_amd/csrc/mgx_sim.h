@@ -255,25 +255,140 @@ template <typename R, typename P> MGX_HD bool boxes_overlap(const Env<R, P> &e, 
     return (la <= rb) & (lb <= ra) & (ba <= tb) & (bb <= ta);
 }
 template <typename R, typename P> MGX_HD bool pair_boxes_overlap(const Env<R, P> &e, int p) { return boxes_overlap(e, T_I(pair, p)); }
-template <typename R, typename P> MGX_HD void ph_broad(Env<R, P> &e, int lane, int nl) {
-    const int np = e.h->n_pairs, cap = e.h->max_overlaps;
-    int total = 0;
+#if MGX_BROAD_SAP
+// Sort and sweep (north_star's broadphase; round 6, A/B against the list above: profiles/r06_step_broadphase_sap_ab.txt).  Three phases of the
+// env's lane group, scratch in the manifold words (dead between ph_cache_commit and ph_narrow): (1) rank by count -- lane i's shape finds its
+// place among the <= 32 min-x keys and leaves (l, r, b, t, shape) there; (2) sweep -- lane s walks the records behind its own while their
+// left edge is not beyond its right one (early exit) and notes y-overlaps in a bit matrix, row = lower shape number; (3) emit -- row a
+// masked by a's candidate partners (the template's filtered pair list as bit masks), in ascending (a, b) = candidate-pair = arbiter order.
+// Same comparisons (<=) on the same box values as boxes_overlap: the list it leaves is the list form's, entry for entry.
+#ifndef MGX_BROAD_SAP_MIN
+#define MGX_BROAD_SAP_MIN 0          // fewer shapes than this: the list form
+#endif
+constexpr int SAP_REC = 5, SAP_ROWS = SAP_REC * 32, SAP_WORDS = SAP_ROWS + 32;      // R-typed words of scratch
+MGX_HD bool broad_sap(const TmplHeader &h) {
+    return h.n_shapes <= 32 && h.n_shapes >= MGX_BROAD_SAP_MIN && 10 * (manifold_slots(h) ? h.cache_slots : h.max_overlaps) >= SAP_WORDS;
+}
+template <typename R, typename P> MGX_HD void sap_or(uint32_t *p, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(p, v);
+#else
+    *p |= v;
+#endif
+}
+template <typename R, typename P> MGX_HD void ph_broad_sort(Env<R, P> &e, int lane, int nl) {
+    const int n = e.h->n_shapes;
+    R *rec = &E_R(mn, 0);
+    uint32_t *row = reinterpret_cast<uint32_t *>(&E_R(mn, SAP_ROWS));
+    for (int i = lane; i < 32; i += nl) row[i] = 0;
+    for (int i = lane; i < n; i += nl) {
+        const R key = E_R(bbl, i), r = E_R(bbr, i), b = E_R(bbb, i), t = E_R(bbt, i);
+        int rank = 0;
+        for (int j = 0; j < n; j++) { const R kj = E_R(bbl, j); rank += (int)((kj < key) | ((kj == key) & (j < i))); }
+        rec[SAP_REC * rank + 0] = key; rec[SAP_REC * rank + 1] = r; rec[SAP_REC * rank + 2] = b; rec[SAP_REC * rank + 3] = t; rec[SAP_REC * rank + 4] = (R)i;
+    }
+}
+template <typename R, typename P> MGX_HD void ph_broad_sweep(Env<R, P> &e, int lane, int nl) {
+    if (!broad_sap(*e.h)) return;
+    const int n = e.h->n_shapes;
+    const R *rec = &E_R(mn, 0);
+    uint32_t *row = reinterpret_cast<uint32_t *>(&E_R(mn, SAP_ROWS));
+    for (int s = lane; s < n; s += nl) {
+        const R r_ = rec[SAP_REC * s + 1], b_ = rec[SAP_REC * s + 2], t_ = rec[SAP_REC * s + 3];
+        const int i = (int)rec[SAP_REC * s + 4];
+        // (the next record is read while this one is tested: the lone wavefront pays every dependent LDS round trip in full)
+        int tn = s + 1 < n ? s + 1 : s;
+        R nl_ = rec[SAP_REC * tn], nb_ = rec[SAP_REC * tn + 2], nt_ = rec[SAP_REC * tn + 3], ni_ = rec[SAP_REC * tn + 4];
+        for (int t = s + 1; t < n; t++) {
+            const R cl = nl_, cb = nb_, ct = nt_, ci = ni_;
+            tn = t + 1 < n ? t + 1 : t;
+            nl_ = rec[SAP_REC * tn]; nb_ = rec[SAP_REC * tn + 2]; nt_ = rec[SAP_REC * tn + 3]; ni_ = rec[SAP_REC * tn + 4];
+            if (!(cl <= r_)) break;                    // sorted by left edge: nothing further on reaches back to this box
+            if ((b_ <= ct) & (cb <= t_)) {
+                const int j = (int)ci, a = i < j ? i : j, bb = i < j ? j : i;
+                sap_or<R, P>(&row[a], 1u << bb);
+            }
+        }
+    }
+}
+template <typename R, typename P> MGX_HD void ph_broad_emit(Env<R, P> &e, int lane, int nl) {
+    if (!broad_sap(*e.h)) return;
+    const int n = e.h->n_shapes, cap = e.h->max_overlaps;
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(&E_R(mn, SAP_ROWS));
+    int before = 0, total = 0;              // overlapping candidate pairs in the rows before this lane's next one / in all rows
+    int a_next = lane;
+    for (int a = 0; a < n; a++) {
+        const uint32_t allow = (uint32_t)T_I(pair_allow, a);
+        uint32_t hits = row[a] & allow;
+        if (a == a_next) {
+            int pos = before;
+            const int first = T_I(pair_row, a);
+            for (uint32_t h = hits; h; h &= h - 1) {
+                const int b = __builtin_ctz(h);
+                if (pos < cap) E_OV(pos) = (uint16_t)(first + __builtin_popcount(allow & ((1u << b) - 1u)));
+                pos++;
+            }
+            a_next += nl;
+        }
+        before += __builtin_popcount(hits);
+    }
+    total = before;
+    if (lane == 0) {
+        if (total > cap) { E_I(misc, M_OVERFLOW) += 1; total = cap; }
+        E_I(misc, M_NOV) = total;
+        E_I(misc, M_NMAN) = 0;
+    }
+}
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// the list form, U rounds of nl candidate pairs per turn of the loop: their pair words are read a turn ahead and their box reads go out back
+// to back, so that the lone wavefront waits for LDS once per turn, not once per round (round 5: U = 1; profiles/r06_step_broadphase_sap_ab.txt:
+// ClusterColour's ph_broad 105 k -> 84 k (U = 2) -> 75 k (U = 4) cycles per env-step, MoveToCorner's 13.8 k -> 11.3 k -> 18.0 k)
+template <int U, typename R, typename P> __device__ __forceinline__ int broad_list(Env<R, P> &e, int lane, int nl, int np, int cap) {
     // (n_pairs is the same for every lane of the wavefront: envs of one world, or one env per wavefront)
     const int wave_lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int shift = wave_lane - lane;
     const unsigned long long group_mask = nl >= 64 ? ~0ull : ((1ull << nl) - 1ull);
-    // (the next round's pairs are read while this round's boxes are: one dependent LDS round trip per round instead of two)
-    int pr_next = lane < np ? T_I(pair, lane) : 0;
-    for (int base = 0; base < np; base += nl) {
-        const int p = base + lane, pr = pr_next;
-        pr_next = p + nl < np ? T_I(pair, p + nl) : 0;
-        const bool hit = boxes_overlap(e, pr) & (p < np);
-        const unsigned long long hits = (__builtin_amdgcn_ballot_w64(hit) >> shift) & group_mask;
-        const int pos = total + __builtin_popcountll(hits & ((1ull << lane) - 1ull));
-        if (hit && pos < cap) E_OV(pos) = (uint16_t)p;
-        total += __builtin_popcountll(hits);
+    int total = 0;
+    int pr_next[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) pr_next[u] = lane + u * nl < np ? T_I(pair, lane + u * nl) : 0;
+    for (int base = 0; base < np; base += U * nl) {
+        int pr[U]; bool hit[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int p = base + u * nl + lane;
+            pr[u] = pr_next[u];
+            pr_next[u] = p + U * nl < np ? T_I(pair, p + U * nl) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) hit[u] = boxes_overlap(e, pr[u]) & (base + u * nl + lane < np);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned long long hits = (__builtin_amdgcn_ballot_w64(hit[u]) >> shift) & group_mask;
+            const int pos = total + __builtin_popcountll(hits & ((1ull << lane) - 1ull));
+            if (hit[u] && pos < cap) E_OV(pos) = (uint16_t)(base + u * nl + lane);
+            total += __builtin_popcountll(hits);
+        }
     }
+    return total;
+}
+#endif
+#ifndef MGX_BROAD_UNROLL_BIG
+#define MGX_BROAD_UNROLL_BIG 4       // rounds per turn where the list has at least MGX_BROAD_BIG_PAIRS candidate pairs per lane-group round ...
+#endif
+#ifndef MGX_BROAD_UNROLL_SMALL
+#define MGX_BROAD_UNROLL_SMALL 2     // ... and elsewhere
+#endif
+template <typename R, typename P> MGX_HD void ph_broad(Env<R, P> &e, int lane, int nl) {
+#if MGX_BROAD_SAP
+    if (broad_sap(*e.h)) { ph_broad_sort(e, lane, nl); return; }
+#endif
+    const int np = e.h->n_pairs, cap = e.h->max_overlaps;
+    int total = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (wave-uniform: a list of at least eight rounds takes the wider turn)
+    total = np >= 8 * nl ? broad_list<MGX_BROAD_UNROLL_BIG>(e, lane, nl, np, cap) : broad_list<MGX_BROAD_UNROLL_SMALL>(e, lane, nl, np, cap);
 #else
     // host emulation (lanes run one after the other): lane 0 does the whole list
     if (lane != 0) return;
@@ -570,16 +685,40 @@ MGX_HD int lds_fetch_inc(int32_t *p) {
 // ---------------------------------------------------------------- phase: narrowphase
 template <typename R, typename P> MGX_HD void ph_narrow(Env<R, P> &e, int lane, int nl) {
     int nov = E_I(misc, M_NOV);
+    // Manifold slots of the crowded worlds (manifold_slots, mgx_tmpl.h): a touching pair takes the next slot IN PAIR ORDER -- the running
+    // total plus the touching pairs of the lanes before it in this round, from a wavefront ballot like ph_broad's list (round 5 took them
+    // off an LDS counter: an atomic round trip per touching pair, and under overflow -- more touching pairs than arbiters can be, counted
+    // in M_OVERFLOW -- the pairs that kept a slot depended on lane order, i.e. on lanes_per_env; now the highest pairs are dropped, whatever
+    // the group's width, as include/mgx.h promises).  The host emulation runs the lanes one after the other: lane 0 walks the whole list.
+    const bool slots = manifold_slots(*e.h);
+    int total = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int wave_lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int shift = wave_lane - lane;
+    const unsigned long long group_mask = nl >= 64 ? ~0ull : ((1ull << nl) - 1ull);
     for (int q = lane; q < nov; q += nl) {
+#else
+    if (slots && lane != 0) return;
+    for (int q = slots ? 0 : lane; q < nov; q += slots ? 1 : nl) {
+#endif
         int pr = T_I(pair, (int)E_OV(q));
         ManifoldOut<R> m;
         collide_pair(e, pr & 0xFF, pr >> 8, m);
-        // point count (0..2) | the two point hashes << 8 | the manifold's slot << 24.  A touching pair takes the next slot (any order: the
-        // slot only says where normal and points lie); more touching pairs than arbiters can be is an overflow like any other
+        // point count (0..2) | the two point hashes << 8 | the manifold's slot << 24; more touching pairs than arbiters can be is an
+        // overflow like any other
         int word = 0;
+        int slot = q;
+        if (slots) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const unsigned long long hits = (__builtin_amdgcn_ballot_w64(m.count > 0) >> shift) & group_mask;
+            slot = total + __builtin_popcountll(hits & ((1ull << lane) - 1ull));
+            total += __builtin_popcountll(hits);
+#else
+            slot = total;
+            total += m.count > 0;
+#endif
+        }
         if (m.count > 0) {
-            const bool slots = manifold_slots(*e.h);
-            const int slot = slots ? lds_fetch_inc(&E_I(misc, M_NMAN)) : q;
             if (!slots || slot < e.h->cache_slots) {
                 word = m.count | ((m.h0 | (m.h1 << 8)) << 8) | (slot << 24);
                 E_R(mn, 2 * slot) = m.nx; E_R(mn, 2 * slot + 1) = m.ny;
@@ -1310,12 +1449,18 @@ MGX_HD void reset_env_state(const TmplHeader &h, const int32_t *ti, const R *tr,
 // synchronises the env's lane group.  Used by mgx_step.hip (device) and tests/emu (host).
 // (everything after the position update: a substep's poses are final once ph_integrate has run -- what follows finds the collisions
 // at the new positions and solves for the velocities that the NEXT substep integrates, cpSpaceStep's order)
+#if MGX_BROAD_SAP
+#define MGX_BROAD_SAP_PHASES(X) X(ph_broad_sweep(e, lane, nl)) X(ph_broad_emit(e, lane, nl))
+#else
+#define MGX_BROAD_SAP_PHASES(X)
+#endif
 #define MGX_SUBSTEP_PHASES(X)                                      \
     X(ph_integrate(e, lane, nl))                                   \
     MGX_SUBSTEP_AFTER_INTEGRATE(X)
 #define MGX_SUBSTEP_AFTER_INTEGRATE(X)                             \
     X(ph_shapes(e, lane, nl))                                      \
     X(ph_broad(e, lane, nl))                                       \
+    MGX_BROAD_SAP_PHASES(X)                                        \
     X(ph_narrow(e, lane, nl))                                      \
     X(ph_arbiters_joints(e, ctx, lane, nl))                        \
     X(solve_begin(e, ctx, lane, nl))                               \

@@ -50,6 +50,7 @@ struct StepHandoff {
     unsigned *started;           // step workgroups that have begun executing, all calls (monotonic)
     unsigned base;               // value of *tail before this call
     unsigned epoch;              // this call's tag
+    unsigned delay_every, delay_sleeps;      // tests (mgx_engine_debug_handoff): every delay_every-th workgroup sleeps delay_sleeps x ~1 us before it publishes (0: off)
 };
 MGX_HD int even_words(int x) { return (x + 1) & ~1; }
 template <typename R> MGX_HD int tmpl_off_r(const TmplHeader &h, int off_i) { return even_words(off_i + h.n_words_i); }
@@ -195,6 +196,7 @@ __device__ __forceinline__ void step_body(const TmplDev &t, P *__restrict__ sp, 
         SYNC(ph_integrate(e, lane, nl))
         if (early && sub == n_sub - 1) {
             if (valid) ph_store_poses(e, sp, stride, env, lane, nl);
+            if (ho.delay_every && blockIdx.x % ho.delay_every == 0) for (unsigned i = 0; i < ho.delay_sleeps; i++) __builtin_amdgcn_s_sleep(127);      // (a late producer, forced: tests)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler may drop the fence's own wait: keep this one)

@@ -47,6 +47,9 @@ constexpr int PRIM_IWORDS = 7;     // kind, nverts, voff | line-vertex offset <<
 // last one of its part (a plain convex polygon has the single bit nverts - 1) -- hence at most 32 vertices per primitive.
 constexpr int PRIM_RWORDS = 6;     // eye_base(2) eye_pre(2) line_halfwidth (n-gons: cos(pi / nverts)) radius
 
+#ifndef MGX_BROAD_SAP
+#define MGX_BROAD_SAP 0      // 1: the sort-and-sweep broadphase (ph_broad, mgx_sim.h) where a world has at most 32 shapes; 0: the candidate-pair list
+#endif
 struct TmplHeader {
     int32_t n_bodies, n_shapes, n_verts, n_joints, n_pairs, n_prims, n_pverts;
     int32_t n_state, n_state_p, n_jacc, cache_slots, max_contacts, max_overlaps;   // n_state_p of the n_state rows are pose rows
@@ -79,10 +82,11 @@ struct TmplOff {
     static constexpr int S_body_type = 1, S_body_parent = 1, S_body_ent = 1, S_joint_kind = 1, S_joint_a = 1, S_joint_b = 1, S_joint_acc = 1,
                          S_joint_pv = 1, S_pair = 1, S_state_map = 1, S_prim_i = 1, S_pv_prim = 1, S_body_prow = 1, S_island_j = 1,
                          S_body_init = 1, S_body_anchor = 1, S_joint_p = 1, S_prim_r = 1, S_pvx = 1, S_pvy = 1, S_consts = 1,
-                         S_p_body_init = 1, S_p_body_anchor = 1, S_p_body_aoff = 1, S_p_joint = 1, S_p_dt = 1;
+                         S_p_body_init = 1, S_p_body_anchor = 1, S_p_body_aoff = 1, S_p_joint = 1, S_p_dt = 1, S_pair_allow = 1, S_pair_row = 1;
     // ints
     int body_type, body_parent, body_ent, shape_kind, shape_body, shape_voff, shape_nv;
     int joint_kind, joint_a, joint_b, joint_acc, joint_pv, pair, state_map, prim_i, pv_prim, body_prow, island_j, n_i;
+    int pair_allow, pair_row;       // MGX_BROAD_SAP builds: per shape a the candidate partners b > a as a bit mask, and the number of a's first candidate pair
     // reals
     int body_minv, body_iinv, body_init, body_anchor, shape_r, shape_u, lvx, lvy, lnx, lny;
     int joint_p, prim_r, pvx, pvy, consts, n_r;
@@ -105,6 +109,10 @@ struct TmplOff {
         pv_prim = o; o += h.n_pverts;         // primitive of every draw-list vertex (the rasteriser sets vertices up one per lane)
         body_prow = o; o += h.n_bodies * 3;   // pose-blob row of (x, y, angle) per body, -1 if not persistent
         island_j = o; o += h.n_islands;
+        pair_allow = pair_row = o;
+#if MGX_BROAD_SAP
+        if (h.n_shapes <= 32) { pair_allow = o; o += h.n_shapes; pair_row = o; o += h.n_shapes; }
+#endif
         n_i = o;
         o = 0;
         { const int d = A_B ? 1 : h.n_bodies; body_minv = o; body_iinv = o + d; o += 2 * h.n_bodies; }
@@ -137,9 +145,14 @@ enum MiscIdx { M_NOV = 0, M_NK, M_NARB, M_NCACHE, M_NNCACHE, M_OVERFLOW, M_ACTIO
 // address a whole record (the solver reads all 13 fields of a contact, all 6 velocities of a body), instead of one
 // scalar offset per field held live across the kernel.  Record strides are odd (or lanes walk them with distinct banks)
 // so that lanes working on consecutive elements do not collide in LDS.
-// the crowded worlds (six blocks and more: FindDupe, ClusterColour / ClusterShape) hand manifold slots out by a counter; the others keep one
-// per overlapping pair -- their working sets fit the CU either way, and the counter costs their step kernel 1.5 %
-MGX_HD bool manifold_slots(const TmplHeader &h) { return h.cache_slots > 25; }
+// Manifold scratch per TOUCHING pair (slots handed out in pair order, ph_narrow) in every world.  Round 5 handed the slots out by an LDS
+// counter, which cost the small worlds' step kernel 1.5 %, and kept one slot per overlapping pair for worlds below 26 cache slots -- a
+// per-env working set that was not monotone in the number of blocks (five blocks 1858 words, six 1698: round-5 advisor).  The ballot form
+// costs nothing (profiles/r06_step_broadphase_sap_ab.txt, the `slotsall` lines), so every world takes it (MGX_MANIFOLD_SLOTS_ALL=0: round 5's rule).
+#ifndef MGX_MANIFOLD_SLOTS_ALL
+#define MGX_MANIFOLD_SLOTS_ALL 1
+#endif
+MGX_HD bool manifold_slots(const TmplHeader &h) { return MGX_MANIFOLD_SLOTS_ALL || h.cache_slots > 25; }
 struct WorkOff {
     // bodies: poses live in the pose-precision region (P words), velocities in the R region
     int px, py, ang, c, s, n_p;
@@ -203,7 +216,7 @@ struct WorkOff {
         kbias = o + 8 * sk; kjb = o + 9 * sk; kjn = o + 10 * sk; kjt = o + 11 * sk; kmu = o + 12 * sk; o += 13 * nk;
         if (o < geom_end) o = geom_end;
         ja0 = o; ja1 = o + sj; jrate = o + 2 * sj; jlim = o + 3 * sj; o += 4 * nj;
-        // manifolds: one slot per overlapping pair that TOUCHES (handed out by an LDS counter in ph_narrow, its number kept in the pair's
+        // manifolds: one slot per overlapping pair that TOUCHES (handed out in pair order by ph_narrow -- round 5: by an LDS counter --, its number kept in the pair's
         // count word) -- as many as there can be arbiters (nc), not as many as there can be overlapping boxes (nov: round 5, 420 words of
         // ClusterColour's 2562 per env; with the three packings below the 16-lane working set fits a CU four times)
         const int mcap = manifold_slots(h) ? nc : nov;

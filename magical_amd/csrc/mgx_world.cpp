@@ -772,6 +772,17 @@ void World::serialise(TmplHeader &h, std::vector<int32_t> &iw, std::vector<doubl
         }
     }
     for (int k = 0; k < h.n_pairs; k++) iw[o.pair + k] = pairs[k].first | (pairs[k].second << 8);
+#if MGX_BROAD_SAP
+    // the candidate list is in (lower shape, higher shape) order: per lower shape the partners as a bit mask and the number of its first pair
+    if (h.n_shapes <= 32) {
+        for (int a = 0; a < h.n_shapes; a++) { iw[o.pair_allow + a] = 0; iw[o.pair_row + a] = 0; }
+        for (int k = h.n_pairs - 1; k >= 0; k--) {
+            const int a = std::min(pairs[k].first, pairs[k].second), b = std::max(pairs[k].first, pairs[k].second);
+            iw[o.pair_allow + a] |= (int32_t)(1u << b);
+            iw[o.pair_row + a] = k;
+        }
+    }
+#endif
     for (int k = 0; k < h.n_state; k++) iw[o.state_map + k] = state_map[k];
     for (int k = 0; k < h.n_islands; k++) iw[o.island_j + k] = island_j[k];
     for (int k = 0; k < 3 * h.n_bodies; k++) iw[o.body_prow + k] = -1;

@@ -39,6 +39,24 @@ def init_from_env(backend=None, single_process_group=False):
     return rank, world, local_rank
 
 
+def device_index_for_local_rank(local_rank, n_visible=None):
+    """The HIP device index a rank uses.  One process per GPU, and two ways a launcher hands the GPUs out: every rank sees the whole node
+    (torchrun as the driver runs it: device = LOCAL_RANK), or every rank sees ONE device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES set per
+    rank: the only device it has is index 0 whatever its LOCAL_RANK).  Anything in between (fewer visible devices than ranks on the node,
+    more than one) is a mis-launch and raises instead of silently doubling ranks up on a GPU."""
+    if n_visible is None:
+        import torch
+        n_visible = torch.cuda.device_count()
+    local_rank, n_visible = int(local_rank), int(n_visible)
+    if n_visible < 1:
+        raise RuntimeError('no HIP device visible to this rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES empty?)')
+    if local_rank < n_visible:
+        return local_rank
+    if n_visible == 1:
+        return 0
+    raise RuntimeError(f'LOCAL_RANK={local_rank} but only {n_visible} HIP devices are visible: give every rank the whole node or exactly one device')
+
+
 def gather_rollout_results(local, n_total=None):
     """All-gather a per-env result tensor [n_local, ...] along dim 0 in rank order -> [n_total, ...] on every
     rank.  Shards may differ in length by one (env_shard), so this pads to the longest shard.  Without a process group the

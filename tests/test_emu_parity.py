@@ -223,3 +223,31 @@ def test_contact_split_and_register_narrowphase_change_no_bit(task, mode):
         assert other[3] == runs[0][3]
         for a, b in zip(runs[0][:3], other[:3]):
             assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize('mode', ['mixed', 'f64'])
+@pytest.mark.parametrize('task', ['MoveToCorner', 'MatchRegions', 'ClusterColour', 'FindDupe'])
+def test_sort_and_sweep_broadphase_changes_no_bit(task, mode):
+    """The sort-and-sweep broadphase (MGX_BROAD_SAP builds, mgx_sim.h: rank the AABB min-x keys, sweep with early exit, emit in ascending
+    candidate-pair order) must leave the list the candidate-pair form leaves, entry for entry -- the arbiter order, and with it every bit
+    of the state, depends on it: 16 envs, 60 env-steps of driving into things, every persistent state row compared (also with the manifold
+    slots of the crowded worlds handed out in every world: MGX_MANIFOLD_SLOTS_ALL)."""
+    ref = new_ref(task)
+    ents = ref_entities_as_tuples(ref)
+    rng = np.random.RandomState(zlib.crc32(task.encode()) % 1000)
+    tape = rng.randint(0, 18, size=(60, 16)).astype(np.int32)
+    tape[::3] = 1
+    runs = []
+    for defines in ((), ('MGX_BROAD_SAP=1',), ('MGX_MANIFOLD_SLOTS_ALL=1',), ('MGX_BROAD_SAP=1', 'MGX_MANIFOLD_SLOTS_ALL=1')):
+        em = EmuBatch(ents, ref.max_episode_steps, 16, mode=mode, defines=defines)
+        em.reset()
+        touched = 0
+        for t in range(60):
+            em.run(tape[t])
+            touched += len(em.contacts())
+        runs.append((em.sp.copy(), em.sf.copy(), em.si.copy(), touched))
+    assert runs[0][3] > 15, 'the tape must produce contacts'
+    for other in runs[1:]:
+        assert other[3] == runs[0][3]
+        for a, b in zip(runs[0][:3], other[:3]):
+            assert a.tobytes() == b.tobytes()

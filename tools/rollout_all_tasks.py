@@ -15,6 +15,36 @@ import numpy as np
 TASKS = ['MoveToCorner', 'MoveToRegion', 'MatchRegions', 'MakeLine', 'FindDupe', 'FixColour', 'ClusterColour', 'ClusterShape']
 
 
+class _StubEnv:
+    """MGX_BENCH_STUB=1 (tests/test_bench_launcher.py, no GPU): stands in for an engine so that the N-rank control flow of this tool --
+    process group (gloo), env shards, per-rank tape slices, seeds by global env index, the end-of-rollout gather, MAX over ranks, one line per
+    task on rank 0 -- runs as it is.  An env's score depends on its own tape column and its own seed only: any sharding gives the same table."""
+
+    def __init__(self, name, n):
+        import torch
+        self.max_episode_steps, self.device, self.n, self.t = 5 + len(name) % 4, torch.device('cpu'), n, 0
+        self.acc = np.zeros(n, dtype=np.int64)
+
+    def seed(self, s):
+        self.acc += np.arange(s, s + self.n)          # env k of the job is seeded seed + k whatever the sharding
+
+    def reset(self):
+        self.t = 0
+
+    def step(self, a):
+        self.t += 1
+        self.acc += np.asarray(a, dtype=np.int64) * self.t
+        done = np.full(self.n, self.t == self.max_episode_steps)
+        return None, None, done, {'eval_score': (self.acc % 11) / 11.0}
+
+    def close(self):
+        pass
+
+
+def _stub():
+    return bool(os.environ.get('MGX_BENCH_STUB'))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--envs', type=int, default=8192, help='envs per task over the whole job')
@@ -28,8 +58,13 @@ def main():
     import torch.distributed as dist
     import magical_amd
     from magical_amd.distributed import env_shard, gather_rollout_results, init_from_env
-    rank, world, local_rank = init_from_env(backend='nccl')
-    torch.cuda.set_device(local_rank)
+    from magical_amd.distributed import device_index_for_local_rank
+    stub = _stub()
+    rank, world, local_rank = init_from_env(backend='gloo' if stub else 'nccl')
+    if not stub:
+        local_rank = device_index_for_local_rank(local_rank)      # (LOCAL_RANK, or 0 where the launcher shows every rank one device only)
+        torch.cuda.set_device(local_rank)
+    sync = (lambda: None) if stub else torch.cuda.synchronize
     lo, hi = env_shard(args.envs, rank, world)
     magical_amd.register_envs()
     variants = (sorted({magical_amd.EnvName(n).variant for n in magical_amd.ALL_REGISTERED_ENVS}, key=lambda v: (v != 'Demo', v))
@@ -86,7 +121,7 @@ def main():
             dist.destroy_process_group()
         return
     for task, name in names:
-        env = magical_amd.make(name, n_envs=hi - lo, device=f'cuda:{local_rank}')
+        env = _StubEnv(name, hi - lo) if stub else magical_amd.make(name, n_envs=hi - lo, device=f'cuda:{local_rank}')
         T = env.max_episode_steps
         # the action tape of the whole job, every rank takes its slice (same results for any number of GPUs)
         tape = np.random.RandomState(args.seed).randint(0, 18, size=(T, args.envs)).astype(np.int32)[:, lo:hi]
@@ -95,19 +130,20 @@ def main():
         env.reset()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        sync(); t0 = time.perf_counter()
         for s in range(T):
             _, _, done, info = env.step(tape[s])
         assert done.all()
         scores = gather_rollout_results(torch.as_tensor(info['eval_score'], device=env.device), args.envs)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        sync(); dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=env.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
         if rank == 0:
             print(json.dumps({'task': name, 'n_envs': args.envs, 'n_gpus': world, 'episode_steps': T,
                               'env_steps_per_s': args.envs * T / dt, 'mean_score': float(scores.mean().item()),
-                              'frac_solved': float((scores > 0.5).double().mean().item())}))
+                              'frac_solved': float((scores > 0.5).double().mean().item()),
+                              **({'stub_scores_crc': int(__import__('zlib').crc32(np.ascontiguousarray(scores.numpy()).tobytes())), 'gathered_rows': int(scores.shape[0])} if stub else {})}), flush=True)
         env.close()
     if world > 1:
         dist.destroy_process_group()
