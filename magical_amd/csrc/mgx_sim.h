@@ -856,17 +856,69 @@ template <typename R, typename P> MGX_HD void ph_arbiters_joints(Env<R, P> &e, S
     int kcap = e.h->max_contacts, ccap = e.h->cache_slots;
     R dt = e.cst(C_DT), slop = e.cst(C_SLOP), brate = e.cst(C_CONTACT_BIAS_RATE);
     int koff = 0, rank = 0, scanned = 0;
+#ifndef MGX_ARB_BALLOT
+#define MGX_ARB_BALLOT 1      // 0: round 5's per-lane rescans of the manifold words (A/B builds)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && MGX_ARB_BALLOT
+    // A touching pair's first contact slot and arbiter rank are prefix sums over the pairs before it.  Round 5: every lane rescanned the
+    // manifold words of all earlier pairs (and lane 0 all of them once more for the totals) -- up to nov DEPENDENT-latency LDS reads on a
+    // wavefront with nothing else to run.  Now: per round of nl pairs two ballots of the point count's bits give every lane the sums of the
+    // lanes before it, the running totals stay in (group-uniform) registers.  Exact whenever nothing is dropped -- all contacts fit
+    // max_contacts, all arbiters cache_slots, which `fits` decides from the same ballots before anything is written; a substep that does
+    // overflow (counted, warned about by the host) takes round 5's sequential rule unchanged.
+    const int wave_lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int shift = wave_lane - lane;
+    const unsigned long long group_mask = nl >= 64 ? ~0ull : ((1ull << nl) - 1ull), below = (1ull << lane) - 1ull;
+    int tot_k = 0, tot_r = 0;
+    for (int base = 0; base < nov; base += nl) {
+        const int q = base + lane, cn = q < nov ? (E_I(mcnt, q) & 3) : 0;
+        const unsigned long long b0 = (__builtin_amdgcn_ballot_w64((cn & 1) != 0) >> shift) & group_mask;
+        const unsigned long long b1 = (__builtin_amdgcn_ballot_w64((cn & 2) != 0) >> shift) & group_mask;
+        tot_k += __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1);
+        tot_r += __builtin_popcountll(b0 | b1);
+    }
+    const bool fits = tot_k <= kcap && tot_r <= ccap;          // (the same in every lane of the group)
+    int run_k = 0, run_r = 0;
+    for (int q = lane; q < nov; q += nl) {
+        const int mc = E_I(mcnt, q), cnt = mc & 3;
+        if (fits) {
+            const unsigned long long b0 = (__builtin_amdgcn_ballot_w64((cnt & 1) != 0) >> shift) & group_mask;
+            const unsigned long long b1 = (__builtin_amdgcn_ballot_w64((cnt & 2) != 0) >> shift) & group_mask;
+            koff = run_k + __builtin_popcountll(b0 & below) + 2 * __builtin_popcountll(b1 & below);
+            rank = run_r + __builtin_popcountll((b0 | b1) & below);
+            run_k += __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1);
+            run_r += __builtin_popcountll(b0 | b1);
+        } else {
+            for (; scanned < q; scanned++) { int c = E_I(mcnt, scanned) & 3; if (c > 0 && koff + c <= kcap && rank < ccap) { koff += c; rank++; } }
+            scanned = q + 1;
+        }
+        if (cnt == 0) continue;
+        if (koff + cnt > kcap || rank >= ccap) continue;     // dropped: counted by lane 0 below
+#else
+    const bool fits = false; const int tot_k = 0, tot_r = 0;
     for (int q = lane; q < nov; q += nl) {
         for (; scanned < q; scanned++) { int c = E_I(mcnt, scanned) & 3; if (c > 0 && koff + c <= kcap && rank < ccap) { koff += c; rank++; } }
         const int mc = E_I(mcnt, q), cnt = mc & 3;
         scanned = q + 1;                                      // this entry is accounted for right below
         if (cnt == 0) continue;
         if (koff + cnt > kcap || rank >= ccap) continue;     // dropped: counted by lane 0 below
+#endif
         int p = (int)E_OV(q), pr = T_I(pair, p), sa = pr & 0xFF, sb = pr >> 8;
         int A = T_I(shape_body, sa), B = T_I(shape_body, sb);
         // cached arbiter for this shape pair?
         int ci = -1; uint32_t old = 0;
-        for (int c = 0; c < ncache; c++) { uint32_t hd = (uint32_t)E_I(chead, c); if ((int)(hd & 0xFFFu) == p) { ci = c; old = hd; } }
+        // (four headers per turn: the reads go out together -- one LDS round trip per four entries, not per entry)
+        for (int c = 0; c < ncache; c += 4) {
+            uint32_t hd[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int u = 0; u < 4; u++) hd[u] = c + u < ncache ? (uint32_t)E_I(chead, c + u) : 0xFFFFFFFFu;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int u = 0; u < 4; u++) if (c + u < ncache && (int)(hd[u] & 0xFFFu) == p) { ci = c + u; old = hd[u]; }
+        }
         bool first = true;
         if (ci >= 0) { first = ((old >> 12) & 3u) != 0u; E_MATCHED(ci) = 1; }
         int ocnt = ci >= 0 ? (int)((old >> 14) & 3u) : 0;
@@ -899,11 +951,15 @@ template <typename R, typename P> MGX_HD void ph_arbiters_joints(Env<R, P> &e, S
         E_I(koff, rank) = koff;
         koff += cnt; rank++;
     }
-    if (lane == 0) {   // totals (lane 0 rescans everything once; also counts drops)
-        int k = 0, r = 0, dropped = 0;
-        for (int q = 0; q < nov; q++) { int c = E_I(mcnt, q) & 3; if (c > 0) { if (k + c <= kcap && r < ccap) { k += c; r++; } else dropped++; } }
-        E_I(misc, M_NK) = k; E_I(misc, M_NARB) = r;
-        if (dropped) E_I(misc, M_OVERFLOW) += dropped;
+    if (lane == 0) {
+        if (fits) {      // totals straight from the ballots
+            E_I(misc, M_NK) = tot_k; E_I(misc, M_NARB) = tot_r;
+        } else {         // lane 0 rescans everything once; also counts drops
+            int k = 0, r = 0, dropped = 0;
+            for (int q = 0; q < nov; q++) { int c = E_I(mcnt, q) & 3; if (c > 0) { if (k + c <= kcap && r < ccap) { k += c; r++; } else dropped++; } }
+            E_I(misc, M_NK) = k; E_I(misc, M_NARB) = r;
+            if (dropped) E_I(misc, M_OVERFLOW) += dropped;
+        }
     }
     // joint preSteps: straight into the registers of the lanes that own the joints (SolveCtx, below).
     (void)dt;
