@@ -132,6 +132,7 @@ struct mgx_engine {
     hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long *d_queue = nullptr; unsigned *d_hand = nullptr, *d_deferred = nullptr;   // d_hand: tail, started, stats[2]
     unsigned hand_tail = 0, hand_started = 0, hand_epoch = 0;                                    // host mirrors of the monotonic counters
+    int cap_prims = 64;         // per-env worlds: primitives of the capacity world's draw list (mgx_engine_enable_env_worlds)
     unsigned dbg_poll_limit = 0, dbg_delay_every = 0, dbg_delay_sleeps = 0;                      // tests: forced hand-off failures (mgx_engine_debug_handoff; 0 = shipped behaviour)
     hipStream_t peek_stream = nullptr; unsigned long long *peek_q = nullptr; unsigned *peek_h = nullptr;   // mgx_engine_debug_handoff_peek's own stream and pinned buffers
     int timing = 0;             // 0 = off, n = bracket every n-th launch of each kind with HIP events
@@ -564,7 +565,9 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     // primitive sets as 32-bit words where no world the engine holds has more than 32 primitives (every Demo / Jitter / Colour / Layout /
     // Dynamics world; per-env worlds are sized by their capacity world and stay at 64): half the words of the pixel queue and of the
     // per-tile sets -- 8 KB of ClusterColour's 40 KB, a FIFTH rasteriser workgroup per CU for the mid-size worlds
-    const bool narrow = !e->env_worlds && e->h.n_prims <= 32 && !getenv("MGX_RASTER_WIDE");
+    // (per-env worlds, round 6: by their CAPACITY world's draw list -- MoveToCorner / MakeLine / FixColour / FindDupe Test* worlds have <= 32 primitives too;
+    // round 5 kept every per-env engine at 64-bit sets)
+    const bool narrow = (e->env_worlds ? e->cap_prims : e->h.n_prims) <= 32 && !getenv("MGX_RASTER_WIDE") && !(e->env_worlds && getenv("MGX_RASTER_WIDE_ENV"));
     e->rdev.narrow = narrow ? 1 : 0;
     const int mw = narrow ? 1 : 2;      // words per primitive set
     const int qcap_lds = (narrow && n_goals_w == 0 && n_blocks_w <= 1 && !getenv("MGX_QCAP_FULL")) ? QCAP_SMALL : QCAP;
@@ -1245,7 +1248,7 @@ int mgx_engine_enable_env_worlds(mgx_engine *e, const mgx_world *capacity_world)
     HIP_OK(hipDeviceSynchronize());
     (void)hipFree(e->d_step); (void)hipFree(e->d_raster);
     e->d_step = tab_s; e->d_raster = tab_r;
-    e->env_worlds = true;
+    e->env_worlds = true; e->cap_prims = cb.h.n_prims;
     e->step_stride = step_stride; e->raster_stride = raster_stride;
     e->tdev.words = tab_s; e->tdev.tmpl_stride_words = step_stride;
     e->rdev.words = tab_r; e->rdev.tmpl_stride_words = raster_stride;
@@ -1390,7 +1393,7 @@ int mgx_engine_set_env_variants(mgx_engine *e, int m, const int32_t *env_idx, co
     tm[ti++] = now();
     for (auto &U : uniq) {
         if (U.rc) return fail(U.rc == -2 ? MGX_ERR_CAPACITY : MGX_ERR_ARG, U.err);
-        if (U.blobs.h.n_prims > 64) return fail(MGX_ERR_CAPACITY, "world variant larger than the capacity world");
+        if (U.blobs.h.n_prims > (e->rdev.narrow ? 32 : 64)) return fail(MGX_ERR_CAPACITY, "world variant larger than the capacity world");
         if (state_rows_p(U.blobs.h) > e->rows_p || state_rows_f(U.blobs.h) > e->rows_f || state_rows_i(U.blobs.h) > e->rows_i)
             return fail(MGX_ERR_CAPACITY, "world variant needs more state rows than the capacity world");
     }
