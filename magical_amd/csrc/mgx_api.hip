@@ -572,6 +572,9 @@ static int configure_launch(mgx_engine *e, int step_words, int step_env_stride, 
     const int mw = narrow ? 1 : 2;      // words per primitive set
     const int qcap_lds = (narrow && n_goals_w == 0 && n_blocks_w <= 1 && !getenv("MGX_QCAP_FULL")) ? QCAP_SMALL : QCAP;
     e->rdev.qcap_lds = qcap_lds;
+    // phase T's wavefronts ahead of the CU's other rasteriser wavefronts: every world but the smallest ones (those of the 640-entry queue:
+    // MoveToCorner -0.4 %, the others +1.1 ... 2.7 %; MGX_RASTER_PRIO=0 / 1: never / always)
+    { const char *pv = getenv("MGX_RASTER_PRIO"); e->rdev.prio_t = pv ? (atoi(pv) != 0) : (qcap_lds != QCAP_SMALL); }
     // (the layout may grow when per-env worlds are enabled: the entries in use follow it, unless a test has set them)
     e->rdev.qcap = e->qcap_debug > 0 && e->qcap_debug < qcap_lds ? e->qcap_debug : qcap_lds;
     // per-tile (set + i32 base colour + u8 base index) + queue (set + i32 position | base index) + counters + overflow bitmap + phase E

@@ -35,6 +35,7 @@ struct RasterDev {
     int qcap;                      // queue entries in use (<= qcap_lds; tests shrink it to exercise the overflow rounds)
     int qcap_lds;                  // queue entries the LDS layout holds (<= QCAP; the host's choice by world, configure_launch)
     int ecap;                      // phase E records in use (<= ECAP; likewise)
+    int prio_t;                    // wavefronts in phase T run at s_setprio 2 (the host's choice by world, configure_launch)
     int narrow;                    // primitive sets are 32-bit words (every world loaded has <= 32 primitives): the uint32_t instantiations
 };
 
