@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-measure the round's profile set on the GPU box (run through gpurun from the repo root:
 #   gpurun --timeout 3600 -- 'bash tools/regen_profiles.sh r03'); results land in gpurun_out/final/, to be copied into profiles/.
-R=${1:-r05}
+R=${1:-r06}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/final; rm -rf $O; mkdir -p $O
@@ -51,7 +51,8 @@ cd $GRAFT_REPO_ROOT
 # the parity tables the GPU tests print (one-step error quantiles against the oracle and its replicas, drift against the perturbation
 # envelope, the fp64 build's absolute one-step error with its contact-coverage shares and offenders) and the long drift table
 timeout 1700 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "one_step or drift or contact_coverage or tracks_oracle" 2>&1 | grep -v "amdgpu.ids" > $O/${R}_gpu_parity_tables.txt
-timeout 1200 python tools/drift_table.py 2>&1 | grep -v "amdgpu.ids" > $O/${R}_pose_drift_vs_oracle_envelope.txt
+timeout 1200 python tools/drift_table.py --envs 32 --norm l2 2>&1 | grep -v "amdgpu.ids" > $O/${R}_pose_drift_f64_vs_oracle.txt
+timeout 1200 python tools/drift_table.py --envs 48 --norm linf 2>&1 | grep -v "amdgpu.ids" > $O/${R}_pose_drift_vs_oracle_envelope.txt
 python tools/kernel_resources.py > $O/${R}_kernel_resources.txt 2>> $O/err.txt
 timeout 1500 python tools/rollout_all_tasks.py --variant all --envs 4096 > $O/${R}_rollout_all_60_variants_4096x1gpu.jsonl 2>> $O/err.txt
 timeout 300 python tools/task_step_times.py 2>&1 | grep -v amdgpu > $O/${R}_task_step_times.txt
@@ -109,5 +110,8 @@ for T in 32 48 64 96 128; do for t in ClusterColour-TestAll-LoRes4E-v0 MatchRegi
 done; done > $O/${R}_reset_threads_pool.txt 2>&1
 timeout 600 python tools/window20_probe.py 2>&1 | grep -v amdgpu.ids > $O/${R}_window20_probe.txt
 timeout 600 python tools/raster_consistency_sweep.py 2>&1 | tail -20 > $O/${R}_raster_consistency_sweep_tail.txt
+# the fused hand-off under load: 8 fused engines on 8 streams (configs[4]'s shape), 20 000 env-steps each, shipped and with the failure paths forced
+{ timeout 900 python tools/dev/hang_hunt.py --fleet 20000 1024; FORCE=1 timeout 900 python tools/dev/hang_hunt.py --fleet 5000 1024; } 2>&1 | grep -v amdgpu.ids > $O/${R}_hang_hunt_fleet.txt
+timeout 900 python tools/fused_soak.py 2>&1 | grep -v amdgpu.ids > $O/${R}_fused_soak_600steps_all_tasks.txt
 head -30 $O/${R}_step_phase_cycles_mtc.txt
 ls $GRAFT_REPO_ROOT/gpurun_out/final $GRAFT_REPO_ROOT/gpurun_out/extra | head -80
