@@ -51,6 +51,9 @@ def main():
     ap.add_argument('--preproc', default='LoRes4E')
     ap.add_argument('--variant', default='Demo', help="'Demo', a Test* variant name, or 'all' for every registered variant of every task")
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--warmup-episodes', type=int, default=0, help='untimed whole episodes (with their auto-reset) before the timed one: the timed episode is then a '
+                    'steady-state one -- without, a variant\'s first episode also pays the process\'s first use of its kernels, the host pool\'s threads and the growth '
+                    'of the pinned staging buffers (per-env-world variants: 65-145 ms in the first episode-end step against 13-18 ms afterwards)')
     ap.add_argument('--concurrent', action='store_true', help='all tasks of the variant at once, one engine + HIP stream per task on every GPU '
                                                               '(magical_amd.distributed.TaskFleet), next to the sequential loop')
     args = ap.parse_args()
@@ -128,6 +131,9 @@ def main():
         tape = torch.as_tensor(tape, device=env.device)
         env.seed(args.seed + lo)      # env k of the job draws from RandomState(seed + k) whatever the number of GPUs
         env.reset()
+        for _ in range(args.warmup_episodes):
+            for s in range(T):
+                env.step(tape[s])          # (the last step auto-resets: the timed episode starts from that reset)
         if world > 1:
             dist.barrier()
         sync(); t0 = time.perf_counter()
@@ -140,7 +146,7 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=env.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
         if rank == 0:
-            print(json.dumps({'task': name, 'n_envs': args.envs, 'n_gpus': world, 'episode_steps': T,
+            print(json.dumps({'task': name, 'n_envs': args.envs, 'n_gpus': world, 'episode_steps': T, 'warmup_episodes': args.warmup_episodes,
                               'env_steps_per_s': args.envs * T / dt, 'mean_score': float(scores.mean().item()),
                               'frac_solved': float((scores > 0.5).double().mean().item()),
                               **({'stub_scores_crc': int(__import__('zlib').crc32(np.ascontiguousarray(scores.numpy()).tobytes())), 'gathered_rows': int(scores.shape[0])} if stub else {})}), flush=True)
