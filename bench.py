@@ -564,12 +564,15 @@ def measure(args, rank, world, device):
         # (profiles/, produced by tools/pmc_summary.py; FETCH_SIZE doubled per MI355X_MICROARCH.md); default workload only
         from tools.csrc_hash import csrc_sha16
         built_from = csrc_sha16(ROOT)            # (magical_amd._native rebuilds the library whenever a source is newer: these ARE its sources)
-        key = {TASK: 'mtc_lores4e', 'ClusterColour-Demo-LoRes4E-v0': 'cc_lores4e'}.get(args.task)
+        # (counter passes are kept for the headline workload, ClusterColour, and -- round 6 -- the two secondary workloads of the driver's line:
+        # the all-fp64 build and the state-only engine)
+        key = {(TASK, 'f32'): 'mtc_lores4e', ('ClusterColour-Demo-LoRes4E-v0', 'f32'): 'cc_lores4e', (TASK, 'f64'): 'mtc_lores4e_f64',
+               ('MoveToCorner-Demo-v0', 'f32'): 'mtc_state_only'}.get((args.task, args.dtype))
 
         def committed_profile(kind):
             """(dict, source note) of the newest profiles/rNN_pmc_<kind>_<workload>.json whose stamp equals the hash of the kernel sources in
             use; (None, why not) otherwise -- a counter profile of other sources says nothing about the kernels this run timed."""
-            if not (key and n == N_ENVS and args.dtype == 'f32'):
+            if not (key and n == N_ENVS):
                 return None, 'no counter passes are kept for this workload'
             why = f'no profiles/rNN_pmc_{kind}_{key}.json committed'
             for rnd in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):

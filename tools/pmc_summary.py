@@ -21,6 +21,8 @@ def per_kernel(d):
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 res = {}
 for k in ('k_raster', 'k_step'):
+    if not fetch[k] or not write[k]:
+        continue                      # (a state-only workload launches no rasteriser)
     fr, wr = statistics.median(fetch[k]), statistics.median(write[k])
     res[k] = {'launches_fetch_pass': len(fetch[k]), 'launches_write_pass': len(write[k]),
               'FETCH_SIZE_raw_bytes_median': fr, 'FETCH_SIZE_x2_bytes': 2 * fr, 'WRITE_SIZE_bytes_median': wr,

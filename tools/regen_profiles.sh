@@ -35,6 +35,14 @@ for t in mtc cc; do
   done
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pmc_${t}_FETCH_SIZE /tmp/pmc_${t}_WRITE_SIZE > $O/${R}_pmc_traffic_${t}_lores4e.json
 done
+# ... and of the driver's line's two other workloads (round 6): the all-fp64 build, the state-only engine
+for t in mtc_lores4e_f64 mtc_state_only; do
+  extra="--dtype f64"; [ $t = mtc_state_only ] && extra="--task MoveToCorner-Demo-v0"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    MGX_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $c -f csv -d /tmp/pmc_${t}_$c -o run -- $B $NS --steps 100 $extra > /dev/null 2>&1
+  done
+  python $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pmc_${t}_FETCH_SIZE /tmp/pmc_${t}_WRITE_SIZE > $O/${R}_pmc_traffic_${t}.json
+done
 # what bounds the kernels: SQ counters, three passes of eight (tools/pmc_alu_summary.py), kernels one after the other
 PA=SQ_WAVES,SQ_WAVE_CYCLES,SQ_BUSY_CU_CYCLES,SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_INSTS_VALU
 PB=SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_INSTS_VMEM,SQ_INSTS_FLAT_FLATSEG,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_ACTIVE_INST_LDS,SQ_ACTIVE_INST_SCA
@@ -46,6 +54,14 @@ for t in mtc cc; do
     MGX_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc ${set//,/ } -f csv -d /tmp/alu_${t}_$p -o run -- $B --no-cpu-baseline --no-secondary --steps 60 --task $task > /dev/null 2>&1
   done
   python $GRAFT_REPO_ROOT/tools/pmc_alu_summary.py /tmp/alu_${t}_A /tmp/alu_${t}_B /tmp/alu_${t}_C > $O/${R}_pmc_alu_${t}_lores4e.json
+done
+for t in mtc_lores4e_f64 mtc_state_only; do
+  extra="--dtype f64"; [ $t = mtc_state_only ] && extra="--task MoveToCorner-Demo-v0"
+  for p in A B C; do
+    eval set=\$P$p
+    MGX_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc ${set//,/ } -f csv -d /tmp/alu_${t}_$p -o run -- $B --no-cpu-baseline --no-secondary --steps 60 $extra > /dev/null 2>&1
+  done
+  python $GRAFT_REPO_ROOT/tools/pmc_alu_summary.py /tmp/alu_${t}_A /tmp/alu_${t}_B /tmp/alu_${t}_C > $O/${R}_pmc_alu_${t}.json
 done
 cd $GRAFT_REPO_ROOT
 # the parity tables the GPU tests print (one-step error quantiles against the oracle and its replicas, drift against the perturbation
