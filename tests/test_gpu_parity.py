@@ -433,6 +433,40 @@ def test_f64_drift_meets_the_substep_target(task):
     env.close()
 
 
+def test_overflowing_working_set_does_not_depend_on_lanes_per_env():
+    """include/mgx.h: "the result does not depend on lanes_per_env" -- also where an env's touching pairs / contacts overflow its fixed-size
+    working set (counted in state_i[2], warned about by the host).  Round 5 handed manifold slots out by an LDS counter, so WHICH pairs kept
+    one depended on lane order (round-5 advisor); since round 6 they go out in pair order (ph_narrow) and the arbiters' offsets are prefix sums
+    with the sequential rule kept under overflow (ph_arbiters_joints).  ClusterColour's eight blocks are heaped onto one spot (set_bodies), so
+    that more pairs touch than there are cache slots; three env-steps at 16 / 32 / 64 lanes per env: same bits."""
+    import torch
+    n, t = 64, 3
+    tape = _tape(29, t, n)
+    outs = {}
+    for L in (16, 32, 64):
+        env = _make('ClusterColour-Demo-v0', n, lanes_per_env=L)
+        env.seed(1); env.reset()
+        b = env.get_bodies()
+        rs = np.random.RandomState(3)
+        blocks = range(1, 9)          # (ClusterColour-Demo: body 0 is the static one, 1..8 the blocks in entity order, then robot, control, eyes, fingers)
+        for i, k in enumerate(blocks):
+            b[:, k, 0] = -0.2 + 0.02 * (i % 3) + rs.uniform(-0.005, 0.005, n)          # (all eight on one spot: the two stars' twelve parts alone
+            b[:, k, 1] = 0.2 + 0.02 * (i // 3) + rs.uniform(-0.005, 0.005, n)          # make more touching shape pairs than there are cache slots)
+            b[:, k, 3:] = 0.0
+        env.set_bodies(b)
+        for s in range(t):
+            env.step(tape[s])
+        outs[L] = (env.state_p.clone(), env.state_f.clone(), env.state_i.clone())
+        env.close()
+    ovf = int((outs[16][2][2] > 0).sum())
+    print(f'envs whose working set overflowed: {ovf} of {n}')
+    assert ovf > 0, 'the heap must overflow the working set for this test to mean anything'
+    raw = lambda x: x.contiguous().view(torch.uint8)          # (bytes: a NaN out of such a heap must compare equal to itself)
+    for L in (32, 64):
+        for a, c in zip(outs[16], outs[L]):
+            assert torch.equal(raw(a), raw(c)), L
+
+
 def test_determinism_and_lockstep():
     """Same tape twice -> identical bytes; identical per-env tapes -> identical envs."""
     import torch
